@@ -1,0 +1,225 @@
+"""TEST INFRASTRUCTURE -- generate tests/golden/*.npz from the REFERENCE's own classes.
+
+Run in the build container only (needs /root/reference):   python -m oracle.gen_golden
+For every case it (1) runs the reference (imported through oracle/harness.py), (2) runs
+the oracle restatement (oracle/torch_ref.py) on the same procedural weights and inputs,
+(3) asserts they agree to 1e-5, and (4) stores the *reference's* outputs.  Only data is
+written (inputs are procedural, so fixtures hold outputs and the numpy permutation).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import harness, procedural as P, torch_ref as O   # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+ARGS = types.SimpleNamespace(shufflerank_theta=0.05)
+CLIP = dict(T=8, H=64, W=64)
+
+
+def _init_pg(rank=0, world=1, port=29531):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+
+
+def build(ns, kind, net, distributed, K=64):
+    S, M = (ns.simclr, ns.moco) if hasattr(ns, 'simclr') else (ns, ns)
+    if kind == 'simclr_naked':
+        return S.SimCLR_Naked(net, 128, 0.07, distributed)
+    if kind == 'simclr_timeseriesv4':
+        return S.SimCLR_TimeSeriesV4(net, 128, 0.07, distributed, args=ARGS)
+    if kind == 'moco_naked':
+        return M.MoCo_Naked(net, 128, K, 0.999, 0.07, distributed)
+    if kind == 'moco_timeseriesv4':
+        return M.MoCo_TimeSeriesV4(net, 128, K, 0.999, 0.07, distributed, args=ARGS)
+    raise KeyError(kind)
+
+
+def grad_summary(model):
+    """{canonical key: [sum|g|, sum g]} for every trainable tensor (compact gradient pin)."""
+    sd = model.state_dict(keep_vars=True)
+    out = {}
+    for key in sorted(P.canonical_groups(model)):
+        t = sd[key]
+        if getattr(t, 'grad', None) is not None:
+            g = t.grad.double()
+            out[key] = np.array([g.abs().sum().item(), g.sum().item()])
+    return out
+
+
+def param_checksum(model):
+    sd = model.state_dict()
+    return {k: np.array([sd[k].double().abs().sum().item(), sd[k].double().sum().item()])
+            for k in sorted(P.canonical_groups(model)) if sd[k].dtype.is_floating_point}
+
+
+def run_model(model, block, steps, np_seed, lr=0.003):
+    """`steps` iterations of pretrain.py:394-451 on the same block.  Records step-0 outputs,
+    step-0 gradients, and the parameter checksum after the last step."""
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD([{'params': [p]} for p in params], lr=lr, weight_decay=1e-4, momentum=0.9)
+    np.random.seed(np_seed)
+    rec = {}
+    for it in range(steps):
+        state = np.random.get_state()
+        ret = model(block)
+        after = np.random.get_state()
+        loss = 0
+        if 'clip_contrast_loss' in ret:
+            loss = ret['clip_contrast_loss']
+        for key in ret:
+            if 'loss' in key and 'clip' not in key:
+                loss = loss + ret[key]
+        opt.zero_grad()
+        loss.backward()
+        if it in (0, steps - 1):
+            tag = 'first' if it == 0 else 'last'
+            if block.shape[1] == 3:                      # the permutation the forward just drew
+                np.random.set_state(state)
+                rec[f'{tag}/perm'] = np.array([np.random.permutation(2) for _ in range(block.shape[0])])
+                np.random.set_state(after)
+            for k, v in ret.items():
+                rec[f'{tag}/out/' + k] = v.detach().numpy().copy()
+            rec[f'{tag}/total_loss'] = np.array(float(loss))
+            for k, v in grad_summary(model).items():
+                rec[f'{tag}/grad/' + k] = v
+        opt.step()
+        rec['loss_step%d' % it] = np.array(float(loss))
+    for k, v in param_checksum(model).items():
+        rec['param/' + k] = v
+    if hasattr(model, 'queue_ptr'):
+        rec['queue_ptr'] = model.queue_ptr.numpy().copy()
+        rec['queue_cols'] = model.queue[:, :16].numpy().copy()
+    return rec
+
+
+def compare(a, b, tag, tol=5e-4):
+    assert a.keys() == b.keys(), (tag, set(a) ^ set(b))
+    worst = 0.0
+    for k in a:
+        x, y = np.asarray(a[k], dtype=np.float64), np.asarray(b[k], dtype=np.float64)
+        assert x.shape == y.shape, (tag, k, x.shape, y.shape)
+        err = float(np.max(np.abs(x - y) / (1.0 + np.abs(x)))) if x.size else 0.0
+        worst = max(worst, err)
+        assert err < tol, (tag, k, err)
+    return worst
+
+
+def case_backbones(ref):
+    rec = {}
+    for net in ('s3dg', 'r21d', 'r3d', 'r50'):
+        x = P.procedural_clips(2, 1, **CLIP)[:, 0]
+        outs = []
+        for sel in (ref.select_backbone, O.select_backbone):
+            m, _ = sel(net)
+            P.procedural_init(m).train()
+            y = m(x)
+            outs.append(y)
+        err = float((outs[0] - outs[1]).abs().max())
+        assert err < 1e-5, (net, err)
+        rec[net + '/feat'] = outs[0].detach().numpy()
+        rec[net + '/pooled'] = outs[0].mean(dim=(2, 3, 4)).detach().numpy()
+        print('backbone', net, tuple(outs[0].shape), 'ref-vs-oracle', err)
+    np.savez_compressed(os.path.join(GOLD, 'backbones.npz'), **rec)
+
+
+def case_models(ref):
+    _init_pg()
+    for kind, net, B in (('simclr_naked', 's3dg', 4), ('simclr_timeseriesv4', 's3dg', 4),
+                         ('simclr_timeseriesv4', 'r21d', 2), ('simclr_naked', 'r3d', 2),
+                         ('moco_naked', 's3dg', 4), ('moco_timeseriesv4', 's3dg', 4)):
+        V = 2 if kind.endswith('naked') else 3
+        block = P.procedural_clips(B, V, **CLIP)
+        # SimCLR_Naked in the reference only works on the distributed path (D2): world_size 1 gloo
+        distributed = True
+        recs = []
+        for ns in (ref, O):
+            torch.manual_seed(0)
+            m = build(ns, kind, net, distributed)
+            P.procedural_init(m)
+            recs.append(run_model(m, block, steps=3 if 'moco' in kind else 2, np_seed=1234))
+        err = compare(recs[0], recs[1], (kind, net))
+        # the oracle's non-distributed path must equal the distributed one at world_size 1
+        torch.manual_seed(0)
+        m = build(O, kind, net, False)
+        P.procedural_init(m)
+        err2 = compare(recs[0], run_model(m, block, steps=3 if 'moco' in kind else 2, np_seed=1234),
+                       (kind, net, 'nondist'))
+        np.savez_compressed(os.path.join(GOLD, f'model_{kind}_{net}.npz'), **recs[0])
+        print('model', kind, net, 'B', B, 'ref-vs-oracle', err, 'nondist', err2,
+              'loss', float(recs[0]['first/total_loss']), float(recs[0]['last/total_loss']))
+
+
+def _loss_worker(rank, world, q, use_ref):
+    _init_pg(rank, world, port=29541 + (1 if use_ref else 0))
+    ns = harness.load_reference() if use_ref else O
+    S = ns.simclr if use_ref else ns
+    N, B = 8, 8 // world
+    clip = P.procedural_unit_features(N, 2, 128, seed=11)[rank * B:(rank + 1) * B].clone().requires_grad_(True)
+    ser = P.procedural_unit_features(N, 2, 2, 64, seed=13)[rank * B:(rank + 1) * B].clone().requires_grad_(True)
+    rk = P.procedural_unit_features(N, 2, 2, 64, seed=17)[rank * B:(rank + 1) * B].clone().requires_grad_(True)
+    m = S.SimCLR_TimeSeriesV4.__new__(S.SimCLR_TimeSeriesV4)
+    torch.nn.Module.__init__(m)
+    m.distributed, m.T, m.aligned_T, m.n_series, m.series_dim, m.dim, m.args = world > 1 or use_ref, 0.07, 0.07, 2, 64, 128, ARGS
+    m.criterion = torch.nn.CrossEntropyLoss()
+    out = {}
+    r1 = m.calc_clip_contrast_loss(clip, 2)
+    r2 = m.calc_tc_contrast_loss(ser)
+    r3 = m.calc_ranking_loss(rk, 2, 'rank_', 0.5)
+    (r1['clip_contrast_loss'] + r2['tc_contrast_loss'] + r3['rank_margin_contrast_loss']).backward()
+    for r in (r1, r2, r3):
+        for k, v in r.items():
+            out[k] = v.detach().numpy().copy()
+    out['grad_clip'], out['grad_ser'], out['grad_rank'] = clip.grad.numpy().copy(), ser.grad.numpy().copy(), rk.grad.numpy().copy()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def case_losses():
+    """Loss-only fixtures from procedural unit features at world_size 1 and 2 (pins GatherLayer
+    semantics: per-rank logits, losses and per-rank gradients)."""
+    ctx = mp.get_context('spawn')
+    rec = {}
+    for world in (1, 2):
+        res = {}
+        for use_ref in (True, False):
+            q = ctx.Queue()
+            procs = [ctx.Process(target=_loss_worker, args=(r, world, q, use_ref)) for r in range(world)]
+            [p.start() for p in procs]
+            got = dict(q.get() for _ in range(world))
+            [p.join() for p in procs]
+            res[use_ref] = got
+        for r in range(world):
+            err = compare(res[True][r], res[False][r], ('loss', world, r))
+            for k, v in res[True][r].items():
+                rec[f'w{world}/r{r}/{k}'] = v
+            print('losses world', world, 'rank', r, 'ref-vs-oracle', err)
+    np.savez_compressed(os.path.join(GOLD, 'losses.npz'), **rec)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ['backbones', 'models', 'losses']
+    if 'losses' in which:
+        case_losses()
+    ref = harness.load_reference()
+    if 'backbones' in which:
+        case_backbones(ref)
+    if 'models' in which:
+        case_models(ref)
+
+
+if __name__ == '__main__':
+    main()
