@@ -725,8 +725,8 @@ class MoCo_TimeSeriesV4(_MoCoBase):
         """moco.py:404-424."""
         B, s, sd = q.shape
         neg = queue.clone().detach().T.contiguous().view(self.K, s, sd)
-        pos_l = torch.matmul(q, k.transpose(2, 1)).mean(dim=(1, 2)).unsqueeze(1)
-        neg_l = torch.matmul(q.unsqueeze(1), neg.transpose(2, 1)).mean(dim=(2, 3))
+        pos_l = torch.matmul(q, k.transpose(2, 1).contiguous()).mean(dim=(1, 2)).unsqueeze(1)
+        neg_l = torch.matmul(q.unsqueeze(1), neg.transpose(2, 1).contiguous()).mean(dim=(2, 3))
         return self._infonce(pos_l, neg_l, self.aligned_T, prefix)
 
     def calc_clip_contrast_loss(self, q, k, queue, prefix='clip_'):
