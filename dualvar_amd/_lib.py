@@ -1,0 +1,126 @@
+"""ctypes binding of libdualvar_hip.so (include/dualvar_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or the device is not a
+gfx950, every compute entry point raises.  The product never routes through PyTorch kernels
+or the CPU oracle."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdualvar_hip.so')
+
+DV_F32, DV_BF16 = 0, 1
+DV_BIAS, DV_RELU, DV_SIGMOID, DV_ACCUM, DV_STATS, DV_NO_RELU_MASK = 1, 2, 4, 8, 16, 32
+
+_ERR = {-1: 'DV_EINVAL (inconsistent shapes / unsupported parameter)',
+        -2: 'DV_EALIGN (pointer or pitch misaligned)',
+        -3: 'DV_EUNSUPPORTED'}
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'dtype', 'N', 'Ti', 'Hi', 'Wi', 'Cin', 'To', 'Ho', 'Wo', 'Cout', 'kt', 'kh', 'kw', 'st', 'sh', 'sw',
+        'pt', 'ph', 'pw', 'cin_pitch', 'cout_pitch', 'ldx', 'ldy', 'flags')]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'dtype', 'N', 'Ti', 'Hi', 'Wi', 'C', 'To', 'Ho', 'Wo', 'kt', 'kh', 'kw', 'st', 'sh', 'sw',
+        'pt', 'ph', 'pw', 'ldx', 'ldy')]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [('src_off', C.c_int64), ('dst_off', C.c_int64), ('Cout', C.c_int32), ('Cin', C.c_int32),
+                ('taps', C.c_int32), ('cin_pitch', C.c_int32), ('cout_pitch', C.c_int32), ('_pad', C.c_int32)]
+
+
+P, I32, I64, F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+CD, PD = C.POINTER(ConvDesc), C.POINTER(PoolDesc)
+
+# name -> argtypes, exactly as declared in include/dualvar_hip.h
+SIGNATURES = {
+    'dv_abi_version': [],
+    'dv_check_device': [],
+    'dv_conv3d_stat_tiles': [CD],
+    'dv_conv3d_fwd': [CD, P, P, P, P, P, P],
+    'dv_conv3d_dgrad': [CD, P, P, P, P],
+    'dv_conv3d_wgrad': [CD, P, P, P, P],
+    'dv_pack_dgrad_weights': [I32, P, P, P, P, I32, P],
+    'dv_cast_arena': [I32, P, P, I64, P],
+    'dv_ingest_ncdhw': [I32, P, P, I32, I32, I32, I32, I32, I64, I32, P, P, P, I32, P],
+    'dv_bn_reduce_stats': [P, I32, I32, I64, I32, P, P],
+    'dv_bn_finalize': [P, I32, I32, P, P, F, F, P, P, P, P, P, P, P],
+    'dv_bn_apply': [I32, P, I32, P, P, P, I32, P, I32, I64, I32, I32, P],
+    'dv_bn_bwd_blocks': [I64, I32],
+    'dv_bn_bwd_reduce': [I32, P, I32, P, I32, P, I32, P, P, I64, I32, I32, P, P],
+    'dv_bn_bwd_finalize': [P, I32, I32, P, P],
+    'dv_bn_bwd_apply': [I32, P, I32, P, I32, P, I32, P, P, P, P, P, F, P, P, P, I32, P, I32, I64, I32, I32, P],
+    'dv_maxpool3d_fwd': [PD, P, P, P, P],
+    'dv_maxpool3d_bwd': [PD, P, P, P, I32, P],
+    'dv_spatial_mean': [I32, P, I32, I32, I32, I32, P, P],
+    'dv_spatial_mean_bwd': [I32, P, I32, I32, I32, P, I32, I32, P],
+    'dv_gate_scale': [I32, P, I32, P, I32, I32, I32, P, I32, P],
+    'dv_gate_bwd_reduce': [I32, P, I32, P, I32, P, I32, I32, I32, P, P],
+    'dv_gate_bwd_apply': [I32, P, I32, P, P, I32, I32, I32, P, I32, I32, P],
+    'dv_colsum_f32': [P, I32, I32, I32, P, P],
+    'dv_l2norm_fwd': [P, I32, I32, F, P, P, P],
+    'dv_l2norm_bwd': [P, P, P, I32, I32, P, P],
+    'dv_relu_bwd_f32': [P, P, I64, P, P],
+    'dv_mean_f32': [P, I32, P, P],
+    'dv_ntxent_fwd': [P, P, I32, I32, I32, I32, I32, F, P, P, P, P, P],
+    'dv_infonce_fwd': [P, P, P, I32, I32, I32, F, P, P, P, P, P, P],
+    'dv_rank_margin': [P, I32, I32, I32, F, F, F, P, P, P, P, P],
+    'dv_gemm_f32': [I32, I32, I32, P, I64, I64, P, I64, I64, P, I64, F, I32, P],
+    'dv_group_mean_f32': [P, I32, I32, I32, P, P],
+    'dv_group_mean_bwd_f32': [P, I32, I32, I32, P, P],
+    'dv_sgd_momentum': [P, P, P, I64, F, F, F, F, I32, P, P],
+    'dv_ema': [P, P, I64, F, I32, P, P],
+}
+
+_lib = None
+
+
+class DualVarHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DualVarHipError(
+            f'{LIB_PATH} is missing: run `python -m dualvar_amd.build` (hipcc --offload-arch=gfx950). '
+            'dualvar_amd has no CPU or PyTorch fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI and this table disagree
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if lib.dv_abi_version() != 1:
+        raise DualVarHipError('libdualvar_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+_device_ok = False
+
+
+def require_device():
+    """Fail loudly unless a gfx950 GPU is current."""
+    global _device_ok
+    if _device_ok:
+        return
+    import torch
+    if not torch.cuda.is_available():
+        raise DualVarHipError('dualvar_amd needs an MI355X (gfx950) GPU; none is visible and there is no fallback path')
+    rc = load().dv_check_device()
+    if rc != 0:
+        raise DualVarHipError('current device is not gfx950; the kernels are built for MI355X only')
+    _device_ok = True
+
+
+def check(rc, name):
+    if rc != 0:
+        raise DualVarHipError(f'{name} failed: {_ERR.get(rc, "hipError_t %d" % rc)}')

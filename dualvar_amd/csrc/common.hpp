@@ -1,0 +1,98 @@
+// Shared device/host helpers for the gfx950 kernels of libdualvar_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dualvar_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+typedef __bf16 bf16_t;
+
+#define DV_WAVE 64
+
+// ------------------------------------------------------------------ fast unsigned division
+// q = n / d for 0 <= n < 2^31, d >= 1:  q = (umulhi(n, mul) + n) >> shr
+struct FastDiv {
+  uint32_t mul, shr, d, _pad;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shr = s;
+  f.mul = (uint32_t)((((1ull << s) - d) << 32) / d + 1);
+  f._pad = 0;
+  return f;
+}
+__device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) {
+  return (__umulhi(n, f.mul) + n) >> f.shr;
+}
+__device__ __forceinline__ void fd_divmod(uint32_t n, const FastDiv& f, uint32_t& q, uint32_t& r) {
+  q = fd_div(n, f);
+  r = n - q * f.d;
+}
+
+// ------------------------------------------------------------------ dtype traits
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int VEC = 4;  // elements per 16 bytes
+  static __device__ __forceinline__ float to_f(float v) { return v; }
+  static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct DT<bf16_t> {
+  static constexpr int VEC = 8;
+  static __device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
+  static __device__ __forceinline__ bf16_t from_f(float v) { return (bf16_t)v; }
+};
+
+// 16-byte vector of T, unpacked to floats and back
+template <typename T> struct Pack16;
+template <> struct Pack16<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+template <> struct Pack16<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+static inline int dv_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,666 @@
+// 3-D convolution (forward, data gradient, weight gradient) as implicit GEMM on the gfx950
+// matrix cores.  NDHWC activations, K-contiguous packed weights; see include/dualvar_hip.h.
+//
+// One gather routine serves all three kernels: a tile of the (virtual) im2col matrix
+//     A[row m][k = tap*CP + c]
+// is built from 16-byte (8-byte for the 3->4-channel stem) vectors, each lying inside one
+// tap.  fwd/dgrad read it K-contiguous (ds_read_b128); wgrad reads the same kind of tile
+// transposed (ds_read_b64_tr_b16 for bf16, plain b32 for f32).
+//
+//   fwd  : Y[m][n]  = sum_k A_x [m][k] * Wf[n][k]            m = output position
+//   dgrad: dX[m][c] = sum_k A_dy[m][k] * Wd[c][k]            m = input position, k=(tap,n)
+//   wgrad: dW[n][j] = sum_m dY[m][n]  * A_x[m][j]            j = (tap,c)
+//
+// MFMA: v_mfma_f32_32x32x16_bf16 (bf16 storage) / v_mfma_f32_32x32x2_f32 (f32 parity mode);
+// both share the 32x32 C/D layout  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#include "common.hpp"
+
+namespace {
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct ConvGeom {
+  // "row space" (what m enumerates) and "source space" (the tensor the gather reads)
+  int rT, rH, rW;        // row-space dims
+  int sT, sH, sW;        // source dims
+  int kt, kh, kw;
+  int st, sh, sw;        // strides (conv strides)
+  int pt, ph, pw;
+  int CP;                // channel pitch used to decode k -> (tap, c)
+  int Ktot;              // kt*kh*kw*CP
+  FastDiv dW, dH, dT;    // fast division by rW, rH, rT
+};
+
+struct ConvArgs {
+  const void* src;       // gathered tensor (x for fwd, dy for dgrad)
+  const void* w;         // [N rows][Ktot] K-contiguous, pitch ldw
+  void* out;             // [M][ldo]
+  const float* bias;
+  float* stats;          // [m_tiles][2][N]
+  int M, N, NP;          // rows, real cols, cols to write (zeros beyond N)
+  int lds_, ldo, ldw;    // pitches in elements (src, out, weights)
+  int ntn;               // number of N tiles
+  int flags;
+  ConvGeom g;
+};
+
+template <int BYTES> struct VecB;
+template <> struct VecB<16> { typedef uint4 type; static __device__ __forceinline__ uint4 zero() { return make_uint4(0, 0, 0, 0); } };
+template <> struct VecB<8> { typedef uint2 type; static __device__ __forceinline__ uint2 zero() { return make_uint2(0, 0); } };
+
+// Per-thread cursor over the k axis of the im2col matrix for one fixed vector slot.
+struct KCursor {
+  int c, dt, dh, dw;
+  __device__ __forceinline__ void init(int k0, const ConvGeom& g) {
+    int tap = k0 / g.CP;
+    c = k0 - tap * g.CP;
+    dw = tap % g.kw;
+    int t2 = tap / g.kw;
+    dh = t2 % g.kh;
+    dt = t2 / g.kh;
+  }
+  __device__ __forceinline__ void advance(int step, const ConvGeom& g) {
+    c += step;
+    while (c >= g.CP) {
+      c -= g.CP;
+      if (++dw == g.kw) {
+        dw = 0;
+        if (++dh == g.kh) { dh = 0; ++dt; }
+      }
+    }
+  }
+};
+
+// Row of the im2col matrix: decoded once per thread.
+struct RowPos {
+  int base;      // n * sT*sH*sW
+  int t0, h0, w0;
+  bool valid;
+};
+
+template <int MODE>
+__device__ __forceinline__ RowPos decode_row(uint32_t m, int M, const ConvGeom& g) {
+  RowPos r;
+  r.valid = (int)m < M;
+  uint32_t q, wo, ho, to, n;
+  fd_divmod(m, g.dW, q, wo);
+  fd_divmod(q, g.dH, q, ho);
+  fd_divmod(q, g.dT, n, to);
+  r.base = (int)n * g.sT * g.sH * g.sW;
+  if (MODE == MODE_FWD) {
+    r.t0 = (int)to * g.st - g.pt;
+    r.h0 = (int)ho * g.sh - g.ph;
+    r.w0 = (int)wo * g.sw - g.pw;
+  } else {
+    r.t0 = (int)to + g.pt;
+    r.h0 = (int)ho + g.ph;
+    r.w0 = (int)wo + g.pw;
+  }
+  return r;
+}
+
+// source position (in elements/ld units) of (row, tap) or -1
+template <int MODE>
+__device__ __forceinline__ int src_pos(const RowPos& r, const KCursor& k, const ConvGeom& g) {
+  int t, h, w;
+  if (MODE == MODE_FWD) {
+    t = r.t0 + k.dt; h = r.h0 + k.dh; w = r.w0 + k.dw;
+  } else {
+    t = r.t0 - k.dt; h = r.h0 - k.dh; w = r.w0 - k.dw;
+    // strides are 1 or 2 (checked on the host)
+    if (((t & (g.st - 1)) | (h & (g.sh - 1)) | (w & (g.sw - 1))) != 0) return -1;
+    if ((t | h | w) < 0) return -1;
+    t >>= (g.st - 1); h >>= (g.sh - 1); w >>= (g.sw - 1);
+  }
+  bool ok = r.valid && (k.dt < g.kt) && (unsigned)t < (unsigned)g.sT && (unsigned)h < (unsigned)g.sH &&
+            (unsigned)w < (unsigned)g.sW;
+  return ok ? r.base + (t * g.sH + h) * g.sW + w : -1;
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  // one K-tile = 64 bytes = 32 bf16 per row: two 32x32x16 steps
+  static __device__ __forceinline__ void tile(const unsigned char* a_row, const unsigned char* b_row, int h,
+                                               f32x16& acc) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a = *reinterpret_cast<const bf16x8*>(a_row + (2 * ks + h) * 16);
+      bf16x8 b = *reinterpret_cast<const bf16x8*>(b_row + (2 * ks + h) * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+  }
+};
+template <> struct Mma<float> {
+  // one K-tile = 64 bytes = 16 f32 per row: eight 32x32x2 steps
+  static __device__ __forceinline__ void tile(const unsigned char* a_row, const unsigned char* b_row, int h,
+                                               f32x16& acc) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(a_row + gq * 16);
+      f32x4 b = *reinterpret_cast<const f32x4*>(b_row + gq * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a.y : a.x, h ? b.y : b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a.w : a.z, h ? b.w : b.z, acc, 0, 0, 0);
+    }
+  }
+};
+
+__device__ __forceinline__ float act_apply(float v, int flags) {
+  if (flags & DV_RELU) v = fmaxf(v, 0.f);
+  if (flags & DV_SIGMOID) v = 1.f / (1.f + __expf(-v));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// fwd / dgrad kernel.  256 threads = 4 waves arranged WAVES_M x WAVES_N over a BM x BN tile.
+// LDS rows hold 64 bytes of K, padded to 80 so that ds_read_b128 fragments are conflict free.
+template <typename T, int MODE, int GVB, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
+  constexpr int ROWB = 64, PITCH = 80;
+  constexpr int BKE = ROWB / (int)sizeof(T);
+  constexpr int GV = GVB / (int)sizeof(T);
+  constexpr int VPR = ROWB / GVB;           // vectors per row (4 or 8)
+  constexpr int RPP = 256 / VPR;            // rows per pass (64 or 32)
+  constexpr int A_PASSES = BM / RPP;
+  constexpr int B_PASSES = (BN + RPP - 1) / RPP;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(TM >= 1 && TN >= 1, "tile");
+  typedef typename VecB<GVB>::type vec_t;
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * PITCH];
+  constexpr int BUFB = (BM + BN) * PITCH;   // A tile then B tile, twice
+
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int tile_n = blockIdx.x % a.ntn, tile_m = blockIdx.x / a.ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+
+  const int vslot = tid % VPR, vrow = tid / VPR;
+  const T* src = reinterpret_cast<const T*>(a.src);
+  const T* wgt = reinterpret_cast<const T*>(a.w);
+
+  RowPos rows[A_PASSES];
+#pragma unroll
+  for (int p = 0; p < A_PASSES; ++p) rows[p] = decode_row<MODE>((uint32_t)(m0 + vrow + p * RPP), a.M, g);
+  KCursor kc;
+  kc.init(vslot * GV, g);
+
+  const int nk = (g.Ktot + BKE - 1) / BKE;
+  vec_t ra[A_PASSES], rb[B_PASSES];
+
+  auto gload = [&](int kt_idx) {
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      int pos = src_pos<MODE>(rows[p], kc, g);
+      ra[p] = pos >= 0 ? *reinterpret_cast<const vec_t*>(src + (size_t)pos * a.lds_ + kc.c) : VecB<GVB>::zero();
+    }
+    const int kk = kt_idx * BKE + vslot * GV;
+#pragma unroll
+    for (int p = 0; p < B_PASSES; ++p) {
+      int r = vrow + p * RPP;
+      int n = n0 + r;
+      bool ok = (r < BN) && (n < a.N) && (kk < g.Ktot);
+      rb[p] = ok ? *reinterpret_cast<const vec_t*>(wgt + (size_t)n * a.ldw + kk) : VecB<GVB>::zero();
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p)
+      *reinterpret_cast<vec_t*>(smem + buf * BUFB + (vrow + p * RPP) * PITCH + vslot * GVB) = ra[p];
+#pragma unroll
+    for (int p = 0; p < B_PASSES; ++p) {
+      int r = vrow + p * RPP;
+      if (r < BN) *reinterpret_cast<vec_t*>(smem + buf * BUFB + (BM + r) * PITCH + vslot * GVB) = rb[p];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt_idx = 0; kt_idx < nk; ++kt_idx) {
+    const int cur = kt_idx & 1;
+    if (kt_idx + 1 < nk) {
+      kc.advance(BKE, g);
+      gload(kt_idx + 1);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        Mma<T>::tile(smem + cur * BUFB + (wm0 + i * 32 + l31) * PITCH,
+                     smem + cur * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, acc[i][j]);
+    if (kt_idx + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue
+  T* out = reinterpret_cast<T*>(a.out);
+  const int flags = a.flags;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn0 + j * 32 + l31;
+      const float bv = ((flags & DV_BIAS) && col < a.N) ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = act_apply(acc[i][j][r] + bv, flags);
+        if (col >= a.N) v = 0.f;
+        if (row < a.M && col < a.NP) {
+          T* p = out + (size_t)row * a.ldo + col;
+          if (flags & DV_ACCUM) v += DT<T>::to_f(*p);
+          T tv = DT<T>::from_f(v);
+          *p = tv;
+          v = DT<T>::to_f(tv);
+        } else {
+          v = 0.f;
+        }
+        acc[i][j][r] = v;   // as stored (0 outside the valid region): feeds the statistics
+      }
+    }
+
+  if (MODE == MODE_FWD && (flags & DV_STATS)) {
+    // per-tile BatchNorm partials: column sums and M2 about the tile mean, over valid rows
+    float* red = reinterpret_cast<float*>(smem);            // [WAVES_M][BN]
+    float* meanb = red + WAVES_M * BN;                      // [BN]
+    const int rows_here = min(BM, a.M - m0);
+    const int wmi = wave / WAVES_N;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+      s += __shfl_xor(s, 32);
+      if (h == 0) red[wmi * BN + wn0 + j * 32 + l31] = s;
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + tid];
+      meanb[tid] = s / (float)rows_here;
+      if (n0 + tid < a.N) a.stats[((size_t)tile_m * 2 + 0) * a.N + n0 + tid] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float mu = meanb[wn0 + j * 32 + l31];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float dlt = acc[i][j][r] - mu;
+          s += (row < a.M) ? dlt * dlt : 0.f;
+        }
+      s += __shfl_xor(s, 32);
+      if (h == 0) red[wmi * BN + wn0 + j * 32 + l31] = s;
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.N) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + tid];
+      a.stats[((size_t)tile_m * 2 + 1) * a.N + n0 + tid] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad kernel.  Each workgroup owns a BI (output channels) x BJ (im2col columns) tile of dW
+// and a contiguous slice of rows; 32 rows per step.  Partial results are added with fp32 atomics.
+struct WgradArgs {
+  const void* x;
+  const void* dy;
+  float* dw;
+  int M, Cout, CoutP, J;  // rows, output channels (padded), J = taps*CP
+  int ldx, ldy, ldw;
+  int nti, ntj;
+  int rows_per_split;
+  ConvGeom g;
+};
+
+// smallest 16-byte-multiple pitch >= bytes with pitch mod 256 in {64, 192}: four consecutive rows of a
+// ds_read_b64_tr_b16 block then fall on four different 64-byte bank groups
+constexpr int tr_pitch(int bytes) {
+  int p = (bytes + 15) / 16 * 16;
+  while (p % 256 != 64 && p % 256 != 192) p += 16;
+  return p;
+}
+
+template <typename T> struct WgMma;
+template <> struct WgMma<bf16_t> {
+  // P: [32 rows m][pitchP bytes] holding i-columns; Q likewise for j-columns
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* tile, int pitch, int col0, int lane, int ks) {
+    const int g16 = lane >> 4, li = lane & 15;
+    const int q = li >> 2, p = li & 3;
+    const int row = ks * 16 + 8 * (g16 >> 1) + q;
+    const unsigned char* ad = tile + row * pitch + (col0 + 16 * (g16 & 1) + 4 * p) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(ad));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(ad + 4 * pitch));
+    s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+};
+
+template <typename T, int GVB, int BI, int BJ>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int GV = GVB / ES;
+  constexpr int ROWS = 32;
+  // pitches: bf16 transposed reads want (pitch mod 256) == 64 or 192 bytes; f32 reads are row-linear
+  constexpr int PITCH_P = ES == 2 ? tr_pitch(BI * 2) : BI * 4 + 16;
+  constexpr int PITCH_Q = ES == 2 ? tr_pitch(BJ * 2) : BJ * 4 + 16;
+  constexpr int PV = BI * ES / 16;               // 16-byte vectors per P row
+  constexpr int P_PER_THREAD = ROWS * PV / 256;
+  constexpr int QV = BJ * ES / GVB;              // gather vectors per Q row
+  constexpr int Q_PER_THREAD = (ROWS * QV + 255) / 256;
+  constexpr int WI = BI / 2, WJ = BJ / 2;        // waves 2x2
+  constexpr int TI = WI / 32, TJ = WJ / 32;
+  static_assert(TI >= 1 && TJ >= 1, "tile");
+  static_assert(P_PER_THREAD >= 1, "P tile");
+  typedef typename VecB<GVB>::type qvec_t;
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * ROWS * (PITCH_P + PITCH_Q)];
+  constexpr int BUFB = ROWS * (PITCH_P + PITCH_Q);   // P tile then Q tile, twice
+  constexpr int QOFF = ROWS * PITCH_P;
+
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  int bid = blockIdx.x;
+  const int tile_j = bid % a.ntj; bid /= a.ntj;
+  const int tile_i = bid % a.nti;
+  const int split = bid / a.nti;
+  const int i0 = tile_i * BI, j0 = tile_j * BJ;
+  const int wi0 = (wave >> 1) * WI, wj0 = (wave & 1) * WJ;
+  const int m_begin = split * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+  if (m_begin >= m_end) return;
+
+  const T* x = reinterpret_cast<const T*>(a.x);
+  const T* dy = reinterpret_cast<const T*>(a.dy);
+
+  // fixed column cursors of this thread's Q vectors
+  KCursor qc[Q_PER_THREAD];
+  int qrow[Q_PER_THREAD], qcol[Q_PER_THREAD];
+  bool qok[Q_PER_THREAD];
+#pragma unroll
+  for (int u = 0; u < Q_PER_THREAD; ++u) {
+    int id = tid + u * 256;
+    qrow[u] = id / QV;
+    qcol[u] = (id % QV) * GV;
+    int j = j0 + qcol[u];
+    qok[u] = (qrow[u] < ROWS) && (j < a.J);
+    qc[u].init(qok[u] ? j : 0, g);
+  }
+
+  uint4 rp[P_PER_THREAD];
+  qvec_t rq[Q_PER_THREAD];
+  auto gload = [&](int mb) {
+#pragma unroll
+    for (int u = 0; u < P_PER_THREAD; ++u) {
+      int id = tid + u * 256;
+      int r = id / PV, cv = (id % PV) * (16 / ES);
+      int m = mb + r, n = i0 + cv;
+      bool ok = (m < m_end) && (n < a.CoutP);
+      rp[u] = ok ? *reinterpret_cast<const uint4*>(dy + (size_t)m * a.ldy + n) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < Q_PER_THREAD; ++u) {
+      int m = mb + qrow[u];
+      int pos = -1;
+      if (qok[u] && m < m_end) {
+        RowPos rpos = decode_row<MODE_FWD>((uint32_t)m, a.M, g);
+        pos = src_pos<MODE_FWD>(rpos, qc[u], g);
+      }
+      rq[u] = pos >= 0 ? *reinterpret_cast<const qvec_t*>(x + (size_t)pos * a.ldx + qc[u].c) : VecB<GVB>::zero();
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < P_PER_THREAD; ++u) {
+      int id = tid + u * 256;
+      int r = id / PV, cb = (id % PV) * 16;
+      *reinterpret_cast<uint4*>(smem + buf * BUFB + r * PITCH_P + cb) = rp[u];
+    }
+#pragma unroll
+    for (int u = 0; u < Q_PER_THREAD; ++u)
+      if (qrow[u] < ROWS) *reinterpret_cast<qvec_t*>(smem + buf * BUFB + QOFF + qrow[u] * PITCH_Q + qcol[u] * ES) = rq[u];
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsteps = (m_end - m_begin + ROWS - 1) / ROWS;
+  gload(m_begin);
+  lstore(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nsteps) gload(m_begin + (s + 1) * ROWS);
+    if constexpr (ES == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[TI], bf[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) af[i] = WgMma<bf16_t>::frag(smem + cur * BUFB, PITCH_P, wi0 + i * 32, lane, ks);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bf[j] = WgMma<bf16_t>::frag(smem + cur * BUFB + QOFF, PITCH_Q, wj0 + j * 32, lane, ks);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < ROWS / 2; ++ks) {
+        float af[TI], bf[TJ];
+        const int kr = ks * 2 + h;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const float*>(smem + cur * BUFB + kr * PITCH_P + (wi0 + i * 32 + l31) * 4);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const float*>(smem + cur * BUFB + QOFF + kr * PITCH_Q + (wj0 + j * 32 + l31) * 4);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nsteps) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = j0 + wj0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wi0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < a.Cout && col < a.J) atomicAdd(a.dw + (size_t)row * a.ldw + col, acc[i][j][r]);
+      }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// host side
+static bool fill_geom(const dv_conv_desc* d, int mode, ConvGeom& g) {
+  g.kt = d->kt; g.kh = d->kh; g.kw = d->kw;
+  g.st = d->st; g.sh = d->sh; g.sw = d->sw;
+  g.pt = d->pt; g.ph = d->ph; g.pw = d->pw;
+  if (mode == MODE_FWD) {
+    g.rT = d->To; g.rH = d->Ho; g.rW = d->Wo;
+    g.sT = d->Ti; g.sH = d->Hi; g.sW = d->Wi;
+    g.CP = d->cin_pitch;
+  } else {
+    g.rT = d->Ti; g.rH = d->Hi; g.rW = d->Wi;
+    g.sT = d->To; g.sH = d->Ho; g.sW = d->Wo;
+    g.CP = d->cout_pitch;
+  }
+  g.Ktot = d->kt * d->kh * d->kw * g.CP;
+  g.dW = make_fastdiv((uint32_t)g.rW);
+  g.dH = make_fastdiv((uint32_t)g.rH);
+  g.dT = make_fastdiv((uint32_t)g.rT);
+  return true;
+}
+
+static int check_desc(const dv_conv_desc* d) {
+  if (!d) return DV_EINVAL;
+  if (d->dtype != DV_F32 && d->dtype != DV_BF16) return DV_EUNSUPPORTED;
+  if (d->N <= 0 || d->Ti <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Cin <= 0 || d->Cout <= 0) return DV_EINVAL;
+  if (d->kt <= 0 || d->kh <= 0 || d->kw <= 0 || d->st <= 0 || d->sh <= 0 || d->sw <= 0) return DV_EINVAL;
+  if (d->pt < 0 || d->ph < 0 || d->pw < 0) return DV_EINVAL;
+  if ((d->Ti + 2 * d->pt - d->kt) / d->st + 1 != d->To) return DV_EINVAL;
+  if ((d->Hi + 2 * d->ph - d->kh) / d->sh + 1 != d->Ho) return DV_EINVAL;
+  if ((d->Wi + 2 * d->pw - d->kw) / d->sw + 1 != d->Wo) return DV_EINVAL;
+  if (d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return DV_EINVAL;
+  const int gv_min = 4;
+  if (d->cin_pitch < d->Cin || d->cin_pitch % gv_min) return DV_EINVAL;
+  if (d->cout_pitch < d->Cout || d->cout_pitch % 8) return DV_EINVAL;
+  if (d->ldx < d->cin_pitch || d->ldy < d->cout_pitch) return DV_EINVAL;
+  const int esz = d->dtype == DV_F32 ? 4 : 2;
+  if ((d->ldx * esz) % 8 || (d->ldy * esz) % 16) return DV_EALIGN;
+  const int64_t mi = (int64_t)d->N * d->Ti * d->Hi * d->Wi, mo = (int64_t)d->N * d->To * d->Ho * d->Wo;
+  if (mi >= (1ll << 31) || mo >= (1ll << 31)) return DV_EINVAL;
+  return DV_OK;
+}
+
+// gather vector bytes for a channel pitch
+static int gather_bytes(int dtype, int cp) {
+  if (dtype == DV_F32) return 16;                   // 4 floats; cp % 4 == 0 checked
+  return (cp % 8 == 0) ? 16 : 8;                    // bf16: 8 elements, or 4 for the padded RGB input
+}
+
+static int pick_bn(int np) {
+  if (np <= 32) return 32;
+  if (np <= 64) return 64;
+  int w128 = (np + 127) / 128 * 128, w64 = (np + 63) / 64 * 64;
+  return (w128 <= w64) ? 128 : 64;
+}
+
+template <typename T, int MODE, int GVB>
+static void launch_gemm(int bn, const ConvArgs& a, int grid, hipStream_t s) {
+  if (bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 32, 4, 1>), dim3(grid), dim3(256), 0, s, a);
+  else if (bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 64, 4, 1>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 128, 2, 2>), dim3(grid), dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+extern "C" int dv_conv3d_stat_tiles(const dv_conv_desc* d) {
+  if (!d) return DV_EINVAL;
+  int64_t m = (int64_t)d->N * d->To * d->Ho * d->Wo;
+  return (int)((m + 127) / 128);
+}
+
+extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
+                             float* stats, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!x || !w || !y) return DV_EINVAL;
+  if ((d->flags & DV_BIAS) && !bias) return DV_EINVAL;
+  if ((d->flags & DV_STATS) && !stats) return DV_EINVAL;
+  if (!aligned16(w) || !aligned16(y) || (reinterpret_cast<uintptr_t>(x) & 7)) return DV_EALIGN;
+  ConvArgs a;
+  fill_geom(d, MODE_FWD, a.g);
+  a.src = x; a.w = w; a.out = y; a.bias = bias; a.stats = stats;
+  a.M = d->N * d->To * d->Ho * d->Wo;
+  a.N = d->Cout; a.NP = d->cout_pitch;
+  a.lds_ = d->ldx; a.ldo = d->ldy; a.ldw = a.g.Ktot;
+  a.flags = d->flags & (DV_BIAS | DV_RELU | DV_SIGMOID | DV_STATS);
+  const int gvb = gather_bytes(d->dtype, d->cin_pitch);
+  if (gvb == 16 && !aligned16(x)) return DV_EALIGN;
+  const int esz = d->dtype == DV_F32 ? 4 : 2;
+  if ((d->ldx * esz) % gvb || (a.ldw * esz) % gvb) return DV_EALIGN;
+  const int bn = pick_bn(a.NP);
+  a.ntn = (a.NP + bn - 1) / bn;
+  const int grid = a.ntn * ((a.M + 127) / 128);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == DV_F32) launch_gemm<float, MODE_FWD, 16>(bn, a, grid, s);
+  else if (gvb == 16) launch_gemm<bf16_t, MODE_FWD, 16>(bn, a, grid, s);
+  else launch_gemm<bf16_t, MODE_FWD, 8>(bn, a, grid, s);
+  return dv_launch_status();
+}
+
+extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void* wd, void* dx, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!dy || !wd || !dx) return DV_EINVAL;
+  if (d->st > 2 || d->sh > 2 || d->sw > 2) return DV_EUNSUPPORTED;
+  if (d->cin_pitch % 8) return DV_EUNSUPPORTED;      // the RGB input never needs a data gradient
+  if (!aligned16(dy) || !aligned16(wd) || !aligned16(dx)) return DV_EALIGN;
+  const int esz = d->dtype == DV_F32 ? 4 : 2;
+  if ((d->ldx * esz) % 16) return DV_EALIGN;
+  ConvArgs a;
+  fill_geom(d, MODE_DGRAD, a.g);
+  a.src = dy; a.w = wd; a.out = dx; a.bias = nullptr; a.stats = nullptr;
+  a.M = d->N * d->Ti * d->Hi * d->Wi;
+  a.N = d->Cin; a.NP = d->cin_pitch;
+  a.lds_ = d->ldy; a.ldo = d->ldx; a.ldw = a.g.Ktot;
+  a.flags = d->flags & DV_ACCUM;
+  const int bn = pick_bn(a.NP);
+  a.ntn = (a.NP + bn - 1) / bn;
+  const int grid = a.ntn * ((a.M + 127) / 128);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bn, a, grid, s);
+  else launch_gemm<bf16_t, MODE_DGRAD, 16>(bn, a, grid, s);
+  return dv_launch_status();
+}
+
+extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void* dy, float* dw, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!x || !dy || !dw) return DV_EINVAL;
+  if (!aligned16(dy) || (reinterpret_cast<uintptr_t>(x) & 7)) return DV_EALIGN;
+  WgradArgs a;
+  fill_geom(d, MODE_FWD, a.g);
+  a.x = x; a.dy = dy; a.dw = dw;
+  a.M = d->N * d->To * d->Ho * d->Wo;
+  a.Cout = d->Cout; a.CoutP = d->cout_pitch; a.J = a.g.Ktot;
+  a.ldx = d->ldx; a.ldy = d->ldy; a.ldw = a.g.Ktot;
+  constexpr int BI = 128, BJ = 64;
+  a.nti = (a.Cout + BI - 1) / BI;
+  a.ntj = (a.J + BJ - 1) / BJ;
+  const int tiles = a.nti * a.ntj;
+  int splits = (1024 + tiles - 1) / tiles;
+  const int max_splits = (a.M + 255) / 256;          // at least 256 rows per workgroup
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  a.rows_per_split = ((a.M + splits - 1) / splits + 31) / 32 * 32;
+  splits = (a.M + a.rows_per_split - 1) / a.rows_per_split;
+  const int grid = tiles * splits;
+  const int gvb = gather_bytes(d->dtype, d->cin_pitch);
+  if (gvb == 16 && !aligned16(x)) return DV_EALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == DV_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 16, BI, BJ>), dim3(grid), dim3(256), 0, s, a);
+  else if (gvb == 16) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 16, BI, BJ>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 8, BI, BJ>), dim3(grid), dim3(256), 0, s, a);
+  return dv_launch_status();
+}

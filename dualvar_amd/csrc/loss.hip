@@ -1,0 +1,302 @@
+// Contrastive objectives of the DualVar hot path on gfx950: similarity products on the fp32
+// matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) + wave-per-row masked log-softmax
+// cross-entropy that also emits the reference-ordered logits, the top-k rank of the positive
+// and the gradient w.r.t. the similarity matrix.  See include/dualvar_hip.h for the citations.
+#include "common.hpp"
+
+namespace {
+
+// C[m][n] (+)= alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]; one wave per 32x32 tile.
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A, int64_t sam,
+                                                        int64_t sak, const float* __restrict__ B, int64_t sbk,
+                                                        int64_t sbn, float* __restrict__ C, int64_t ldc, float alpha,
+                                                        int accumulate, int tiles_n) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + wave;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * 32, n0 = tn * 32;
+  if (m0 >= M) return;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int m = m0 + l31, n = n0 + l31;
+  const float* ap = A + (int64_t)m * sam;
+  const float* bp = B + (int64_t)n * sbn;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k = 0; k < K; k += 2) {
+    const int kk = k + h;
+    float a = (m < M && kk < K) ? ap[(int64_t)kk * sak] : 0.f;
+    float b = (n < N && kk < K) ? bp[(int64_t)kk * sbk] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  if (n < N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < M) {
+        float* p = C + (int64_t)row * ldc + n;
+        float v = alpha * acc[r];
+        *p = accumulate ? *p + v : v;
+      }
+    }
+  }
+}
+
+static int launch_gemm_f32(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
+                           int64_t sbn, float* C, int64_t ldc, float alpha, int accumulate, hipStream_t s) {
+  const int tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32;
+  const int tiles = tiles_m * tiles_n;
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc,
+                     alpha, accumulate, tiles_n);
+  return dv_launch_status();
+}
+
+// One wave per row.  On entry sim[r][c] holds the scaled similarities (dot * inv_T); on exit the
+// gradient of mean_r(loss_r) w.r.t. the unscaled dot products.
+__global__ void ntxent_rows_kernel(float* __restrict__ sim, int R, int n_local, int N, int row_index0, float inv_T,
+                                   float* __restrict__ logits, float* __restrict__ loss_rows, int* __restrict__ rank0) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int lane = threadIdx.x & 63;
+  const int C2 = 2 * N;
+  const int gi = row_index0 + (r / n_local) * N + (r % n_local);
+  const int pos = (gi + N) % C2;
+  float* s = sim + (size_t)r * C2;
+  float mx = -INFINITY;
+  for (int c = lane; c < C2; c += 64)
+    if (c != gi) mx = fmaxf(mx, s[c]);
+  mx = wave_max(mx);
+  const float sp = s[pos];
+  float se = 0.f, cnt = 0.f;
+  for (int c = lane; c < C2; c += 64)
+    if (c != gi) {
+      float v = s[c];
+      se += __expf(v - mx);
+      if (c != pos && v > sp) cnt += 1.f;
+    }
+  se = wave_sum(se);
+  cnt = wave_sum(cnt);
+  const float lse = logf(se) + mx;
+  if (lane == 0) {
+    loss_rows[r] = lse - sp;
+    rank0[r] = (int)cnt;
+  }
+  float* lg = logits + (size_t)r * (C2 - 1);
+  const float gscale = inv_T / (float)R;
+  for (int c = lane; c < C2; c += 64) {
+    float v = s[c];
+    float grad = 0.f;
+    if (c != gi) {
+      float p = __expf(v - lse);
+      grad = (p - (c == pos ? 1.f : 0.f)) * gscale;
+      int j = (c == pos) ? 0 : 1 + c - (c > gi ? 1 : 0) - (c > pos ? 1 : 0);
+      lg[j] = v;
+    }
+    s[c] = grad;
+  }
+}
+
+// MoCo InfoNCE rows: logits[b][0] = q.k*inv_T computed here, logits[b][1..K] already hold q.queue*inv_T.
+__global__ void infonce_rows_kernel(const float* __restrict__ q, const float* __restrict__ k, int B, int D, int K,
+                                    float inv_T, float* __restrict__ logits, float* __restrict__ loss_rows,
+                                    int* __restrict__ rank0, float* __restrict__ dlogits) {
+  const int b = blockIdx.x;
+  __shared__ float sh[16];
+  const int t = threadIdx.x;
+  float d = 0.f;
+  for (int i = t; i < D; i += blockDim.x) d += q[(size_t)b * D + i] * k[(size_t)b * D + i];
+  d = wave_sum(d);
+  if ((t & 63) == 0) sh[t >> 6] = d;
+  __syncthreads();
+  float l0 = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) l0 += sh[i];
+  l0 *= inv_T;
+  __syncthreads();
+  float* lg = logits + (size_t)b * (K + 1);
+  float mx = l0;
+  for (int j = 1 + t; j <= K; j += blockDim.x) mx = fmaxf(mx, lg[j]);
+  mx = wave_max(mx);
+  if ((t & 63) == 0) sh[t >> 6] = mx;
+  __syncthreads();
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) mx = fmaxf(mx, sh[i]);
+  __syncthreads();
+  float se = 0.f, cnt = 0.f;
+  for (int j = 1 + t; j <= K; j += blockDim.x) {
+    float v = lg[j];
+    se += __expf(v - mx);
+    if (v > l0) cnt += 1.f;
+  }
+  se = wave_sum(se);
+  cnt = wave_sum(cnt);
+  if ((t & 63) == 0) { sh[t >> 6] = se; sh[8 + (t >> 6)] = cnt; }
+  __syncthreads();
+  se = 0.f; cnt = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { se += sh[i]; cnt += sh[8 + i]; }
+  se += __expf(l0 - mx);
+  const float lse = logf(se) + mx;
+  const float gs = inv_T / (float)B;
+  float* dl = dlogits + (size_t)b * (K + 1);
+  for (int j = 1 + t; j <= K; j += blockDim.x) dl[j] = __expf(lg[j] - lse) * gs;
+  if (t == 0) {
+    lg[0] = l0;
+    dl[0] = (__expf(l0 - lse) - 1.f) * gs;
+    loss_rows[b] = lse - l0;
+    rank0[b] = (int)cnt;
+  }
+}
+
+// dq[b][:] += dlogits[b][0] * k[b][:]
+__global__ void axpy_rows_kernel(const float* __restrict__ dl, int64_t ld, const float* __restrict__ k, int B, int D,
+                                 float* __restrict__ dq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D;
+  dq[i] += dl[(int64_t)b * ld] * k[i];
+}
+
+// shuffle-rank margin: one block (64 threads) per sample; feats [Bn][2s][D] (view-major)
+__global__ void rank_margin_kernel(const float* __restrict__ f, int Bn, int s, int D, float theta, float clip,
+                                   float weight, float* __restrict__ logits, float* __restrict__ loss_part,
+                                   float* __restrict__ df) {
+  extern __shared__ float sm[];          // S[n2*n2], dS[n2*n2]
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int n2 = 2 * s;
+  float* S = sm;
+  float* dS = sm + n2 * n2;
+  const float* fb = f + (size_t)b * n2 * D;
+  for (int p = t; p < n2 * n2; p += blockDim.x) {
+    const int i = p / n2, j = p % n2;
+    float a = 0.f;
+    for (int d = 0; d < D; ++d) a += fb[i * D + d] * fb[j * D + d];
+    S[p] = a;
+    dS[p] = 0.f;
+  }
+  __syncthreads();
+  const float count = (float)Bn * n2 * (n2 - 2);
+  float lsum = 0.f;
+  if (t < n2) {
+    const int i = t, pr = (i + s) % n2;
+    const float hi = S[i * n2 + pr];
+    float* lg = logits + ((size_t)b * n2 + i) * (n2 - 1);
+    lg[0] = hi;
+    int o = 1;
+    for (int j = 0; j < n2; ++j) {
+      if (j == i || j == pr) continue;
+      const float lo = S[i * n2 + j];
+      lg[o++] = lo;
+      float z = (lo - hi) / theta;
+      float pass = 1.f;
+      if (clip > 0.f && z > clip) { z = clip; pass = 0.f; }
+      lsum += log1pf(__expf(z));                    // log(1+exp(z)), z <= 5 with clip; fp32 safe to z~88
+      const float sg = 1.f / (1.f + __expf(-z));
+      const float dz = weight / count * sg * pass / theta;
+      dS[i * n2 + j] += dz;
+      dS[i * n2 + pr] -= dz;
+    }
+  }
+  lsum = wave_sum(lsum);
+  if (t == 0) loss_part[b] = lsum * weight / count;
+  __syncthreads();
+  // df[i][d] = sum_j (dS[i][j] + dS[j][i]) f[j][d]
+  for (int p = t; p < n2 * D; p += blockDim.x) {
+    const int i = p / D, d = p % D;
+    float a = 0.f;
+    for (int j = 0; j < n2; ++j) a += (dS[i * n2 + j] + dS[j * n2 + i]) * fb[j * D + d];
+    df[(size_t)b * n2 * D + p] = a;
+  }
+}
+
+__global__ void sum_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float r = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    out[0] = r * scale;
+  }
+}
+
+// x [R][G][D] -> y [R][D] mean over G;  bwd: dx[r][g][d] = dy[r][d]/G
+__global__ void group_mean_kernel(const float* __restrict__ x, int R, int G, int D, float* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * D) return;
+  const int r = i / D, d = i % D;
+  float a = 0.f;
+  for (int g = 0; g < G; ++g) a += x[((size_t)r * G + g) * D + d];
+  y[i] = a / (float)G;
+}
+__global__ void group_mean_bwd_kernel(const float* __restrict__ dy, int R, int G, int D, float* __restrict__ dx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * G * D) return;
+  const int d = i % D, r = i / (G * D);
+  dx[i] = dy[(size_t)r * D + d] / (float)G;
+}
+
+}  // namespace
+
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int dv_gemm_f32(int32_t M, int32_t N, int32_t K, const float* A, int64_t sam, int64_t sak, const float* B,
+                           int64_t sbk, int64_t sbn, float* C, int64_t ldc, float alpha, int32_t accumulate,
+                           void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return DV_EINVAL;
+  return launch_gemm_f32(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, alpha, accumulate, ST(stream));
+}
+
+extern "C" int dv_ntxent_fwd(const float* rows, const float* cols, int32_t R, int32_t n_local, int32_t N, int32_t D,
+                             int32_t row_index0, float inv_T, float* logits, float* loss_rows, int32_t* rank0, float* dsim,
+                             void* stream) {
+  if (!rows || !cols || !logits || !loss_rows || !rank0 || !dsim) return DV_EINVAL;
+  if (R <= 0 || N <= 1 || D <= 0 || n_local <= 0 || R % n_local || R / n_local != 2) return DV_EINVAL;
+  if (row_index0 < 0 || row_index0 + n_local > N) return DV_EINVAL;
+  int rc = launch_gemm_f32(R, 2 * N, D, rows, D, 1, cols, 1, D, dsim, 2 * N, inv_T, 0, ST(stream));
+  if (rc) return rc;
+  hipLaunchKernelGGL(ntxent_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, ST(stream), dsim, R, n_local, N, row_index0, inv_T,
+                     logits, loss_rows, rank0);
+  return dv_launch_status();
+}
+
+extern "C" int dv_infonce_fwd(const float* q, const float* k, const float* queue, int32_t B, int32_t D, int32_t K,
+                              float inv_T, float* logits, float* loss_rows, int32_t* rank0, float* dlogits, float* dq,
+                              void* stream) {
+  if (!q || !k || !queue || !logits || !loss_rows || !rank0 || !dlogits || !dq || B <= 0 || D <= 0 || K <= 0) return DV_EINVAL;
+  // logits[:,1:] = q . queue * inv_T      (queue is [D][K]: B operand strides (K, 1))
+  int rc = launch_gemm_f32(B, K, D, q, D, 1, queue, K, 1, logits + 1, K + 1, inv_T, 0, ST(stream));
+  if (rc) return rc;
+  hipLaunchKernelGGL(infonce_rows_kernel, dim3(B), dim3(256), 0, ST(stream), q, k, B, D, K, inv_T, logits, loss_rows, rank0,
+                     dlogits);
+  rc = dv_launch_status();
+  if (rc) return rc;
+  // dq = dlogits[:,1:] . queue^T + dlogits[:,0] * k
+  rc = launch_gemm_f32(B, D, K, dlogits + 1, K + 1, 1, queue, 1, K, dq, D, 1.f, 0, ST(stream));
+  if (rc) return rc;
+  hipLaunchKernelGGL(axpy_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, ST(stream), dlogits, (int64_t)(K + 1), k, B, D, dq);
+  return dv_launch_status();
+}
+
+extern "C" int dv_rank_margin(const float* feats, int32_t Bn, int32_t s, int32_t D, float theta, float clip, float weight,
+                              float* logits, float* loss, float* dfeats, float* scratch /*[Bn]*/, void* stream) {
+  if (!feats || !logits || !loss || !dfeats || !scratch || Bn <= 0 || s < 2 || s > 8 || D <= 0 || theta <= 0.f) return DV_EINVAL;
+  const int n2 = 2 * s;
+  hipLaunchKernelGGL(rank_margin_kernel, dim3(Bn), dim3(64), 2 * n2 * n2 * sizeof(float), ST(stream), feats, Bn, s, D, theta,
+                     clip, weight, logits, scratch, dfeats);
+  int rc = dv_launch_status();
+  if (rc) return rc;
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, ST(stream), scratch, Bn, 1.f, loss);
+  return dv_launch_status();
+}
+
+extern "C" int dv_group_mean_f32(const float* x, int32_t R, int32_t G, int32_t D, float* y, void* stream) {
+  if (!x || !y || R <= 0 || G <= 0 || D <= 0) return DV_EINVAL;
+  hipLaunchKernelGGL(group_mean_kernel, dim3((R * D + 255) / 256), dim3(256), 0, ST(stream), x, R, G, D, y);
+  return dv_launch_status();
+}
+extern "C" int dv_group_mean_bwd_f32(const float* dy, int32_t R, int32_t G, int32_t D, float* dx, void* stream) {
+  if (!dy || !dx || R <= 0 || G <= 0 || D <= 0) return DV_EINVAL;
+  hipLaunchKernelGGL(group_mean_bwd_kernel, dim3((R * G * D + 255) / 256), dim3(256), 0, ST(stream), dy, R, G, D, dx);
+  return dv_launch_status();
+}

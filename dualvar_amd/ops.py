@@ -1,0 +1,154 @@
+"""Thin Python launchers over the C ABI: shape checks on the host, raw pointers to the kernels.
+
+`Act` is an NDHWC activation view (a channel slice of a [rows, ld] buffer).  Nothing here computes
+with PyTorch; torch tensors are only device memory."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import DV_ACCUM, DV_BF16, DV_BIAS, DV_F32, DV_NO_RELU_MASK, DV_RELU, DV_SIGMOID, DV_STATS  # noqa: F401
+
+TORCH_DTYPE = {DV_F32: torch.float32, DV_BF16: torch.bfloat16}
+ESIZE = {DV_F32: 4, DV_BF16: 2}
+
+
+def cp8(c):
+    return (c + 7) & ~7
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Act:
+    """[N,T,H,W,C] view with row pitch `ld` starting at channel `off` of `buf` ([rows, ld_total])."""
+    __slots__ = ('buf', 'N', 'T', 'H', 'W', 'C', 'ld', 'off', 'dtype', 'grad', 'cpitch')
+
+    def __init__(self, buf, N, T, H, W, C, ld, off, dtype, cpitch=None):
+        self.buf, self.N, self.T, self.H, self.W, self.C, self.ld, self.off, self.dtype = buf, N, T, H, W, C, ld, off, dtype
+        self.cpitch = cpitch if cpitch is not None else cp8(C)
+        self.grad = None
+
+    @property
+    def rows(self):
+        return self.N * self.T * self.H * self.W
+
+    @property
+    def S(self):
+        return self.T * self.H * self.W
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.off * ESIZE[self.dtype]
+
+    def slice(self, off, C_):
+        assert off % 8 == 0 and off + cp8(C_) <= self.ld - self.off or off + C_ <= self.C
+        return Act(self.buf, self.N, self.T, self.H, self.W, C_, self.ld, self.off + off, self.dtype)
+
+    def like(self, device=None):
+        return new_act(self.N, self.T, self.H, self.W, self.C, self.dtype, self.buf.device, cpitch=self.cpitch)
+
+
+def new_act(N, T, H, W, C_, dtype, device, cpitch=None, zero=False):
+    cpitch = cpitch if cpitch is not None else cp8(C_)
+    rows = N * T * H * W
+    alloc = torch.zeros if zero else torch.empty
+    buf = alloc((rows, cpitch), dtype=TORCH_DTYPE[dtype], device=device)
+    return Act(buf, N, T, H, W, C_, cpitch, 0, dtype, cpitch)
+
+
+def _p(t):
+    return 0 if t is None else (t.ptr if isinstance(t, Act) else t.data_ptr())
+
+
+def conv_desc(dtype, x, y, k, s, p, flags=0):
+    d = L.ConvDesc()
+    d.dtype = dtype
+    d.N, d.Ti, d.Hi, d.Wi, d.Cin = x.N, x.T, x.H, x.W, x.C
+    d.To, d.Ho, d.Wo, d.Cout = y.T, y.H, y.W, y.C
+    d.kt, d.kh, d.kw = k
+    d.st, d.sh, d.sw = s
+    d.pt, d.ph, d.pw = p
+    d.cin_pitch, d.cout_pitch = x.cpitch, y.cpitch
+    d.ldx, d.ldy = x.ld, y.ld
+    d.flags = flags
+    return d
+
+
+def conv_out_dims(x, k, s, p):
+    return tuple((i + 2 * pp - kk) // ss + 1 for i, kk, ss, pp in zip((x.T, x.H, x.W), k, s, p))
+
+
+def conv_fwd(d, x, w, bias, y, stats):
+    lib = L.load()
+    L.check(lib.dv_conv3d_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(y), _p(stats), stream_ptr()), 'dv_conv3d_fwd')
+
+
+def conv_dgrad(d, dy, wd, dx):
+    lib = L.load()
+    L.check(lib.dv_conv3d_dgrad(C.byref(d), _p(dy), _p(wd), _p(dx), stream_ptr()), 'dv_conv3d_dgrad')
+
+
+def conv_wgrad(d, x, dy, dw):
+    lib = L.load()
+    L.check(lib.dv_conv3d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), stream_ptr()), 'dv_conv3d_wgrad')
+
+
+def stat_tiles(d):
+    return L.load().dv_conv3d_stat_tiles(C.byref(d))
+
+
+def pool_desc(dtype, x, y, k, s, p):
+    d = L.PoolDesc()
+    d.dtype = dtype
+    d.N, d.Ti, d.Hi, d.Wi, d.C = x.N, x.T, x.H, x.W, x.C
+    d.To, d.Ho, d.Wo = y.T, y.H, y.W
+    d.kt, d.kh, d.kw = k
+    d.st, d.sh, d.sw = s
+    d.pt, d.ph, d.pw = p
+    d.ldx, d.ldy = x.ld, y.ld
+    return d
+
+
+def call(name, *args):
+    """Generic launcher: converts Act / tensors to pointers and appends the current stream."""
+    lib = L.load()
+    conv = []
+    for a in args:
+        if isinstance(a, (Act, torch.Tensor)) or a is None:
+            conv.append(_p(a))
+        elif isinstance(a, C.Structure):
+            conv.append(C.byref(a))
+        else:
+            conv.append(a)
+    L.check(getattr(lib, name)(*conv, stream_ptr()), name)
+
+
+# --------------------------------------------------------------------- layout helpers (host utilities)
+def pack_weight(w, cin_pitch):
+    """[O,I,kt,kh,kw] fp32 -> [O, taps, cin_pitch] fp32 (the master / forward layout)."""
+    O, I = w.shape[:2]
+    taps = w[0, 0].numel()
+    out = torch.zeros(O, taps, cin_pitch, dtype=torch.float32, device=w.device)
+    out[:, :, :I] = w.reshape(O, I, taps).permute(0, 2, 1)
+    return out
+
+
+def unpack_weight(wp, shape):
+    O, I = shape[:2]
+    taps = wp.shape[1]
+    return wp[:, :, :I].permute(0, 2, 1).reshape(shape).contiguous()
+
+
+def act_from_ncdhw(x, dtype, cpitch=None):
+    """Test/host utility: NCDHW float tensor -> Act (uses torch ops; not on the product hot path)."""
+    N, C_, T, H, W = x.shape
+    a = new_act(N, T, H, W, C_, dtype, x.device, cpitch=cpitch, zero=True)
+    a.buf[:, :C_] = x.permute(0, 2, 3, 4, 1).reshape(-1, C_).to(TORCH_DTYPE[dtype])
+    return a
+
+
+def act_to_ncdhw(a):
+    v = a.buf[:, a.off:a.off + a.C].float().reshape(a.N, a.T, a.H, a.W, a.C)
+    return v.permute(0, 4, 1, 2, 3).contiguous()

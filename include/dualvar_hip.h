@@ -1,0 +1,253 @@
+/*
+ * dualvar_hip.h -- C ABI of libdualvar_hip.so, the MI355X (gfx950) kernels underneath the
+ * DualVar pretrain hot path.
+ *
+ * The reference (lzhangbj/DualVar) has no FFI of its own: its "operator API" for this path is
+ * the set of torch calls made by backbone/{s3dg,r21d,r3d,resnet_2d3d}.py, model/simclr.py, model/moco.py and
+ * pretrain.py:394-451.  Each entry point below replaces the library kernel behind one of those
+ * calls (cited per function).  The Python host (dualvar_amd/) binds them with ctypes; a
+ * maintainer of the reference would bind the same symbols.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, PODs.  No torch types.
+ *   - every pointer is a DEVICE pointer unless named host_*.  The caller owns every buffer;
+ *     nothing is allocated, freed or synchronised inside.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - return value: 0 on success, a negative DV_E* code for a rejected argument (nothing is
+ *     launched), a positive hipError_t if the launch itself failed.
+ *   - activations are NDHWC ("channels last"): element (n,t,h,w,c) of a view lives at
+ *     ptr[((n*T+t)*H+h)*W+w)*ld + c]; ld >= round_up(C,8) elements, and the lanes
+ *     [C, round_up(C,8)) hold zeros (kernels that produce a view write those zeros).
+ *     A channel slice of a wider buffer is a view with ptr advanced by the channel offset.
+ *   - dtype: DV_F32 (parity mode) or DV_BF16 (storage bf16, fp32 accumulate).  Statistics,
+ *     losses, gradients of parameters and optimizer state are always fp32.
+ */
+#ifndef DUALVAR_HIP_H
+#define DUALVAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DV_ABI_VERSION 1
+
+enum { DV_F32 = 0, DV_BF16 = 1 };
+
+enum {
+  DV_OK = 0,
+  DV_EINVAL = -1,      /* inconsistent shapes / unsupported parameter */
+  DV_EALIGN = -2,      /* pointer or pitch not 16-byte aligned */
+  DV_EUNSUPPORTED = -3
+};
+
+/* epilogue / behaviour flags */
+enum {
+  DV_BIAS = 1,         /* add bias[n]                                     */
+  DV_RELU = 2,         /* max(.,0)                                        */
+  DV_SIGMOID = 4,      /* 1/(1+exp(-.))                                   */
+  DV_ACCUM = 8,        /* out += result (dgrad into a shared input)       */
+  DV_STATS = 16,       /* conv fwd: also emit per-tile BatchNorm partials */
+  DV_NO_RELU_MASK = 32 /* bn backward: activation was identity            */
+};
+
+int dv_abi_version(void);
+/* Required device: gfx950.  Returns 0 when the current device can run the kernels. */
+int dv_check_device(void);
+
+/* ---------------------------------------------------------------------------------------
+ * 3-D convolution as implicit GEMM on MFMA.  Replaces nn.Conv3d (bias=False) forward /
+ * backward at backbone/s3dg.py:11,39,41  r21d.py:54,64  r3d.py:33  resnet_2d3d.py:11-29,124-173
+ * and the 1x1x1 projection heads model/simclr.py:47-49,176-180, model/moco.py:58-60,284-308
+ * (with DV_BIAS), and SelfGating's nn.Linear (s3dg.py:71) as a 1x1x1 conv over [N,1,1,1,C].
+ *
+ * Geometry: input [N,Ti,Hi,Wi,Cin] (pitch ldx), output [N,To,Ho,Wo,Cout] (pitch ldy).
+ * Weights:  w_fwd  [Cout][kt*kh*kw][CinP]   (K-contiguous per output channel), CinP = cin_pitch
+ *           w_dgrad[Cin ][kt*kh*kw][CoutP]  (made by dv_pack_dgrad_weights)
+ *           dw     [Cout][kt*kh*kw][CinP]   fp32, same layout as the fp32 master weights
+ * cin_pitch / cout_pitch are the zero-padded channel counts the gathers decode with
+ * (multiples of 8, or 4 for the 3-channel network input).
+ */
+typedef struct dv_conv_desc {
+  int32_t dtype;
+  int32_t N, Ti, Hi, Wi, Cin;
+  int32_t To, Ho, Wo, Cout;
+  int32_t kt, kh, kw;
+  int32_t st, sh, sw;
+  int32_t pt, ph, pw;
+  int32_t cin_pitch, cout_pitch;
+  int32_t ldx, ldy;
+  int32_t flags;
+} dv_conv_desc;
+
+/* number of M-tiles dv_conv3d_fwd emits BatchNorm partials for (rows of `stats`) */
+int dv_conv3d_stat_tiles(const dv_conv_desc* d);
+/* y = conv(x, w) [+bias][act]; with DV_STATS also stats[tile][2][Cout] = (sum, M2 about the
+ * tile mean) of the values as stored.  */
+int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
+                  void* y, float* stats, void* stream);
+/* dx (+)= conv_transpose(dy, w).  strides must be 1 or 2. */
+int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* stream);
+/* dw += x^T * dy  (fp32 atomics into the gradient arena; caller zeroes at zero_grad) */
+int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void* dy, float* dw, void* stream);
+
+/* master fp32 [Cout][taps][CinP] -> compute-dtype [Cin][taps][CoutP] for n_desc tensors at once */
+typedef struct dv_pack_desc {
+  int64_t src_off;   /* element offset into the fp32 master arena */
+  int64_t dst_off;   /* element offset into the dgrad-layout arena */
+  int32_t Cout, Cin, taps, cin_pitch, cout_pitch, _pad;
+} dv_pack_desc;
+int dv_pack_dgrad_weights(int32_t dtype, const float* master, void* dst, const dv_pack_desc* descs /*device*/,
+                          const int32_t* block_map /*device: [n_blocks][2] = (desc, first output row)*/,
+                          int32_t n_blocks, void* stream);
+/* fp32 -> compute dtype copy of a flat arena (n elements) */
+int dv_cast_arena(int32_t dtype, const float* src, void* dst, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Input ingest: NCDHW fp32 clips -> NDHWC (C padded to 4), optional (x-mean)/std
+ * (utils/transforms.py:57-63 via pretrain.py:386-389) and optional per-sample temporal
+ * segment permutation (torch.gather at simclr.py:378-383 / moco.py:543-549): with perm != NULL
+ * output frame t of sample n comes from frame perm[n][t / seg]*seg + t % seg.
+ */
+int dv_ingest_ncdhw(int32_t dtype, const float* x, void* y, int32_t N, int32_t C, int32_t T, int32_t H,
+                    int32_t W, int64_t x_stride_n, int32_t ldy, const float* mean3, const float* istd3,
+                    const int32_t* perm, int32_t n_seg, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * BatchNorm3d, training mode (nn.BatchNorm3d at s3dg.py:16,46-47, r21d.py:56,99,106,111,228, ...;
+ * SyncBatchNorm math torch/nn/modules/_functions.py:39-200).
+ * Forward is split so that the cross-rank exchange can sit between the two calls:
+ *   dv_bn_reduce_stats : conv-epilogue partials [tiles][2][C] -> local (sum, M2, count) [2*C+1]
+ *   dv_bn_finalize     : R ranks' (sum, M2, count) -> mean, invstd, scale=gamma*invstd,
+ *                        shift=beta-mean*scale; running stats updated with momentum
+ *                        (unbiased variance, PyTorch semantics).
+ *   dv_bn_apply        : y = act(x*scale + shift [+ residual]) into a (possibly sliced) view.
+ * Backward:
+ *   dv_bn_bwd_reduce   : g = dy*(y>0); per-block partials of sum(g), sum(g*xhat)
+ *   dv_bn_bwd_finalize : partials -> local sums [2][C]
+ *   dv_bn_bwd_apply    : dgamma += sum(g*xhat)_local, dbeta += sum(g)_local (local sums);
+ *                        dx = scale*(g - sum_g/M - xhat*sum_gx/M) with the GLOBAL sums/M;
+ *                        optional dres (+)= g for the residual branch.
+ */
+int dv_bn_reduce_stats(const float* partials, int32_t n_tiles, int32_t tile_rows, int64_t M, int32_t C,
+                       float* local_stats /*[2*C+1]*/, void* stream);
+int dv_bn_finalize(const float* stats /*[R][2*C+1]*/, int32_t R, int32_t C, const float* gamma,
+                   const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                   float* mean, float* invstd, float* scale, float* shift, void* stream);
+int dv_bn_apply(int32_t dtype, const void* x, int32_t ldx, const float* scale, const float* shift,
+                const void* residual, int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t C,
+                int32_t flags, void* stream);
+int dv_bn_bwd_blocks(int64_t M, int32_t C);
+int dv_bn_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
+                     int32_t ldx, const float* mean, const float* invstd, int64_t M, int32_t C,
+                     int32_t flags, float* partials /*[blocks][2][C]*/, void* stream);
+int dv_bn_bwd_finalize(const float* partials, int32_t n_blocks, int32_t C, float* sums /*[2][C]*/, void* stream);
+int dv_bn_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
+                    int32_t ldx, const float* mean, const float* invstd, const float* gamma,
+                    const float* sums_global /*[2][C]*/, const float* sums_local /*[2][C]*/, float inv_count,
+                    float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres, int32_t lddres,
+                    int64_t M, int32_t C, int32_t flags, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * MaxPool3d (s3dg.py:105,151,162,173,190; resnet_2d3d.py:212,280): -inf padding, first maximum
+ * in (t,h,w) scan order wins (PyTorch CPU semantics).  idx holds the winning tap per element.
+ */
+typedef struct dv_pool_desc {
+  int32_t dtype;
+  int32_t N, Ti, Hi, Wi, C;
+  int32_t To, Ho, Wo;
+  int32_t kt, kh, kw, st, sh, sw, pt, ph, pw;
+  int32_t ldx, ldy;
+} dv_pool_desc;
+int dv_maxpool3d_fwd(const dv_pool_desc* d, const void* x, void* y, uint8_t* idx, void* stream);
+/* dx (+)= scatter of dy through idx (gather formulation, deterministic); flags: DV_ACCUM */
+int dv_maxpool3d_bwd(const dv_pool_desc* d, const void* dy, const uint8_t* idx, void* dx, int32_t flags,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Spatio-temporal mean and broadcast scaling: nn.AdaptiveAvgPool3d((1,1,1)) (simclr.py:44,166,
+ * moco.py:55,66) and SelfGating (s3dg.py:68-78).
+ *   dv_spatial_mean      : out[n][c] = mean_s x[n][s][c]                      (fp32 out, pitch C)
+ *   dv_spatial_mean_bwd  : dx[n][s][c] (+)= dout[n][c]/S
+ *   dv_gate_scale        : y[n][s][c] = x[n][s][c]*g[n][c]
+ *   dv_gate_bwd_reduce   : dpre[n][c] = (sum_s dy*x) * g*(1-g)
+ *   dv_gate_bwd_apply    : dx[n][s][c] (+)= dy*g[n][c] + dmean[n][c]/S
+ */
+int dv_spatial_mean(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t S, int32_t C, float* out,
+                    void* stream);
+int dv_spatial_mean_bwd(int32_t dtype, const float* dout, int32_t N, int32_t S, int32_t C, void* dx,
+                        int32_t lddx, int32_t flags, void* stream);
+int dv_gate_scale(int32_t dtype, const void* x, int32_t ldx, const float* g, int32_t N, int32_t S, int32_t C,
+                  void* y, int32_t ldy, void* stream);
+int dv_gate_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* x, int32_t ldx, const float* g,
+                       int32_t N, int32_t S, int32_t C, float* dpre, void* stream);
+int dv_gate_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const float* g, const float* dmean,
+                      int32_t N, int32_t S, int32_t C, void* dx, int32_t lddx, int32_t flags, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Small fp32 helpers for the projection heads and parameter gradients.
+ *   dv_colsum_f32  : out[c] += sum_r x[r][c]                 (bias gradients)
+ *   dv_l2norm_fwd  : y = x / max(||x||_2, eps) over the last dim (F.normalize, simclr.py:117,359,367,393)
+ *   dv_l2norm_bwd  : dx = (dy - y*<dy,y>) / max(||x||,eps)
+ *   dv_relu_bwd_f32: dx = dy * (y > 0)
+ */
+int dv_colsum_f32(const float* x, int32_t ldx, int32_t R, int32_t C, float* out, void* stream);
+int dv_l2norm_fwd(const float* x, int32_t R, int32_t D, float eps, float* y, float* norm, void* stream);
+int dv_l2norm_bwd(const float* dy, const float* y, const float* norm, int32_t R, int32_t D, float* dx, void* stream);
+int dv_relu_bwd_f32(const float* dy, const float* y, int64_t n, float* dx, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Contrastive objectives, fused similarity (fp32 MFMA) + masked log-softmax cross-entropy.
+ *
+ * dv_ntxent_fwd: NT-Xent over the gathered negative set, simclr.py:56-99,183-229 (clip head:
+ *   rows = all 2N view-major features) and simclr.py:280-337 (tc head: rows = this rank's 2B
+ *   entries; features are the series-mean vectors).
+ *     rows  [R][D] fp32, row r is global (view-major) index row_index0 + (r / n_local)*N + r % n_local
+ *     cols  [2N][D] fp32 view-major
+ *     logits[R][2N-1]   = [positive, negatives in column order] * inv_T   (reference layout)
+ *     loss_rows[R]      = logsumexp(logits) - logits[:,0]
+ *     rank0[R]          = number of negatives whose logit is > the positive's (top-k accuracy:
+ *                         utils/utils.py:75-92; hit@k <=> rank0 < k)
+ *     dsim  [R][2N]     = d(mean_r loss)/d sim[r][c]  (softmax - onehot) * inv_T / R, 0 at self
+ * dv_infonce_fwd: MoCo InfoNCE against a queue, moco.py:222-229,404-438:
+ *     logits[B][1+K] = [q.k, q.queue] * inv_T, queue stored [D][K] as in the reference.
+ *     dlogits[B][1+K] = d(mean loss)/d(unscaled dot products);  dq[B][D] = d(mean loss)/dq.
+ * dv_rank_margin: shuffle-rank margin loss simclr.py:231-278 / moco.py:440-480 on
+ *     feats[Bn][2 views][s][D] (view-major per sample): loss = w*mean softplus(min(z,clip)),
+ *     z=(other-highest)/theta; also margin logits [Bn*2s][2s-1] and dfeats.
+ */
+int dv_ntxent_fwd(const float* rows, const float* cols, int32_t R, int32_t n_local, int32_t N, int32_t D,
+                  int32_t row_index0, float inv_T, float* logits, float* loss_rows, int32_t* rank0,
+                  float* dsim, void* stream);
+int dv_infonce_fwd(const float* q, const float* k, const float* queue, int32_t B, int32_t D, int32_t K,
+                   float inv_T, float* logits, float* loss_rows, int32_t* rank0, float* dlogits /*[B][1+K]*/,
+                   float* dq, void* stream);
+int dv_rank_margin(const float* feats /*[Bn][2s][D]*/, int32_t Bn, int32_t s, int32_t D, float theta,
+                   float clip /*<=0: none*/, float weight, float* logits, float* loss /*[1]*/, float* dfeats,
+                   float* scratch /*[Bn]*/, void* stream);
+/* Strided fp32 GEMM on v_mfma_f32_32x32x2_f32 for the small head / loss products:
+ *   C[m][n] (+)= alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]      (C row pitch ldc) */
+int dv_gemm_f32(int32_t M, int32_t N, int32_t K, const float* A, int64_t sam, int64_t sak, const float* B,
+                int64_t sbk, int64_t sbn, float* C, int64_t ldc, float alpha, int32_t accumulate, void* stream);
+/* y[r][d] = mean_g x[r][g][d]  (series-mean vectors of the tc head, simclr.py:297-304 ==
+ * <mean_i row_i, mean_j col_j>);  bwd: dx[r][g][d] = dy[r][d]/G */
+int dv_group_mean_f32(const float* x, int32_t R, int32_t G, int32_t D, float* y, void* stream);
+int dv_group_mean_bwd_f32(const float* dy, int32_t R, int32_t G, int32_t D, float* dx, void* stream);
+/* out[0] = mean(x[0..n)) */
+int dv_mean_f32(const float* x, int32_t n, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optimizer / momentum encoder over flat fp32 arenas (pretrain.py:272,451: SGD momentum 0.9 with
+ * weight decay on every tensor; moco.py:104-107,329-334: k = m*k + (1-m)*q).
+ *   buf = mu*buf + (g*grad_scale + wd*p);  p -= lr*buf;  optional compute-dtype copy of p.
+ */
+int dv_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float mu, float wd,
+                    float grad_scale, int32_t copy_dtype, void* p_copy, void* stream);
+int dv_ema(float* k, const float* q, int64_t n, float m, int32_t copy_dtype, void* k_copy, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUALVAR_HIP_H */

@@ -1,0 +1,432 @@
+"""GPU parity of every HIP kernel against the fp32 PyTorch-CPU op the oracle is made of.
+
+Tolerances: DV_F32 path -> 2e-5 relative to the tensor's max (exact-fp32 MFMA, different
+summation order only); DV_BF16 path -> inputs are rounded to bf16 first, outputs compared at
+1.5e-2 of the tensor's max (bf16 storage rounding, fp32 accumulation)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from dualvar_amd import ops  # noqa: E402
+from dualvar_amd.ops import DV_BF16, DV_F32  # noqa: E402
+
+TOL = {DV_F32: 2e-5, DV_BF16: 1.5e-2}
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(x, dtype):
+    return x.to(torch.bfloat16).float() if dtype == DV_BF16 else x
+
+
+def close(got, ref, dtype, what, factor=1.0):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    den = ref.abs().max().item() + 1e-12
+    assert err <= TOL[dtype] * factor * den + 1e-7, f'{what}: max err {err:.3e} vs max |ref| {den:.3e}'
+
+
+CONV_CASES = [
+    # name, N, Cin, T, H, W, Cout, k, s, p
+    ('stem_sp7', 2, 3, 4, 30, 30, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
+    ('stem_tm7', 2, 64, 8, 9, 9, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0)),
+    ('pw', 3, 64, 2, 7, 7, 96, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('sp3', 2, 96, 2, 7, 9, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('tm3', 2, 32, 4, 5, 5, 32, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ('small_c', 2, 16, 2, 6, 6, 48, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('c24', 2, 24, 2, 7, 7, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('r21d_odd', 1, 64, 2, 8, 8, 83, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ('r21d_odd_in', 1, 83, 4, 6, 6, 64, (3, 1, 1), (2, 1, 1), (1, 0, 0)),
+    ('pw_s', 2, 64, 4, 8, 8, 42, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ('pw_t', 2, 42, 4, 4, 4, 128, (1, 1, 1), (2, 1, 1), (0, 0, 0)),
+    ('full3', 2, 32, 4, 8, 8, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    ('big_n', 2, 160, 1, 3, 3, 320, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('r50_stem', 1, 3, 8, 20, 20, 64, (5, 7, 7), (2, 2, 2), (2, 3, 3)),
+]
+
+
+@pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(gpu, dtype, case):
+    name, N, Cin, T, H, W, Cout, k, s, p = case
+    x = q(rnd(N, Cin, T, H, W, seed=1), dtype)
+    w = q(rnd(Cout, Cin, *k, seed=2, scale=(Cin * k[0] * k[1] * k[2]) ** -0.5), dtype)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, s, p)
+    gy = q(rnd(*yr.shape, seed=3), dtype)
+    yr.backward(gy)
+
+    cin_pitch = 4 if Cin == 3 else ops.cp8(Cin)
+    xa = ops.act_from_ncdhw(x.to(gpu), dtype, cpitch=cin_pitch)
+    To, Ho, Wo = yr.shape[2:]
+    # write y into a channel slice of a wider buffer (concat-by-slice)
+    wide = ops.new_act(N, To, Ho, Wo, ops.cp8(Cout) + 16, dtype, gpu, zero=True)
+    ya = wide.slice(8, Cout)
+    d = ops.conv_desc(dtype, xa, ya, k, s, p, flags=ops.DV_STATS)
+    wp = ops.pack_weight(w.to(gpu), cin_pitch)
+    wpc = wp.to(ops.TORCH_DTYPE[dtype])
+    tiles = ops.stat_tiles(d)
+    stats = torch.zeros(tiles, 2, Cout, device=gpu)
+    ops.conv_fwd(d, xa, wpc, None, ya, stats)
+    torch.cuda.synchronize()
+    close(ops.act_to_ncdhw(ya), yr, dtype, name + ' fwd')
+    # neighbours of the slice untouched, pad lanes zero
+    assert float(wide.buf[:, :8].abs().max()) == 0.0
+    assert float(wide.buf[:, 8 + Cout:8 + ops.cp8(Cout)].abs().max()) == 0.0
+
+    # statistics: sum and M2 recombine to the batch mean / biased variance of the stored values
+    M = N * To * Ho * Wo
+    local = torch.zeros(2 * Cout + 1, device=gpu)
+    ops.call('dv_bn_reduce_stats', stats, tiles, 128, M, Cout, local)
+    ys = ops.act_to_ncdhw(ya)
+    mean_ref = ys.mean(dim=(0, 2, 3, 4)).cpu()
+    var_ref = ys.var(dim=(0, 2, 3, 4), unbiased=False).cpu()
+    close(local[:Cout] / M, mean_ref, DV_F32, name + ' mean', factor=5)
+    close(local[Cout:2 * Cout] / M, var_ref, DV_F32, name + ' var', factor=20)
+    assert float(local[2 * Cout]) == M
+
+    # wgrad
+    dya = ops.act_from_ncdhw(gy.to(gpu), dtype)
+    d2 = ops.conv_desc(dtype, xa, dya, k, s, p)
+    dw = torch.zeros_like(wp)
+    ops.conv_wgrad(d2, xa, dya, dw)
+    close(ops.unpack_weight(dw, w.shape), wr.grad, dtype, name + ' wgrad')
+    assert float(dw[:, :, Cin:].abs().max() if cin_pitch > Cin else 0.0) == 0.0
+
+    # dgrad (never needed for the RGB input)
+    if Cin != 3:
+        taps = k[0] * k[1] * k[2]
+        cout_pitch = ops.cp8(Cout)
+        wd = torch.zeros(Cin, taps, cout_pitch, device=gpu)
+        wd[:, :, :Cout] = w.to(gpu).reshape(Cout, Cin, taps).permute(1, 2, 0)
+        wd = wd.to(ops.TORCH_DTYPE[dtype])
+        dxa = ops.new_act(N, T, H, W, Cin, dtype, gpu, zero=True)
+        ops.conv_dgrad(d2, dya, wd, dxa)
+        close(ops.act_to_ncdhw(dxa), xr.grad, dtype, name + ' dgrad')
+        # accumulate flag
+        d3 = ops.conv_desc(dtype, xa, dya, k, s, p, flags=ops.DV_ACCUM)
+        ops.conv_dgrad(d3, dya, wd, dxa)
+        close(ops.act_to_ncdhw(dxa), 2 * xr.grad, dtype, name + ' dgrad accum', factor=2)
+
+
+def test_pack_dgrad_and_cast(gpu):
+    import ctypes as C
+    from dualvar_amd import _lib as L
+    shapes = [(64, 32, 9), (83, 64, 3), (48, 16, 1)]
+    master, descs, bmap, soff, doff = [], [], [], 0, 0
+    for i, (O, I, taps) in enumerate(shapes):
+        cinp, coutp = ops.cp8(I), ops.cp8(O)
+        w = rnd(O, taps, cinp, seed=10 + i)
+        w[:, :, I:] = 0
+        master.append(w.reshape(-1))
+        descs.append((soff, doff, O, I, taps, cinp, coutp))
+        bmap += [(i, c) for c in range(I)]
+        soff += w.numel()
+        doff += I * taps * coutp
+    m = torch.cat(master).to(gpu)
+    darr = (L.PackDesc * len(descs))()
+    for j, t in enumerate(descs):
+        darr[j].src_off, darr[j].dst_off, darr[j].Cout, darr[j].Cin, darr[j].taps, darr[j].cin_pitch, darr[j].cout_pitch = t
+    dbytes = torch.frombuffer(bytearray(bytes(darr)), dtype=torch.uint8).to(gpu)
+    bm = torch.tensor(bmap, dtype=torch.int32).to(gpu)
+    for dtype in (DV_F32, DV_BF16):
+        dst = torch.full((doff,), 7.0, dtype=ops.TORCH_DTYPE[dtype], device=gpu)
+        ops.call('dv_pack_dgrad_weights', dtype, m, dst, dbytes, bm, len(bmap))
+        for (so, do, O, I, taps, cinp, coutp), w in zip(descs, master):
+            ref = torch.zeros(I, taps, coutp)
+            ref[:, :, :O] = w.reshape(O, taps, cinp)[:, :, :I].permute(2, 1, 0)
+            close(dst[do:do + I * taps * coutp].reshape(I, taps, coutp), q(ref, dtype), DV_F32, 'pack')
+        c = torch.empty(m.numel(), dtype=ops.TORCH_DTYPE[dtype], device=gpu)
+        ops.call('dv_cast_arena', dtype, m, c, m.numel())
+        close(c, q(m.cpu(), dtype), DV_F32, 'cast')
+
+
+@pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
+def test_ingest(gpu, dtype):
+    B, V, T, H, W = 3, 2, 4, 6, 5
+    block = rnd(B, V, 3, T, H, W, seed=4)
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    x = block.reshape(B * V, 3, T, H, W).to(gpu)
+    a = ops.new_act(B * V, T, H, W, 3, dtype, gpu, cpitch=4)
+    ops.call('dv_ingest_ncdhw', dtype, x, a, B * V, 3, T, H, W, 3 * T * H * W, 4, mean.to(gpu), (1 / std).to(gpu), None, 0)
+    ref = (block.reshape(B * V, 3, T, H, W) - mean.view(1, 3, 1, 1, 1)) / std.view(1, 3, 1, 1, 1)
+    close(ops.act_to_ncdhw(a), q(ref, dtype), dtype, 'ingest', factor=0.5 if dtype == DV_BF16 else 1)
+    assert float(a.buf[:, 3].abs().max()) == 0.0
+    # strided view (one view of the block) + segment permutation (simclr.py:378-383)
+    perm = torch.tensor([[1, 0], [0, 1], [1, 0]], dtype=torch.int32)
+    v2 = block.to(gpu)[:, 1]
+    a2 = ops.new_act(B, T, H, W, 3, dtype, gpu, cpitch=4)
+    ops.call('dv_ingest_ncdhw', dtype, v2, a2, B, 3, T, H, W, V * 3 * T * H * W, 4, None, None, perm.to(gpu), 2)
+    xv = block[:, 1].reshape(B, 3, 2, T // 2, H, W)
+    ref2 = torch.gather(xv, 2, perm.long().view(B, 1, 2, 1, 1, 1).expand_as(xv)).reshape(B, 3, T, H, W)
+    close(ops.act_to_ncdhw(a2), q(ref2, dtype), dtype, 'ingest perm', factor=0.5 if dtype == DV_BF16 else 1)
+
+
+@pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
+@pytest.mark.parametrize('C_,residual,relu', [(64, False, True), (83, True, True), (24, True, False), (1152, False, True)])
+def test_batchnorm_fwd_bwd(gpu, dtype, C_, residual, relu):
+    N, T, H, W = 3, 2, 5, 4
+    x = q(rnd(N, C_, T, H, W, seed=5) * 2 + 0.5, dtype)
+    res = q(rnd(N, C_, T, H, W, seed=6), dtype) if residual else None
+    gamma, beta = 1 + 0.2 * rnd(C_, seed=7), 0.1 * rnd(C_, seed=8)
+    bn = torch.nn.BatchNorm3d(C_)
+    bn.weight.data.copy_(gamma)
+    bn.bias.data.copy_(beta)
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if residual else None
+    o = bn(xr)
+    if residual:
+        o = o + rr
+    yr = F.relu(o) if relu else o
+    gy = q(rnd(*yr.shape, seed=9), dtype)
+    yr.backward(gy)
+
+    M = N * T * H * W
+    xa = ops.act_from_ncdhw(x.to(gpu), dtype)
+    # statistics straight from the tensor (as the conv epilogue would emit them): one 128-row tile each
+    tiles = (M + 127) // 128
+    xs = xa.buf[:, :C_].float()
+    part = torch.zeros(tiles, 2, C_, device=gpu)
+    for i in range(tiles):
+        blk = xs[i * 128:(i + 1) * 128]
+        part[i, 0] = blk.sum(0)
+        part[i, 1] = ((blk - blk.mean(0)) ** 2).sum(0)
+    local = torch.zeros(2 * C_ + 1, device=gpu)
+    ops.call('dv_bn_reduce_stats', part, tiles, 128, M, C_, local)
+    # two "ranks" with half the data each must give the same result as one (SyncBN identity)
+    rm, rv = torch.zeros(C_, device=gpu), torch.ones(C_, device=gpu)
+    mean, invstd, scale, shift = (torch.empty(C_, device=gpu) for _ in range(4))
+    ops.call('dv_bn_finalize', local, 1, C_, gamma.to(gpu), beta.to(gpu), 1e-5, 0.1, rm, rv, mean, invstd, scale, shift)
+    close(rm, bn.running_mean, DV_F32, 'running_mean', factor=10)
+    close(rv, bn.running_var, DV_F32, 'running_var', factor=10)
+    ya = ops.new_act(N, T, H, W, C_, dtype, gpu)
+    ra = ops.act_from_ncdhw(res.to(gpu), dtype) if residual else None
+    ops.call('dv_bn_apply', dtype, xa, xa.ld, scale, shift, ra, ra.ld if ra else 0, ya, ya.ld, M, C_, ops.DV_RELU if relu else 0)
+    close(ops.act_to_ncdhw(ya), yr, dtype, 'bn apply')
+
+    dya = ops.act_from_ncdhw(gy.to(gpu), dtype)
+    flags = 0 if relu else ops.DV_NO_RELU_MASK
+    nb = ops.L.load().dv_bn_bwd_blocks(M, C_)
+    partb = torch.zeros(nb, 2, C_, device=gpu)
+    ops.call('dv_bn_bwd_reduce', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, M, C_, flags, partb)
+    sums = torch.zeros(2, C_, device=gpu)
+    ops.call('dv_bn_bwd_finalize', partb, nb, C_, sums)
+    dg, db = torch.zeros(C_, device=gpu), torch.zeros(C_, device=gpu)
+    dxa = ops.new_act(N, T, H, W, C_, dtype, gpu)
+    dra = ops.new_act(N, T, H, W, C_, dtype, gpu) if residual else None
+    ops.call('dv_bn_bwd_apply', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, gamma.to(gpu), sums, sums,
+             1.0 / M, dg, db, dxa, dxa.ld, dra, dra.ld if dra else 0, M, C_, flags)
+    f = 3 if dtype == DV_BF16 else 20
+    close(ops.act_to_ncdhw(dxa), xr.grad, dtype, 'bn dx', factor=f)
+    close(dg, bn.weight.grad, dtype, 'dgamma', factor=f)
+    close(db, bn.bias.grad, dtype, 'dbeta', factor=f)
+    if residual:
+        close(ops.act_to_ncdhw(dra), rr.grad, dtype, 'dres')
+
+
+def test_bn_two_rank_combine(gpu):
+    C_, M = 40, 600
+    x = rnd(M, C_, seed=11) * 3 + 1
+    stats = []
+    for part in (x[:250], x[250:]):
+        stats.append(torch.cat([part.sum(0), ((part - part.mean(0)) ** 2).sum(0), torch.tensor([float(part.shape[0])])]))
+    st = torch.stack(stats).to(gpu)
+    outs = [torch.empty(C_, device=gpu) for _ in range(4)]
+    ops.call('dv_bn_finalize', st, 2, C_, torch.ones(C_, device=gpu), torch.zeros(C_, device=gpu), 1e-5, 0.1, None, None, *outs)
+    close(outs[0], x.mean(0), DV_F32, 'mean 2-rank', factor=5)
+    close(outs[1], (x.var(0, unbiased=False) + 1e-5).rsqrt(), DV_F32, 'invstd 2-rank', factor=5)
+
+
+POOL_CASES = [((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((3, 3, 3), (1, 1, 1), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)),
+              ((2, 2, 2), (2, 2, 2), (0, 0, 0))]
+
+
+@pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
+@pytest.mark.parametrize('k,s,p', POOL_CASES)
+def test_maxpool(gpu, dtype, k, s, p):
+    N, C_, T, H, W = 2, 24, 4, 9, 10
+    x = F.relu(q(rnd(N, C_, T, H, W, seed=12), dtype))       # post-ReLU: many exact ties at 0
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool3d(xr, k, s, p)
+    gy = q(rnd(*yr.shape, seed=13), dtype)
+    yr.backward(gy)
+    xa = ops.act_from_ncdhw(x.to(gpu), dtype)
+    ya = ops.new_act(N, *yr.shape[2:], C_, dtype, gpu)
+    idx = torch.zeros(ya.rows, ops.cp8(C_), dtype=torch.uint8, device=gpu)
+    d = ops.pool_desc(dtype, xa, ya, k, s, p)
+    ops.call('dv_maxpool3d_fwd', d, xa, ya, idx)
+    close(ops.act_to_ncdhw(ya), yr, DV_F32, 'maxpool fwd')
+    dya = ops.act_from_ncdhw(gy.to(gpu), dtype)
+    dxa = ops.new_act(N, T, H, W, C_, dtype, gpu)
+    ops.call('dv_maxpool3d_bwd', d, dya, idx, dxa, 0)
+    close(ops.act_to_ncdhw(dxa), q(xr.grad, dtype), dtype, 'maxpool bwd')
+    ops.call('dv_maxpool3d_bwd', d, dya, idx, dxa, ops.DV_ACCUM)
+    close(ops.act_to_ncdhw(dxa), 2 * xr.grad, dtype, 'maxpool bwd accum', factor=2)
+
+
+@pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
+def test_self_gating_and_mean(gpu, dtype):
+    N, C_, T, H, W = 3, 48, 2, 5, 5
+    S = T * H * W
+    x = q(F.relu(rnd(N, C_, T, H, W, seed=14)), dtype)
+    fc = torch.nn.Linear(C_, C_)
+    xr = x.clone().requires_grad_(True)
+    g_ref = torch.sigmoid(fc(xr.mean(dim=[2, 3, 4])))
+    yr = g_ref[:, :, None, None, None] * xr
+    gy = q(rnd(*yr.shape, seed=15), dtype)
+    yr.backward(gy)
+
+    xa = ops.act_from_ncdhw(x.to(gpu), dtype)
+    mean = torch.empty(N, C_, device=gpu)
+    ops.call('dv_spatial_mean', dtype, xa, xa.ld, N, S, C_, mean)
+    close(mean, x.mean(dim=[2, 3, 4]), DV_F32, 'spatial mean', factor=5)
+    # fc + sigmoid through the strided fp32 GEMM
+    Wt, b = fc.weight.detach().to(gpu), fc.bias.detach().to(gpu)
+    pre = b.repeat(N, 1).contiguous()
+    ops.call('dv_gemm_f32', N, C_, C_, mean, C_, 1, Wt, 1, C_, pre, C_, 1.0, 1)
+    g = torch.sigmoid(pre)                      # test-side only; the product fuses sigmoid in the conv epilogue
+    close(g, g_ref, DV_F32, 'gate', factor=10)
+    ya = ops.new_act(N, T, H, W, C_, dtype, gpu)
+    ops.call('dv_gate_scale', dtype, xa, xa.ld, g, N, S, C_, ya, ya.ld)
+    close(ops.act_to_ncdhw(ya), yr, dtype, 'gate scale')
+    dya = ops.act_from_ncdhw(gy.to(gpu), dtype)
+    dpre = torch.empty(N, C_, device=gpu)
+    ops.call('dv_gate_bwd_reduce', dtype, dya, dya.ld, xa, xa.ld, g, N, S, C_, dpre)
+    dmean = torch.empty(N, C_, device=gpu)
+    ops.call('dv_gemm_f32', N, C_, C_, dpre, C_, 1, Wt, C_, 1, dmean, C_, 1.0, 0)
+    dxa = ops.new_act(N, T, H, W, C_, dtype, gpu)
+    ops.call('dv_gate_bwd_apply', dtype, dya, dya.ld, g, dmean, N, S, C_, dxa, dxa.ld, 0)
+    close(ops.act_to_ncdhw(dxa), xr.grad, dtype, 'gate dx', factor=2)
+    dW = torch.zeros(C_, C_, device=gpu)
+    ops.call('dv_gemm_f32', C_, C_, N, dpre, 1, C_, mean, C_, 1, dW, C_, 1.0, 1)
+    close(dW, fc.weight.grad, dtype, 'gate dW', factor=2)
+    dbias = torch.zeros(C_, device=gpu)
+    ops.call('dv_colsum_f32', dpre, C_, N, C_, dbias)
+    close(dbias, fc.bias.grad, dtype, 'gate db', factor=2)
+    # spatial mean backward
+    dm = rnd(N, C_, seed=16).to(gpu)
+    ops.call('dv_spatial_mean_bwd', dtype, dm, N, S, C_, dxa, dxa.ld, 0)
+    ref = (dm.cpu() / S)[:, :, None, None, None].expand(N, C_, T, H, W)
+    close(ops.act_to_ncdhw(dxa), q(ref, dtype), dtype, 'mean bwd')
+
+
+def test_l2norm_relu_colsum(gpu):
+    x = rnd(10, 128, seed=17)
+    xr = x.clone().requires_grad_(True)
+    yr = F.normalize(xr, dim=1)
+    gy = rnd(10, 128, seed=18)
+    yr.backward(gy)
+    xg = x.to(gpu)
+    y, nrm, dx = torch.empty_like(xg), torch.empty(10, device=gpu), torch.empty_like(xg)
+    ops.call('dv_l2norm_fwd', xg, 10, 128, 1e-12, y, nrm)
+    ops.call('dv_l2norm_bwd', gy.to(gpu), y, nrm, 10, 128, dx)
+    close(y, yr, DV_F32, 'l2norm')
+    close(dx, xr.grad, DV_F32, 'l2norm bwd', factor=5)
+    r = torch.empty_like(xg)
+    ops.call('dv_relu_bwd_f32', gy.to(gpu), xg, x.numel(), r)
+    close(r, gy * (x > 0), DV_F32, 'relu bwd')
+
+
+def test_losses_against_oracle(gpu):
+    from oracle import torch_ref as O
+    import types
+    N, dim = 6, 128
+    m = O.SimCLR_TimeSeriesV4.__new__(O.SimCLR_TimeSeriesV4)
+    torch.nn.Module.__init__(m)
+    m.distributed, m.T, m.aligned_T, m.n_series, m.series_dim, m.dim = False, 0.07, 0.07, 2, 64, 128
+    m.args = types.SimpleNamespace(shufflerank_theta=0.05)
+    feats = F.normalize(rnd(N, 2, dim, seed=19), dim=-1).requires_grad_(True)
+    r = m.calc_clip_contrast_loss(feats, 2)
+    r['clip_contrast_loss'].backward()
+    fvm = feats.detach().permute(1, 0, 2).reshape(2 * N, dim).contiguous().to(gpu)     # view-major
+    logits = torch.empty(2 * N, 2 * N - 1, device=gpu)
+    loss_rows, rank0 = torch.empty(2 * N, device=gpu), torch.empty(2 * N, dtype=torch.int32, device=gpu)
+    dsim = torch.empty(2 * N, 2 * N, device=gpu)
+    ops.call('dv_ntxent_fwd', fvm, fvm, 2 * N, N, N, dim, 0, 1 / 0.07, logits, loss_rows, rank0, dsim)
+    close(logits, r['clip_logits'], DV_F32, 'clip logits', factor=5)
+    close(loss_rows.mean(), r['clip_contrast_loss'], DV_F32, 'clip loss', factor=5)
+    top1 = O.calc_topk_accuracy(r['clip_logits'], r['clip_labels'], (1,))[0]
+    assert abs(float((rank0 < 1).float().mean()) - float(top1)) < 1e-6
+    # dF = dsim.F + dsim^T.F
+    dF = torch.zeros(2 * N, dim, device=gpu)
+    ops.call('dv_gemm_f32', 2 * N, dim, 2 * N, dsim, 2 * N, 1, fvm, dim, 1, dF, dim, 1.0, 0)
+    ops.call('dv_gemm_f32', 2 * N, dim, 2 * N, dsim, 1, 2 * N, fvm, dim, 1, dF, dim, 1.0, 1)
+    ref_g = feats.grad.permute(1, 0, 2).reshape(2 * N, dim)
+    close(dF, ref_g, DV_F32, 'clip dF', factor=20)
+
+    # tc head: series-mean vectors
+    ser = F.normalize(rnd(N, 2, 2, 64, seed=20), dim=-1).requires_grad_(True)
+    r2 = m.calc_tc_contrast_loss(ser)
+    r2['tc_contrast_loss'].backward()
+    svm = ser.detach().permute(1, 0, 2, 3).reshape(2 * N, 2, 64).contiguous().to(gpu)
+    sm = torch.empty(2 * N, 64, device=gpu)
+    ops.call('dv_group_mean_f32', svm, 2 * N, 2, 64, sm)
+    ops.call('dv_ntxent_fwd', sm, sm, 2 * N, N, N, 64, 0, 1 / 0.07, logits, loss_rows, rank0, dsim)
+    close(logits, r2['tc_logits'], DV_F32, 'tc logits', factor=5)
+    close(loss_rows.mean(), r2['tc_contrast_loss'], DV_F32, 'tc loss', factor=5)
+    dM = torch.zeros(2 * N, 64, device=gpu)
+    ops.call('dv_gemm_f32', 2 * N, 64, 2 * N, dsim, 2 * N, 1, sm, 64, 1, dM, 64, 1.0, 0)
+    ops.call('dv_gemm_f32', 2 * N, 64, 2 * N, dsim, 1, 2 * N, sm, 64, 1, dM, 64, 1.0, 1)
+    dS = torch.empty(2 * N, 2, 64, device=gpu)
+    ops.call('dv_group_mean_bwd_f32', dM, 2 * N, 2, 64, dS)
+    close(dS, ser.grad.permute(1, 0, 2, 3).reshape(2 * N, 2, 64), DV_F32, 'tc dF', factor=20)
+
+    # shuffle-rank margin (SimCLR: theta .05, clip 5; MoCo: no clip)
+    for clip in (5.0, 0.0):
+        rk = F.normalize(rnd(N, 2, 2, 64, seed=21), dim=-1).requires_grad_(True)     # [Bn, s, 2, D]
+        r3 = O.ranking_loss(rk, 2, 2, 'x_', 0.5, theta=0.05, clip=clip if clip > 0 else None)
+        r3['x_margin_contrast_loss'].backward()
+        fv = rk.detach().permute(0, 2, 1, 3).reshape(N, 4, 64).contiguous().to(gpu)
+        lg, ls, df, scr = torch.empty(N * 4, 3, device=gpu), torch.empty(1, device=gpu), torch.empty(N, 4, 64, device=gpu), torch.empty(N, device=gpu)
+        ops.call('dv_rank_margin', fv, N, 2, 64, 0.05, clip, 0.5, lg, ls, df, scr)
+        close(lg, r3['x_margin_logits'], DV_F32, 'rank logits', factor=5)
+        close(ls[0], r3['x_margin_contrast_loss'], DV_F32, 'rank loss', factor=20)
+        close(df.reshape(N, 2, 2, 64).permute(0, 2, 1, 3), rk.grad, DV_F32, 'rank grad', factor=50)
+
+
+def test_infonce_against_oracle(gpu):
+    B, D, K = 5, 128, 96
+    qf = F.normalize(rnd(B, D, seed=22), dim=1).requires_grad_(True)
+    kf = F.normalize(rnd(B, D, seed=23), dim=1)
+    queue = F.normalize(rnd(D, K, seed=24), dim=0)
+    pos = torch.einsum('nc,nc->n', [qf, kf]).unsqueeze(-1)
+    neg = torch.einsum('nc,ck->nk', [qf, queue])
+    lr = torch.cat([pos, neg], 1) / 0.07
+    loss = F.cross_entropy(lr, torch.zeros(B, dtype=torch.long))
+    loss.backward()
+    logits, dl = torch.empty(B, K + 1, device=gpu), torch.empty(B, K + 1, device=gpu)
+    lrows, rk, dq = torch.empty(B, device=gpu), torch.empty(B, dtype=torch.int32, device=gpu), torch.empty(B, D, device=gpu)
+    ops.call('dv_infonce_fwd', qf.detach().to(gpu), kf.to(gpu), queue.to(gpu), B, D, K, 1 / 0.07, logits, lrows, rk, dl, dq)
+    close(logits, lr, DV_F32, 'infonce logits', factor=5)
+    close(lrows.mean(), loss, DV_F32, 'infonce loss', factor=5)
+    close(dq, qf.grad, DV_F32, 'infonce dq', factor=20)
+
+
+def test_sgd_and_ema(gpu):
+    n = 1003
+    p0, g = rnd(n, seed=25), rnd(n, seed=26)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([p], lr=0.003, momentum=0.9, weight_decay=1e-4)
+    pg, buf = torch.zeros(1008, device=gpu), torch.zeros(1008, device=gpu)
+    pg[:n] = p0.to(gpu)
+    gg = torch.zeros(1008, device=gpu)
+    gg[:n] = g.to(gpu)
+    cp = torch.zeros(1008, dtype=torch.bfloat16, device=gpu)
+    for _ in range(3):
+        p.grad = g.clone()
+        opt.step()
+        ops.call('dv_sgd_momentum', pg, gg, buf, n, 0.003, 0.9, 1e-4, 1.0, DV_BF16, cp)
+    close(pg[:n], p.detach(), DV_F32, 'sgd', factor=5)
+    close(cp[:n], p.detach().to(torch.bfloat16).float(), DV_F32, 'sgd bf16 copy', factor=500)
+    k, qq = rnd(n, seed=27), rnd(n, seed=28)
+    kg = k.to(gpu)
+    ops.call('dv_ema', kg, qq.to(gpu), n, 0.999, DV_F32, None)
+    close(kg, k * 0.999 + qq * (1 - 0.999), DV_F32, 'ema')
