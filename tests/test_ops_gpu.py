@@ -80,7 +80,8 @@ def test_conv_fwd_dgrad_wgrad(gpu, dtype, case):
     close(ops.act_to_ncdhw(ya), yr, dtype, name + ' fwd')
     # neighbours of the slice untouched, pad lanes zero
     assert float(wide.buf[:, :8].abs().max()) == 0.0
-    assert float(wide.buf[:, 8 + Cout:8 + ops.cp8(Cout)].abs().max()) == 0.0
+    if ops.cp8(Cout) > Cout:
+        assert float(wide.buf[:, 8 + Cout:8 + ops.cp8(Cout)].abs().max()) == 0.0
 
     # statistics: sum and M2 recombine to the batch mean / biased variance of the stored values
     M = N * To * Ho * Wo
@@ -99,7 +100,8 @@ def test_conv_fwd_dgrad_wgrad(gpu, dtype, case):
     dw = torch.zeros_like(wp)
     ops.conv_wgrad(d2, xa, dya, dw)
     close(ops.unpack_weight(dw, w.shape), wr.grad, dtype, name + ' wgrad')
-    assert float(dw[:, :, Cin:].abs().max() if cin_pitch > Cin else 0.0) == 0.0
+    if cin_pitch > Cin:
+        assert float(dw[:, :, Cin:].abs().max()) == 0.0
 
     # dgrad (never needed for the RGB input)
     if Cin != 3:
