@@ -1,0 +1,229 @@
+"""Common machinery of the HIP backbones.
+
+A backbone is an nn.Module whose sub-modules are *parameter holders* (nn.Conv3d / nn.BatchNorm3d /
+nn.Linear instances carrying the reference's names, shapes and initialisation -- so state_dict()
+round-trips with reference checkpoints) plus an `emit(plan, x)` method that lays the network out as
+engine ops.  Compute never goes through those holders' own forward()."""
+import os
+import weakref
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops
+from ..engine import Comm, Op, ParamStore, Plan
+from ..ops import DV_BF16, DV_F32
+
+_DTYPES = {'bf16': DV_BF16, 'bfloat16': DV_BF16, 'fp32': DV_F32, 'float32': DV_F32, 'f32': DV_F32}
+
+
+def default_dtype():
+    return _DTYPES[os.environ.get('DUALVAR_DTYPE', 'bf16').lower()]
+
+
+class IngestOp(Op):
+    """NCDHW fp32 clips (the reference's input layout) -> NDHWC compute dtype; optional Normalize and
+    temporal segment shuffle fused in (pretrain.py:386-389, simclr.py:378-383)."""
+
+    def __init__(self, plan, N, T, H, W, n_seg):
+        super().__init__(plan)
+        self.y = plan.act(N, T, H, W, 3, cpitch=4, grad=False)
+        self.N, self.T, self.H, self.W, self.n_seg = N, T, H, W, n_seg
+        self.src = self.perm = self.mean = self.istd = None
+        self.stride_n = 3 * T * H * W
+
+    def bind(self, x, perm, mean, istd):
+        self.src, self.perm, self.mean, self.istd = x, perm, mean, istd
+        self.stride_n = x.stride(0) if x.dim() == 5 else 3 * self.T * self.H * self.W
+
+    def forward(self):
+        p = self.plan
+        L.check(p.lib.dv_ingest_ncdhw(p.dtype, self.src.data_ptr(), self.y.ptr, self.N, 3, self.T, self.H, self.W,
+                                      self.stride_n, self.y.ld,
+                                      self.mean.data_ptr() if self.mean is not None else 0,
+                                      self.istd.data_ptr() if self.istd is not None else 0,
+                                      self.perm.data_ptr() if self.perm is not None else 0,
+                                      self.n_seg if self.perm is not None else 0, ops.stream_ptr()), 'dv_ingest_ncdhw')
+
+
+class _Token:
+    pass
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, x, backbone, perm, want_map):
+        plan = backbone._acquire_plan(x, perm is not None, want_map, with_grad=True)
+        backbone._run_plan(plan, x, perm)
+        ctx.plan = plan
+        ctx.token = _Token()
+        plan._busy_ref = weakref.ref(ctx.token)
+        ctx.want_map = want_map
+        if want_map:
+            return ops.act_to_ncdhw(plan.out_act)
+        return plan.pooled.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        backbone_store = plan.store
+        backbone_store.attach_grads()
+        if ctx.want_map:
+            a = plan.out_act.grad
+            a.buf[:, a.off:a.off + a.C] = g.permute(0, 2, 3, 4, 1).reshape(-1, a.C).to(a.buf.dtype)
+        else:
+            plan.mean_op.dout.copy_(g)
+        plan.run_backward()
+        plan._busy_ref = None
+        hook = plan.after_backward
+        if hook is not None:
+            hook(plan)
+        return None, None, None, None, None
+
+
+class HipBackbone(nn.Module):
+    """Base class: owns (or is bound to) a ParamStore and a cache of launch plans."""
+    feature_size = 0
+
+    def __init__(self):
+        super().__init__()
+        self._store = None
+        self._own_store = True
+        self._plans = {}
+        self._dtype = None
+        self._anchor = None
+        self._norm = None
+        self.comm = None
+        self.after_backward = None      # set by the data-parallel wrapper (gradient all-reduce hook)
+
+    # -- configuration
+    def set_compute_dtype(self, name):
+        self._dtype = _DTYPES[name] if isinstance(name, str) else name
+        self._plans.clear()
+        return self
+
+    def set_input_normalization(self, mean, std):
+        """Fuse utils.transforms.Normalize (pretrain.py:280-282) into the ingest kernel."""
+        self._norm = (torch.tensor(mean, dtype=torch.float32), 1.0 / torch.tensor(std, dtype=torch.float32))
+        return self
+
+    def bind_store(self, store):
+        """Called by the owning objective so that backbone + heads share one arena."""
+        self._store, self._own_store = store, False
+        self.register_params(store)
+
+    @property
+    def store(self):
+        if self._store is None:
+            self._store = ParamStore()
+            self.register_params(self._store)
+        return self._store
+
+    @property
+    def dtype(self):
+        if self._dtype is None:
+            self._dtype = default_dtype()
+        return self._dtype
+
+    # -- to be provided by the concrete network
+    def register_params(self, store):
+        raise NotImplementedError
+
+    def emit(self, plan, x):
+        raise NotImplementedError
+
+    # -- plans
+    def prepare(self, device):
+        L.require_device()
+        st = self.store
+        if not st.ready(device, self.dtype):
+            st.materialize(device, self.dtype)
+            self._plans.clear()
+        st.refresh()
+        if self._anchor is None or self._anchor.device != device:
+            self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        if self._norm is not None and self._norm[0].device != device:
+            self._norm = (self._norm[0].to(device), self._norm[1].to(device))
+
+    def _acquire_plan(self, x, use_perm, want_map, with_grad):
+        N, _, T, H, W = x.shape
+        n_seg = 0
+        key = (N, T, H, W, use_perm, want_map, with_grad, self.store.generation, self.dtype)
+        lst = self._plans.setdefault(key, [])
+        for pl in lst:
+            ref = pl._busy_ref
+            if ref is None or ref() is None:
+                return pl
+        comm = self.comm if self.comm is not None else Comm()
+        pl = Plan(self.store, self.dtype, x.device, with_grad=with_grad, comm=comm)
+        pl.ingest = pl._push(IngestOp(pl, N, T, H, W, n_seg))
+        out = self.emit(pl, pl.ingest.y)
+        pl.out_act = out
+        pl.mean_op = None
+        if not want_map:
+            pl.pooled = pl.spatial_mean(out)
+            pl.mean_op = pl.fwd[-1]
+        pl.finalize()
+        pl._busy_ref = None
+        pl.after_backward = None
+        lst.append(pl)
+        return pl
+
+    def _run_plan(self, plan, x, perm):
+        if x.dtype != torch.float32 or x.stride()[1:] != (x.shape[2] * x.shape[3] * x.shape[4], x.shape[3] * x.shape[4], x.shape[4], 1):
+            x = x.float().contiguous()
+        plan._keep = x
+        mean, istd = self._norm if self._norm is not None else (None, None)
+        plan.ingest.n_seg = perm.shape[1] if perm is not None else 0
+        plan.ingest.bind(x, perm, mean, istd)
+        plan.after_backward = self.after_backward
+        with torch.no_grad():
+            if self.training:
+                self.store.bump_bn_counters()
+            plan.run_forward()
+
+    def _call(self, x, perm, want_map):
+        if x.dim() != 5 or x.shape[1] != 3:
+            raise ValueError('expected clips [N, 3, T, H, W], got %s' % (tuple(x.shape),))
+        if not x.is_cuda:
+            raise L.DualVarHipError('dualvar_amd backbones run on the MI355X only (input is on %s)' % x.device)
+        if not self.training:
+            raise NotImplementedError('eval-mode (running-stat) BatchNorm is outside the pretrain hot path')
+        self.prepare(x.device)
+        if perm is not None:
+            perm = torch.as_tensor(np.ascontiguousarray(perm), dtype=torch.int32).to(x.device) \
+                if not isinstance(perm, torch.Tensor) else perm.to(device=x.device, dtype=torch.int32).contiguous()
+        if torch.is_grad_enabled() and any(s.tensor.requires_grad for s in self.store.slots):
+            return _BackboneFn.apply(self._anchor, x, self, perm, want_map)
+        plan = self._acquire_plan(x, perm is not None, want_map, with_grad=False)
+        self._run_plan(plan, x, perm)
+        return ops.act_to_ncdhw(plan.out_act) if want_map else plan.pooled.clone()
+
+    def forward(self, x):
+        """[N,3,T,H,W] -> [N,feature_size,T',H',W'] (post-ReLU), the reference module contract."""
+        return self._call(x, None, True)
+
+    def forward_pooled(self, x, perm=None):
+        """[N,3,T,H,W] -> [N,feature_size] = AdaptiveAvgPool3d(1)(backbone(x)), pooled inside the plan.
+        perm [N, n_series] applies the reference's temporal segment shuffle while ingesting."""
+        return self._call(x, perm, False)
+
+
+# ------------------------------------------------------------------ shared emit helpers
+def conv_geometry(conv):
+    return tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding)
+
+
+def emit_conv_bn(plan, conv, bn, x, relu=True, residual=None, out=None):
+    """conv (bias-free) -> train-mode BN (+residual) (+ReLU)."""
+    k, s, p = conv_geometry(conv)
+    raw = plan.conv(plan.store.slot(conv.weight), x, k, s, p)
+    return plan.bn(bn, raw, relu=relu, residual=residual, out=out)
+
+
+def register_conv_bn(store, conv, bn, first=False):
+    store.add_conv(conv.weight, cin_pitch=4 if conv.in_channels == 3 else None, need_dgrad=not first)
+    if bn is not None:
+        store.add_bn(bn)

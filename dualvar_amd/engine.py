@@ -1,0 +1,539 @@
+"""Execution engine: flat parameter arenas + static launch plans over the HIP kernels.
+
+A backbone is described once as a graph of ops on NDHWC activations (`Plan`); the plan owns
+every buffer (activations, their gradients, BatchNorm scratch) and replays a fixed list of kernel
+launches for forward and for backward.  Nothing is traced or compiled: the lists are built by
+ordinary Python that mirrors the reference's module structure, and they are replayed on the
+current HIP stream (so a whole step can be captured into a hipGraph).
+
+`ParamStore` keeps the fp32 master weights of one encoder in a single arena laid out
+[Cout][taps][Cin_pad] (K-contiguous, what the implicit-GEMM kernels read), with the nn.Parameters
+re-pointed to strided views of it so that state_dict()/optimizers see the reference's shapes.
+Gradients accumulate in a twin arena (one flat all-reduce for data parallel), bf16 compute
+copies and the dgrad-layout weights are refreshed by two launches after every update.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import ops
+from .ops import DV_ACCUM, DV_BF16, DV_BIAS, DV_F32, DV_NO_RELU_MASK, DV_RELU, DV_SIGMOID, DV_STATS, Act, cp8
+
+
+def _align8(n):
+    return (n + 7) & ~7
+
+
+class Slot:
+    __slots__ = ('tensor', 'kind', 'off', 'size', 'Cout', 'Cin', 'taps', 'cin_pitch', 'cout_pitch', 'wd_off',
+                 'shape', 'strides')
+
+
+class ParamStore:
+    """Arenas for the trainable tensors of one encoder (registered in forward order)."""
+
+    def __init__(self):
+        self.slots = []
+        self._by_id = {}
+        self.buffers = []          # (module, name) float buffers (BN running stats) -- left where they are
+        self.nbt = []              # BN modules whose num_batches_tracked is bumped per forward
+        self.master = self.grad = self.cc = self.wd = None
+        self.dtype = None
+        self.generation = 0
+        self._dirty = True            # master changed: compute copy + dgrad layout stale
+        self._cast_done = False       # ... but the bf16 copy was already refreshed by the update kernel
+        self._versions = None
+        self.total = 0
+        self.no_dgrad = False         # key encoders (never back-propagated) skip the dgrad-layout weights
+
+    # ---- registration (idempotent per tensor: S3D registers its stem twice)
+    def _add(self, t, kind, **kw):
+        if id(t) in self._by_id:
+            return self._by_id[id(t)]
+        s = Slot()
+        s.tensor, s.kind = t, kind
+        s.Cout = s.Cin = s.taps = s.cin_pitch = s.cout_pitch = 0
+        s.wd_off = -1
+        for k, v in kw.items():
+            setattr(s, k, v)
+        self.slots.append(s)
+        self._by_id[id(t)] = s
+        return s
+
+    def add_conv(self, weight, cin_pitch=None, need_dgrad=True):
+        """weight: [O, I, kt, kh, kw] or [O, I] parameter."""
+        O, I = weight.shape[:2]
+        taps = 1
+        for d in weight.shape[2:]:
+            taps *= d
+        return self._add(weight, 'conv', Cout=O, Cin=I, taps=taps, cin_pitch=cin_pitch or cp8(I), cout_pitch=cp8(O),
+                         wd_off=0 if (need_dgrad and not self.no_dgrad) else -1)
+
+    def add_vec(self, t):
+        return self._add(t, 'vec')
+
+    def add_bn(self, bn):
+        self.add_vec(bn.weight)
+        self.add_vec(bn.bias)
+        if bn not in self.nbt:
+            self.nbt.append(bn)
+
+    def slot(self, t):
+        return self._by_id[id(t)]
+
+    # ---- materialisation
+    def ready(self, device, dtype):
+        if self.master is None or self.master.device != device or self.dtype != dtype:
+            return False
+        s0, s1 = self.slots[0], self.slots[-1]
+        es = 4
+        return (s0.tensor.data_ptr() == self.master.data_ptr() + s0.off * es and
+                s1.tensor.data_ptr() == self.master.data_ptr() + s1.off * es)
+
+    def _view(self, arena, s):
+        if s.kind == 'vec':
+            return arena.narrow(0, s.off, s.tensor.numel()).view(s.tensor.shape)
+        return torch.as_strided(arena, s.shape, s.strides, s.off)
+
+    def materialize(self, device, dtype):
+        L.require_device()
+        off = 0
+        wd_off = 0
+        for s in self.slots:
+            s.off = off
+            if s.kind == 'vec':
+                s.size = _align8(s.tensor.numel())
+            else:
+                s.size = s.Cout * s.taps * s.cin_pitch
+                shp = tuple(s.tensor.shape)
+                rowp = s.taps * s.cin_pitch
+                if len(shp) == 5:
+                    kt, kh, kw = shp[2:]
+                    s.strides = (rowp, 1, kh * kw * s.cin_pitch, kw * s.cin_pitch, s.cin_pitch)
+                else:
+                    s.strides = (rowp, 1)
+                s.shape = shp
+                if s.wd_off >= 0:
+                    s.wd_off = wd_off
+                    wd_off += _align8(s.Cin * s.taps * s.cout_pitch)
+            off += _align8(s.size)
+        self.total = off
+        master = torch.zeros(off, dtype=torch.float32, device=device)
+        grad = torch.zeros(off, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for s in self.slots:
+                v = self._view(master, s)
+                v.copy_(s.tensor.data.to(device=device, dtype=torch.float32))
+                rg = s.tensor.requires_grad
+                s.tensor.data = v
+                s.tensor.grad = self._view(grad, s) if rg else None
+        self.master, self.grad, self.dtype = master, grad, dtype
+        self.cc = master if dtype == DV_F32 else torch.zeros(off, dtype=torch.bfloat16, device=device)
+        self.wd = torch.zeros(max(wd_off, 8), dtype=ops.TORCH_DTYPE[dtype], device=device)
+        # pack descriptors (device copies)
+        packs = [s for s in self.slots if s.kind == 'conv' and s.wd_off >= 0]
+        self._n_pack_blocks = 0
+        if packs:
+            arr = (L.PackDesc * len(packs))()
+            bmap = []
+            for i, s in enumerate(packs):
+                a = arr[i]
+                a.src_off, a.dst_off, a.Cout, a.Cin, a.taps, a.cin_pitch, a.cout_pitch = \
+                    s.off, s.wd_off, s.Cout, s.Cin, s.taps, s.cin_pitch, s.cout_pitch
+                bmap += [(i, c) for c in range(s.Cin)]
+            self._pack_descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+            self._pack_map = torch.tensor(bmap, dtype=torch.int32).to(device)
+            self._n_pack_blocks = len(bmap)
+        # BN counters in one int64 arena
+        if self.nbt:
+            self._nbt_arena = torch.zeros(len(self.nbt), dtype=torch.long, device=device)
+            for i, bn in enumerate(self.nbt):
+                if bn.num_batches_tracked is not None:
+                    self._nbt_arena[i] = int(bn.num_batches_tracked)
+                    bn.num_batches_tracked.data = self._nbt_arena[i]
+                for nm in ('running_mean', 'running_var'):
+                    b = getattr(bn, nm)
+                    if b.device != device:
+                        b.data = b.data.to(device)
+        self.generation += 1
+        self._dirty = True
+        self._versions = None
+
+    def attach_grads(self):
+        """Re-attach .grad views (e.g. after zero_grad(set_to_none=True)); zeroes the arena if any was dropped."""
+        dropped = False
+        for s in self.slots:
+            if s.tensor.requires_grad and s.tensor.grad is None:
+                dropped = True
+                s.tensor.grad = self._view(self.grad, s)
+        if dropped:
+            self.grad.zero_()
+
+    def zero_grad(self):
+        if self.grad is not None:
+            self.grad.zero_()
+
+    def mark_dirty(self, cast_done=False):
+        self._dirty = True
+        self._cast_done = cast_done
+
+    def _version_sum(self):
+        return sum(s.tensor._version for s in self.slots)
+
+    def refresh(self, check_versions=True):
+        """Bring the compute-dtype copy and the dgrad-layout weights up to date with the master."""
+        if not self._dirty and check_versions:
+            v = self._version_sum()
+            if v != self._versions:
+                self._dirty = True
+        if not self._dirty:
+            return
+        if self.dtype == DV_BF16 and not self._cast_done:
+            ops.call('dv_cast_arena', DV_BF16, self.master, self.cc, self.total)
+        if self._n_pack_blocks:
+            ops.call('dv_pack_dgrad_weights', self.dtype, self.master, self.wd, self._pack_descs, self._pack_map,
+                     self._n_pack_blocks)
+        self._dirty = False
+        self._cast_done = False
+        self._versions = self._version_sum()
+
+    # pointers
+    def w_fwd(self, s):
+        return self.cc.data_ptr() + s.off * ops.ESIZE[self.dtype]
+
+    def w_master(self, s):
+        return self.master.data_ptr() + s.off * 4
+
+    def w_grad(self, s):
+        return self.grad.data_ptr() + s.off * 4
+
+    def w_dgrad(self, s):
+        return self.wd.data_ptr() + s.wd_off * ops.ESIZE[self.dtype]
+
+    def bump_bn_counters(self):
+        if self.nbt:
+            self._nbt_arena += 1
+
+
+class Comm:
+    """Data-parallel context for SyncBatchNorm statistics (one process per GPU, RCCL)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+
+
+class Plan:
+    """Static forward/backward launch lists for one backbone at one input shape."""
+
+    def __init__(self, store, dtype, device, with_grad=True, comm=None):
+        self.store, self.dtype, self.device, self.with_grad = store, dtype, device, with_grad
+        self.comm = comm if comm is not None else Comm()
+        self.fwd, self.bwd_ops = [], []
+        self._acts = []
+        self.busy = False
+        self.bytes = 0
+        self.lib = L.load()
+
+    # ------------------------------------------------------------------ buffers
+    def act(self, N, T, H, W, C_, dtype=None, cpitch=None, grad=None, zero=False):
+        dtype = self.dtype if dtype is None else dtype
+        a = ops.new_act(N, T, H, W, C_, dtype, self.device, cpitch=cpitch, zero=zero)
+        self.bytes += a.buf.numel() * a.buf.element_size()
+        want_grad = self.with_grad if grad is None else grad
+        if want_grad:
+            a.grad = ops.new_act(N, T, H, W, C_, dtype, self.device, cpitch=cpitch, zero=True)
+            self.bytes += a.buf.numel() * a.buf.element_size()
+        self._acts.append(a)
+        return a
+
+    def slice(self, a, off, C_):
+        s = a.slice(off, C_)
+        if a.grad is not None:
+            s.grad = a.grad.slice(off, C_)
+        return s
+
+    def f32(self, *shape, zero=True):
+        t = (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=self.device)
+        self.bytes += t.numel() * 4
+        return t
+
+    # ------------------------------------------------------------------ graph ops
+    def _push(self, op):
+        self.fwd.append(op)
+        self.bwd_ops.append(op)
+        return op
+
+    def conv(self, slot, x, k, s, p, out=None, stats=True, dtype=None, bias=None, act_flags=0):
+        op = self._push(ConvOp(self, slot, x, k, s, p, out, stats, dtype, bias, act_flags))
+        op.y.producer = op
+        return op.y
+
+    def bn(self, bn_mod, x, relu=True, residual=None, out=None):
+        return self._push(BNOp(self, bn_mod, x, relu, residual, out, x.producer)).y
+
+    def maxpool(self, x, k, s, p):
+        return self._push(PoolOp(self, x, k, s, p)).y
+
+    def gate(self, fc, x, out):
+        return self._push(GateOp(self, fc, x, out)).y
+
+    def spatial_mean(self, x):
+        return self._push(MeanOp(self, x)).out
+
+    def finalize(self):
+        # the last consumer (forward order) of an activation is the first writer of its gradient
+        seen = set()
+        for op in reversed(self.fwd):
+            for name, a in op.grad_targets():
+                key = (a.buf.data_ptr(), a.off)
+                op.acc[name] = key in seen
+                seen.add(key)
+        for op in self.fwd:
+            op.prepare()
+
+    # ------------------------------------------------------------------ execution
+    def run_forward(self):
+        for op in self.fwd:
+            op.forward()
+
+    def run_backward(self):
+        for op in reversed(self.bwd_ops):
+            op.backward()
+
+
+class Op:
+    def __init__(self, plan):
+        self.plan = plan
+        self.acc = {}
+
+    def grad_targets(self):
+        return []
+
+    def prepare(self):
+        pass
+
+    def forward(self):
+        raise NotImplementedError
+
+    def backward(self):
+        pass
+
+
+class ConvOp(Op):
+    """conv (bias-free, BN partial statistics in the epilogue) with wgrad + dgrad."""
+
+    def __init__(self, plan, slot, x, k, s, p, out, stats, dtype, bias, act_flags):
+        super().__init__(plan)
+        self.slot, self.x = slot, x
+        dtype = plan.dtype if dtype is None else dtype
+        self.dtype = dtype
+        To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
+        self.y = out if out is not None else plan.act(x.N, To, Ho, Wo, slot.Cout, dtype=dtype)
+        assert x.cpitch == slot.cin_pitch, (x.cpitch, slot.cin_pitch)
+        flags = act_flags | (DV_STATS if stats else 0) | (DV_BIAS if bias is not None else 0)
+        self.d = ops.conv_desc(dtype, x, self.y, k, s, p, flags=flags)
+        self.d_b = ops.conv_desc(dtype, x, self.y, k, s, p, flags=0)
+        self.bias = bias
+        self.tiles = ops.stat_tiles(self.d)
+        self.stats = plan.f32(self.tiles, 2, slot.Cout) if stats else None
+        self.need_dx = plan.with_grad and x.grad is not None and slot.wd_off >= 0
+        self.f32_weights = dtype == DV_F32 and plan.dtype != DV_F32
+
+    def grad_targets(self):
+        return [('x', self.x)] if self.need_dx else []
+
+    def prepare(self):
+        st, lib, d = self.plan.store, self.plan.lib, self.d
+        w = st.w_master(self.slot) if self.f32_weights else st.w_fwd(self.slot)
+        bias = self.bias.data_ptr() if self.bias is not None else 0
+        self._f = (lib.dv_conv3d_fwd, C.byref(d), self.x.ptr, w, bias, self.y.ptr,
+                   self.stats.data_ptr() if self.stats is not None else 0)
+        if self.plan.with_grad:
+            self._wg = (lib.dv_conv3d_wgrad, C.byref(self.d_b), self.x.ptr, self.y.grad.ptr, st.w_grad(self.slot))
+            if self.need_dx:
+                self.d_b2 = ops.conv_desc(self.dtype, self.x, self.y, (self.d.kt, self.d.kh, self.d.kw),
+                                          (self.d.st, self.d.sh, self.d.sw), (self.d.pt, self.d.ph, self.d.pw),
+                                          flags=DV_ACCUM if self.acc.get('x') else 0)
+                self._dg = (lib.dv_conv3d_dgrad, C.byref(self.d_b2), self.y.grad.ptr, st.w_dgrad(self.slot), self.x.grad.ptr)
+
+    def forward(self):
+        f = self._f
+        L.check(f[0](*f[1:], ops.stream_ptr()), 'dv_conv3d_fwd')
+
+    def backward(self):
+        s = ops.stream_ptr()
+        f = self._wg
+        L.check(f[0](*f[1:], s), 'dv_conv3d_wgrad')
+        if self.need_dx:
+            f = self._dg
+            L.check(f[0](*f[1:], s), 'dv_conv3d_dgrad')
+
+
+class BNOp(Op):
+    """training-mode BatchNorm (+residual) (+ReLU); cross-rank statistics when world > 1."""
+
+    def __init__(self, plan, bn, x, relu, residual, out, stats_from):
+        super().__init__(plan)
+        self.bn, self.x, self.relu, self.res = bn, x, relu, residual
+        self.C = x.C
+        self.M = x.rows
+        self.y = out if out is not None else plan.act(x.N, x.T, x.H, x.W, x.C)
+        self.conv = stats_from
+        Cn, R = self.C, plan.comm.world
+        self.local = plan.f32(2 * Cn + 1)
+        self.gathered = plan.f32(R, 2 * Cn + 1) if R > 1 else self.local
+        self.mean, self.invstd, self.scale, self.shift = (plan.f32(Cn) for _ in range(4))
+        if plan.with_grad:
+            self.nb = plan.lib.dv_bn_bwd_blocks(self.M, Cn)
+            self.part = plan.f32(self.nb, 2, Cn)
+            self.sums = plan.f32(2, Cn)
+            self.sums_g = plan.f32(2, Cn) if R > 1 else self.sums
+
+    def grad_targets(self):
+        return [('res', self.res)] if (self.res is not None and self.res.grad is not None and self.plan.with_grad) else []
+
+    def prepare(self):
+        p, st, bn = self.plan, self.plan.store, self.bn
+        self.gslot, self.bslot = st.slot(bn.weight), st.slot(bn.bias)
+        self.flags = DV_RELU if self.relu else 0
+        self.bflags = 0 if self.relu else DV_NO_RELU_MASK
+        if self.res is not None and self.acc.get('res'):
+            self.bflags |= DV_ACCUM
+        self.rm = bn.running_mean.data_ptr() if bn.running_mean is not None else 0
+        self.rv = bn.running_var.data_ptr() if bn.running_var is not None else 0
+        self.eps, self.mom = float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1)
+
+    def forward(self):
+        p, lib, s = self.plan, self.plan.lib, ops.stream_ptr()
+        Cn, x, y = self.C, self.x, self.y
+        st = p.store
+        L.check(lib.dv_bn_reduce_stats(self.conv.stats.data_ptr(), self.conv.tiles, 128, self.M, Cn,
+                                       self.local.data_ptr(), s), 'dv_bn_reduce_stats')
+        R = p.comm.world
+        if R > 1:
+            dist.all_gather_into_tensor(self.gathered.view(-1), self.local, group=p.comm.group)
+        L.check(lib.dv_bn_finalize(self.gathered.data_ptr(), R, Cn, st.w_master(self.gslot), st.w_master(self.bslot),
+                                   self.eps, self.mom, self.rm, self.rv, self.mean.data_ptr(), self.invstd.data_ptr(),
+                                   self.scale.data_ptr(), self.shift.data_ptr(), s), 'dv_bn_finalize')
+        res = self.res
+        L.check(lib.dv_bn_apply(p.dtype, x.ptr, x.ld, self.scale.data_ptr(), self.shift.data_ptr(),
+                                res.ptr if res is not None else 0, res.ld if res is not None else 0, y.ptr, y.ld,
+                                self.M, Cn, self.flags, s), 'dv_bn_apply')
+
+    def backward(self):
+        p, lib, s = self.plan, self.plan.lib, ops.stream_ptr()
+        Cn, x, y, st = self.C, self.x, self.y, self.plan.store
+        dy = y.grad
+        L.check(lib.dv_bn_bwd_reduce(p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, self.mean.data_ptr(),
+                                     self.invstd.data_ptr(), self.M, Cn, self.bflags & DV_NO_RELU_MASK,
+                                     self.part.data_ptr(), s), 'dv_bn_bwd_reduce')
+        L.check(lib.dv_bn_bwd_finalize(self.part.data_ptr(), self.nb, Cn, self.sums.data_ptr(), s), 'dv_bn_bwd_finalize')
+        R = p.comm.world
+        if R > 1:
+            self.sums_g.copy_(self.sums)
+            dist.all_reduce(self.sums_g, group=p.comm.group)
+        res = self.res
+        dres = res.grad if (res is not None and res.grad is not None) else None
+        L.check(lib.dv_bn_bwd_apply(p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, self.mean.data_ptr(),
+                                    self.invstd.data_ptr(), st.w_master(self.gslot), self.sums_g.data_ptr(),
+                                    self.sums.data_ptr(), 1.0 / (self.M * R), st.w_grad(self.gslot), st.w_grad(self.bslot),
+                                    x.grad.ptr, x.grad.ld, dres.ptr if dres is not None else 0,
+                                    dres.ld if dres is not None else 0, self.M, Cn, self.bflags, s), 'dv_bn_bwd_apply')
+
+
+class PoolOp(Op):
+    def __init__(self, plan, x, k, s, p):
+        super().__init__(plan)
+        self.x = x
+        To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
+        self.y = plan.act(x.N, To, Ho, Wo, x.C)
+        self.idx = torch.empty(self.y.rows, cp8(x.C), dtype=torch.uint8, device=plan.device)
+        plan.bytes += self.idx.numel()
+        self.d = ops.pool_desc(plan.dtype, x, self.y, k, s, p)
+        self.need_dx = plan.with_grad and x.grad is not None
+
+    def grad_targets(self):
+        return [('x', self.x)] if self.need_dx else []
+
+    def forward(self):
+        L.check(self.plan.lib.dv_maxpool3d_fwd(C.byref(self.d), self.x.ptr, self.y.ptr, self.idx.data_ptr(),
+                                               ops.stream_ptr()), 'dv_maxpool3d_fwd')
+
+    def backward(self):
+        if self.need_dx:
+            L.check(self.plan.lib.dv_maxpool3d_bwd(C.byref(self.d), self.y.grad.ptr, self.idx.data_ptr(), self.x.grad.ptr,
+                                                   DV_ACCUM if self.acc.get('x') else 0, ops.stream_ptr()),
+                    'dv_maxpool3d_bwd')
+
+
+class GateOp(Op):
+    """S3D-G self gating: out = x * sigmoid(fc(mean_thw x)), written into a concat slice."""
+
+    def __init__(self, plan, fc, x, out):
+        super().__init__(plan)
+        self.fc, self.x, self.y = fc, x, out
+        N, Cn = x.N, x.C
+        self.mean = plan.f32(N, Cn)
+        self.g = plan.f32(N, Cn)
+        # fc as a 1x1x1 fp32 conv over [N,1,1,1,C] with bias + sigmoid epilogue
+        self.a_mean = Act(self.mean, N, 1, 1, 1, Cn, Cn, 0, DV_F32, Cn)
+        self.a_g = Act(self.g, N, 1, 1, 1, Cn, Cn, 0, DV_F32, Cn)
+        self.d = ops.conv_desc(DV_F32, self.a_mean, self.a_g, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=DV_BIAS | DV_SIGMOID)
+        if plan.with_grad:
+            self.dpre = plan.f32(N, Cn)
+            self.dmean = plan.f32(N, Cn)
+
+    def grad_targets(self):
+        return []          # x (the branch's BN output) has this op as its only consumer
+
+    def prepare(self):
+        st = self.plan.store
+        self.ws, self.bs = st.slot(self.fc.weight), st.slot(self.fc.bias)
+
+    def forward(self):
+        p, lib, s, x, y = self.plan, self.plan.lib, ops.stream_ptr(), self.x, self.y
+        st = p.store
+        L.check(lib.dv_spatial_mean(p.dtype, x.ptr, x.ld, x.N, x.S, x.C, self.mean.data_ptr(), s), 'dv_spatial_mean')
+        L.check(lib.dv_conv3d_fwd(C.byref(self.d), self.mean.data_ptr(), st.w_master(self.ws), st.w_master(self.bs),
+                                  self.g.data_ptr(), 0, s), 'gate fc')
+        L.check(lib.dv_gate_scale(p.dtype, x.ptr, x.ld, self.g.data_ptr(), x.N, x.S, x.C, y.ptr, y.ld, s), 'dv_gate_scale')
+
+    def backward(self):
+        p, lib, s, x, y = self.plan, self.plan.lib, ops.stream_ptr(), self.x, self.y
+        st, N, Cn = p.store, x.N, x.C
+        dy = y.grad
+        L.check(lib.dv_gate_bwd_reduce(p.dtype, dy.ptr, dy.ld, x.ptr, x.ld, self.g.data_ptr(), N, x.S, Cn,
+                                       self.dpre.data_ptr(), s), 'dv_gate_bwd_reduce')
+        w, cinp = st.w_master(self.ws), self.ws.cin_pitch
+        # dmean = dpre @ W ; dW += dpre^T @ mean ; db += colsum(dpre)
+        L.check(lib.dv_gemm_f32(N, Cn, Cn, self.dpre.data_ptr(), Cn, 1, w, cinp, 1, self.dmean.data_ptr(), Cn, 1.0, 0, s), 'gate dmean')
+        L.check(lib.dv_gemm_f32(Cn, Cn, N, self.dpre.data_ptr(), 1, Cn, self.mean.data_ptr(), Cn, 1, st.w_grad(self.ws), cinp, 1.0, 1, s), 'gate dW')
+        L.check(lib.dv_colsum_f32(self.dpre.data_ptr(), Cn, N, Cn, st.w_grad(self.bs), s), 'gate db')
+        L.check(lib.dv_gate_bwd_apply(p.dtype, dy.ptr, dy.ld, self.g.data_ptr(), self.dmean.data_ptr(), N, x.S, Cn,
+                                      x.grad.ptr, x.grad.ld, 0, s), 'dv_gate_bwd_apply')
+
+
+class MeanOp(Op):
+    """global average pool -> fp32 [N, C] (AdaptiveAvgPool3d((1,1,1)))."""
+
+    def __init__(self, plan, x):
+        super().__init__(plan)
+        self.x = x
+        self.out = plan.f32(x.N, x.C)
+        self.dout = plan.f32(x.N, x.C) if plan.with_grad else None
+
+    def grad_targets(self):
+        return [('x', self.x)] if (self.plan.with_grad and self.x.grad is not None) else []
+
+    def forward(self):
+        p, x = self.plan, self.x
+        L.check(p.lib.dv_spatial_mean(p.dtype, x.ptr, x.ld, x.N, x.S, x.C, self.out.data_ptr(), ops.stream_ptr()), 'dv_spatial_mean')
+
+    def backward(self):
+        p, x = self.plan, self.x
+        L.check(p.lib.dv_spatial_mean_bwd(p.dtype, self.dout.data_ptr(), x.N, x.S, x.C, x.grad.ptr, x.grad.ld,
+                                          DV_ACCUM if self.acc.get('x') else 0, ops.stream_ptr()), 'dv_spatial_mean_bwd')

@@ -1,0 +1,284 @@
+"""torch.autograd.Function wrappers over the fp32 head / loss kernels.
+
+These are the small ops after the backbone (a few KB..MB per step): projection heads, L2
+normalisation, the fused similarity + cross-entropy objectives.  All arithmetic is in the HIP
+library; torch only provides autograd plumbing, views and allocation.  Parameter gradients are
+accumulated straight into the owning ParamStore's gradient arena (like the backbone's)."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import DV_BIAS, DV_F32, DV_RELU, Act
+
+
+def _lib():
+    return L.load()
+
+
+def _chk(rc, what):
+    L.check(rc, what)
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise L.DualVarHipError('this op runs on the MI355X only; got a %s tensor (no CPU fallback)' % t.device)
+    L.require_device()
+
+
+class ProjectionHead:
+    """pooled [n,F] -> Conv1x1x1(F->F)+bias -> ReLU -> Conv1x1x1(F->D)+bias   (simclr.py:45-50,167-180;
+    moco.py:56-72,282-308).  `conv_a`, `conv_b` are nn.Conv3d parameter holders registered in `store`."""
+
+    def __init__(self, store, conv_a, conv_b):
+        self.store, self.a, self.b = store, conv_a, conv_b
+
+    @staticmethod
+    def register(store, conv_a, conv_b):
+        for c in (conv_a, conv_b):
+            store.add_conv(c.weight, need_dgrad=False)
+            store.add_vec(c.bias)
+
+    def __call__(self, pooled):
+        return _HeadFn.apply(pooled, self)
+
+    def _linear(self, x, conv, flags):
+        st, lib = self.store, _lib()
+        ws, bs = st.slot(conv.weight), st.slot(conv.bias)
+        n, fin, fout = x.shape[0], ws.Cin, ws.Cout
+        y = torch.empty(n, fout, dtype=torch.float32, device=x.device)
+        ax = Act(x, n, 1, 1, 1, fin, fin, 0, DV_F32, ws.cin_pitch)
+        ay = Act(y, n, 1, 1, 1, fout, fout, 0, DV_F32, fout)
+        assert fin == ws.cin_pitch and fout % 8 == 0, 'head widths must be multiples of 8'
+        d = ops.conv_desc(DV_F32, ax, ay, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=flags | DV_BIAS)
+        _chk(lib.dv_conv3d_fwd(C.byref(d), x.data_ptr(), st.w_master(ws), st.w_master(bs), y.data_ptr(), 0,
+                               ops.stream_ptr()), 'head linear')
+        return y
+
+    def _linear_bwd(self, dy, x, conv, need_dx=True):
+        """accumulates dW, db into the gradient arena; returns dx"""
+        st, lib, s = self.store, _lib(), ops.stream_ptr()
+        ws, bs = st.slot(conv.weight), st.slot(conv.bias)
+        n, fin, fout = x.shape[0], ws.Cin, ws.Cout
+        if conv.weight.requires_grad:
+            _chk(lib.dv_gemm_f32(fout, fin, n, dy.data_ptr(), 1, fout, x.data_ptr(), fin, 1, st.w_grad(ws), ws.cin_pitch,
+                                 1.0, 1, s), 'head dW')
+            _chk(lib.dv_colsum_f32(dy.data_ptr(), fout, n, fout, st.w_grad(bs), s), 'head db')
+        if not need_dx:
+            return None
+        dx = torch.empty(n, fin, dtype=torch.float32, device=x.device)
+        _chk(lib.dv_gemm_f32(n, fin, fout, dy.data_ptr(), fout, 1, st.w_master(ws), ws.cin_pitch, 1, dx.data_ptr(), fin,
+                             1.0, 0, s), 'head dx')
+        return dx
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pooled, head):
+        _need_gpu(pooled)
+        x = _f32c(pooled)
+        h = head._linear(x, head.a, DV_RELU)
+        z = head._linear(h, head.b, 0)
+        ctx.head = head
+        ctx.save_for_backward(x, h)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        head = ctx.head
+        x, h = ctx.saved_tensors
+        head.store.attach_grads()
+        dz = _f32c(dz)
+        dh = head._linear_bwd(dz, h, head.b)
+        dh2 = torch.empty_like(dh)
+        _chk(_lib().dv_relu_bwd_f32(dh.data_ptr(), h.data_ptr(), dh.numel(), dh2.data_ptr(), ops.stream_ptr()), 'relu bwd')
+        dx = head._linear_bwd(dh2, x, head.a, need_dx=ctx.needs_input_grad[0])
+        return dx, None
+
+
+class _L2NormFn(torch.autograd.Function):
+    """F.normalize(x, dim=-1, eps=1e-12) on [..., D]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        xc = _f32c(x)
+        D = xc.shape[-1]
+        R = xc.numel() // D
+        y = torch.empty_like(xc)
+        nrm = torch.empty(R, dtype=torch.float32, device=x.device)
+        _chk(_lib().dv_l2norm_fwd(xc.data_ptr(), R, D, 1e-12, y.data_ptr(), nrm.data_ptr(), ops.stream_ptr()), 'l2norm')
+        ctx.save_for_backward(y, nrm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, nrm = ctx.saved_tensors
+        dy = _f32c(dy)
+        D = y.shape[-1]
+        dx = torch.empty_like(y)
+        _chk(_lib().dv_l2norm_bwd(dy.data_ptr(), y.data_ptr(), nrm.data_ptr(), y.numel() // D, D, dx.data_ptr(),
+                                  ops.stream_ptr()), 'l2norm bwd')
+        return dx
+
+
+def l2_normalize(x):
+    return _L2NormFn.apply(x)
+
+
+class _GroupMeanFn(torch.autograd.Function):
+    """[R, G, D] -> [R, D] mean over G (the series-mean vector of the tc head)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        xc = _f32c(x)
+        R, G, D = xc.shape
+        y = torch.empty(R, D, dtype=torch.float32, device=x.device)
+        _chk(_lib().dv_group_mean_f32(xc.data_ptr(), R, G, D, y.data_ptr(), ops.stream_ptr()), 'group mean')
+        ctx.shape = (R, G, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        R, G, D = ctx.shape
+        dy = _f32c(dy)
+        dx = torch.empty(R, G, D, dtype=torch.float32, device=dy.device)
+        _chk(_lib().dv_group_mean_bwd_f32(dy.data_ptr(), R, G, D, dx.data_ptr(), ops.stream_ptr()), 'group mean bwd')
+        return dx
+
+
+def group_mean(x):
+    return _GroupMeanFn.apply(x)
+
+
+class _GroupTileFn(torch.autograd.Function):
+    """[R, D] -> [R, G, D] with every copy divided by G (adjoint of group_mean)."""
+
+    @staticmethod
+    def forward(ctx, x, G):
+        _need_gpu(x)
+        xc = _f32c(x)
+        R, D = xc.shape
+        y = torch.empty(R, G, D, dtype=torch.float32, device=x.device)
+        _chk(_lib().dv_group_mean_bwd_f32(xc.data_ptr(), R, G, D, y.data_ptr(), ops.stream_ptr()), 'group tile')
+        ctx.shape = (R, G, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        R, G, D = ctx.shape
+        dy = _f32c(dy)
+        dx = torch.empty(R, D, dtype=torch.float32, device=dy.device)
+        _chk(_lib().dv_group_mean_f32(dy.data_ptr(), R, G, D, dx.data_ptr(), ops.stream_ptr()), 'group tile bwd')
+        return dx, None
+
+
+def group_tile_div(x, G):
+    return _GroupTileFn.apply(x, G)
+
+
+class _NTXentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, cols, n_local, N, row_index0, inv_T):
+        _need_gpu(rows)
+        rows, cols = _f32c(rows), _f32c(cols)
+        R, D = rows.shape
+        dev = rows.device
+        logits = torch.empty(R, 2 * N - 1, dtype=torch.float32, device=dev)
+        loss_rows = torch.empty(R, dtype=torch.float32, device=dev)
+        rank0 = torch.empty(R, dtype=torch.int32, device=dev)
+        dsim = torch.empty(R, 2 * N, dtype=torch.float32, device=dev)
+        lib, s = _lib(), ops.stream_ptr()
+        _chk(lib.dv_ntxent_fwd(rows.data_ptr(), cols.data_ptr(), R, n_local, N, D, row_index0, inv_T, logits.data_ptr(),
+                               loss_rows.data_ptr(), rank0.data_ptr(), dsim.data_ptr(), s), 'dv_ntxent_fwd')
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _chk(lib.dv_mean_f32(loss_rows.data_ptr(), R, loss.data_ptr(), s), 'mean')
+        ctx.save_for_backward(rows, cols, dsim)
+        ctx.mark_non_differentiable(logits, rank0)
+        return loss, logits, rank0
+
+    @staticmethod
+    def backward(ctx, gloss, _gl, _gr):
+        rows, cols, dsim = ctx.saved_tensors
+        R, D = rows.shape
+        C2 = cols.shape[0]
+        lib, s = _lib(), ops.stream_ptr()
+        drows = torch.empty_like(rows)
+        dcols = torch.empty_like(cols)
+        _chk(lib.dv_gemm_f32(R, D, C2, dsim.data_ptr(), C2, 1, cols.data_ptr(), D, 1, drows.data_ptr(), D, 1.0, 0, s), 'ntxent drows')
+        _chk(lib.dv_gemm_f32(C2, D, R, dsim.data_ptr(), 1, C2, rows.data_ptr(), D, 1, dcols.data_ptr(), D, 1.0, 0, s), 'ntxent dcols')
+        # upstream gradient of the scalar loss (1.0 in the reference's plain sum of heads)
+        return drows * gloss, dcols * gloss, None, None, None, None
+
+
+def ntxent(rows, cols, n_local, N, row_index0, temperature):
+    """NT-Xent of `rows` (this rank's view-major [2*n_local, D]) against `cols` (gathered view-major
+    [2N, D]).  Returns (loss, logits [R, 2N-1] in the reference's [positive, negatives] layout, rank0)."""
+    return _NTXentFn.apply(rows, cols, n_local, N, row_index0, 1.0 / temperature)
+
+
+class _InfoNCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, queue, inv_T):
+        _need_gpu(q)
+        q, k, queue = _f32c(q), _f32c(k), _f32c(queue)
+        B, D = q.shape
+        K = queue.shape[1]
+        dev = q.device
+        logits = torch.empty(B, K + 1, dtype=torch.float32, device=dev)
+        dlog = torch.empty(B, K + 1, dtype=torch.float32, device=dev)
+        loss_rows = torch.empty(B, dtype=torch.float32, device=dev)
+        rank0 = torch.empty(B, dtype=torch.int32, device=dev)
+        dq = torch.empty(B, D, dtype=torch.float32, device=dev)
+        lib, s = _lib(), ops.stream_ptr()
+        _chk(lib.dv_infonce_fwd(q.data_ptr(), k.data_ptr(), queue.data_ptr(), B, D, K, inv_T, logits.data_ptr(),
+                                loss_rows.data_ptr(), rank0.data_ptr(), dlog.data_ptr(), dq.data_ptr(), s), 'dv_infonce_fwd')
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _chk(lib.dv_mean_f32(loss_rows.data_ptr(), B, loss.data_ptr(), s), 'mean')
+        ctx.save_for_backward(dq)
+        ctx.mark_non_differentiable(logits, rank0)
+        return loss, logits, rank0
+
+    @staticmethod
+    def backward(ctx, gloss, _gl, _gr):
+        (dq,) = ctx.saved_tensors
+        return dq * gloss, None, None, None
+
+
+def infonce(q, k, queue, temperature):
+    """MoCo InfoNCE: logits [B, 1+K] = [q.k, q.queue]/T (queue [D, K], no gradient to k / queue)."""
+    return _InfoNCEFn.apply(q, k, queue, 1.0 / temperature)
+
+
+class _RankMarginFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, s, theta, clip, weight):
+        _need_gpu(feats)
+        f = _f32c(feats)
+        Bn, n2, D = f.shape
+        dev = f.device
+        logits = torch.empty(Bn * n2, n2 - 1, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        df = torch.empty_like(f)
+        scr = torch.empty(Bn, dtype=torch.float32, device=dev)
+        _chk(_lib().dv_rank_margin(f.data_ptr(), Bn, s, D, theta, clip, weight, logits.data_ptr(), loss.data_ptr(),
+                                   df.data_ptr(), scr.data_ptr(), ops.stream_ptr()), 'dv_rank_margin')
+        ctx.save_for_backward(df)
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, gloss, _gl):
+        (df,) = ctx.saved_tensors
+        return df * gloss, None, None, None, None
+
+
+def rank_margin(feats_vm, n_series, theta, clip, weight):
+    """feats_vm [Bn, 2*n_series, D] (view-major per sample).  clip <= 0 disables the clamp (MoCo variant)."""
+    return _RankMarginFn.apply(feats_vm, n_series, float(theta), float(clip) if clip else 0.0, float(weight))

@@ -23,12 +23,13 @@ def stream_ptr():
 
 class Act:
     """[N,T,H,W,C] view with row pitch `ld` starting at channel `off` of `buf` ([rows, ld_total])."""
-    __slots__ = ('buf', 'N', 'T', 'H', 'W', 'C', 'ld', 'off', 'dtype', 'grad', 'cpitch')
+    __slots__ = ('buf', 'N', 'T', 'H', 'W', 'C', 'ld', 'off', 'dtype', 'grad', 'cpitch', 'producer')
 
     def __init__(self, buf, N, T, H, W, C, ld, off, dtype, cpitch=None):
         self.buf, self.N, self.T, self.H, self.W, self.C, self.ld, self.off, self.dtype = buf, N, T, H, W, C, ld, off, dtype
         self.cpitch = cpitch if cpitch is not None else cp8(C)
         self.grad = None
+        self.producer = None
 
     @property
     def rows(self):

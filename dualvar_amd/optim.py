@@ -1,0 +1,54 @@
+"""Fused SGD over the parameter arenas (pretrain.py:262-272,451: SGD, momentum 0.9, weight decay applied to
+every tensor incl. BN and biases, one lr for all groups).
+
+One launch per encoder updates master weights, momentum and the bf16 compute copy; the class derives from
+torch.optim.Optimizer only so that torch LR schedulers (MultiStepLR, pretrain.py:328) drive `param_groups`."""
+import torch
+
+from . import ops
+
+
+class SGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=0.03, momentum=0.9, weight_decay=0.0, stores=None, grad_sync=None):
+        if stores is None:
+            raise ValueError('dualvar_amd.optim.SGD updates ParamStore arenas: pass stores=model.stores()')
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self.stores = list(stores)
+        self.grad_sync = grad_sync
+        self._buf = {}
+
+    def _momentum_buf(self, st):
+        b = self._buf.get(id(st))
+        if b is None or b.numel() != st.total or b.device != st.master.device:
+            b = torch.zeros(st.total, dtype=torch.float32, device=st.master.device)
+            self._buf[id(st)] = b
+        return b
+
+    def zero_grad(self, set_to_none=False):
+        for st in self.stores:
+            st.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        lr, mu, wd = float(g['lr']), float(g['momentum']), float(g['weight_decay'])
+        for st in self.stores:
+            if st.master is None:
+                continue
+            scale = 1.0
+            if self.grad_sync is not None:
+                scale = self.grad_sync(st)
+            copy = st.cc if st.dtype != ops.DV_F32 else None
+            ops.call('dv_sgd_momentum', st.master, st.grad, self._momentum_buf(st), st.total, lr, mu, wd, scale,
+                     st.dtype, copy)
+            st.mark_dirty(cast_done=True)
+
+    def state_dict(self):
+        return {'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups],
+                'momentum_arenas': [self._momentum_buf(st).detach().cpu() for st in self.stores if st.master is not None]}
+
+    def load_state_dict(self, sd):
+        for g, s in zip(self.param_groups, sd['param_groups']):
+            g.update(s)
+        for st, b in zip([s for s in self.stores if s.master is not None], sd.get('momentum_arenas', [])):
+            self._momentum_buf(st).copy_(b)
