@@ -21,7 +21,7 @@ from oracle import harness, procedural as P, torch_ref as O   # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 ARGS = types.SimpleNamespace(shufflerank_theta=0.05)
-CLIP = dict(T=8, H=64, W=64)
+CLIP = dict(T=8, H=112, W=112)
 
 
 def _init_pg(rank=0, world=1, port=29531):
@@ -119,7 +119,7 @@ def compare(a, b, tag, tol=5e-4):
 def case_backbones(ref):
     rec = {}
     for net in ('s3dg', 'r21d', 'r3d', 'r50'):
-        x = P.procedural_clips(2, 1, **CLIP)[:, 0]
+        x = P.procedural_clips(4, 1, **CLIP)[:, 0]
         outs = []
         for sel in (ref.select_backbone, O.select_backbone):
             m, _ = sel(net)
@@ -130,7 +130,12 @@ def case_backbones(ref):
         assert err < 1e-5, (net, err)
         rec[net + '/feat'] = outs[0].detach().numpy()
         rec[net + '/pooled'] = outs[0].mean(dim=(2, 3, 4)).detach().numpy()
-        print('backbone', net, tuple(outs[0].shape), 'ref-vs-oracle', err)
+        # conditioning of the case: the reference's own fp32 result vs the same network in fp64
+        with torch.no_grad():
+            y64 = m.double()(x.double())
+        cond = float((outs[0].double() - y64).abs().max() / y64.abs().max())
+        rec[net + '/fp32_vs_fp64'] = np.array(cond)
+        print('backbone', net, tuple(outs[0].shape), 'ref-vs-oracle', err, 'reference fp32-vs-fp64', cond)
     np.savez_compressed(os.path.join(GOLD, 'backbones.npz'), **rec)
 
 

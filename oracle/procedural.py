@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE -- RNG-independent fills shared by the fixture generator, oracle and tests.
 
 Weights are never shipped (46-60 MB); instead every float tensor of a state_dict is
-filled as a deterministic function of its *canonical key* (the lexicographically
+filled as a deterministic function (numpy legacy RandomState stream) of its *canonical key* (the lexicographically
 smallest of its alias names -- S3D registers the stem twice) and its shape, so the
 reference, the oracle and the HIP product can all be initialised identically without
 depending on any torch RNG stream.
@@ -33,39 +33,39 @@ def canonical_groups(module):
 def procedural_init(module, gain=1.0):
     """Fill every parameter / float buffer of `module` from its canonical key.
 
-    conv / linear weights : N(0, ~sqrt(2/fan_in))-like amplitude (keeps activations O(1))
-    biases                : 0.05 * wave
-    BN weight / bias      : 1 + 0.2*wave / 0.1*wave    (non-trivial affine so their grads matter)
-    running_mean / var    : 0 / 1 (PyTorch defaults)   num_batches_tracked : 0
-    MoCo queues           : wave, then column-normalised like moco.py:79-81,318-323
+    Values are iid Gaussian draws from numpy's legacy RandomState(crc32(key)) -- a generator whose
+    stream is frozen by numpy's compatibility policy, so the fill does not depend on the torch version.
+    (A smooth closed-form fill was tried first: it makes S3D-G's BatchNorm channels nearly degenerate and
+    the reference's own fp32 output then differs from its fp64 output by 10 %, useless as a parity pin.)
+
+    conv / linear weights : N(0, 1/fan_in)          biases              : 0.1 * N(0,1)
+    BN weight / bias      : 1 + 0.1*N / 0.1*N       running_mean / var  : 0 / 1      counters : 0
+    MoCo queues           : N(0,1), then column-normalised like moco.py:79-81,318-323
     """
     sd = module.state_dict(keep_vars=True)
     for key in sorted(canonical_groups(module)):
         t = sd[key]
-        seed = zlib.crc32(key.encode())
+        seed = zlib.crc32(key.encode()) & 0x7FFFFFFF
         leaf = key.rsplit('.', 1)[-1]
         if not t.dtype.is_floating_point:
             t.zero_()
             continue
         n = t.numel()
+        draw = torch.from_numpy(np.random.RandomState(seed).standard_normal(n)).to(t.dtype)
         if leaf == 'running_mean':
             t.zero_()
         elif leaf == 'running_var':
             t.fill_(1.0)
         elif leaf in ('queue', 'series_queue'):
-            t.copy_(torch.from_numpy(_wave(n, seed)).reshape(t.shape).to(t.dtype))
+            t.copy_(draw.reshape(t.shape))
         elif t.dim() == 1:
-            w = torch.from_numpy(_wave(n, seed)).to(t.dtype)
             if leaf == 'weight':                      # BN gamma
-                t.copy_(1.0 + 0.2 * w)
-            elif key.rsplit('.', 1)[0] + '.running_mean' in sd:
-                t.copy_(0.1 * w)                      # BN beta
-            else:
-                t.copy_(0.05 * w)                     # conv / linear bias
+                t.copy_(1.0 + 0.1 * draw)
+            else:                                     # BN beta, conv / linear bias
+                t.copy_(0.1 * draw)
         else:
             fan_in = n // t.shape[0]
-            amp = gain * (3.0 / fan_in) ** 0.5        # uniform-ish in [-amp, amp] -> var = 1/fan_in * ~1.5
-            t.copy_((amp * torch.from_numpy(_wave(n, seed))).reshape(t.shape).to(t.dtype))
+            t.copy_((gain * (1.0 / fan_in) ** 0.5) * draw.reshape(t.shape))
     # derived buffers (normalised queues)
     if 'queue' in sd:
         q = sd['queue']

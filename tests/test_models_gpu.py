@@ -19,7 +19,7 @@ def _P():
 
 
 @pytest.mark.parametrize('net', ['s3dg', 'r21d', 'r3d', 'r50'])
-@pytest.mark.parametrize('dtype,tol', [('fp32', 2e-4), ('bf16', 6e-2)])
+@pytest.mark.parametrize('dtype,tol', [('fp32', 3e-4), ('bf16', 6e-2)])
 def test_backbone_features(gpu, net, dtype, tol):
     from dualvar_amd.backbone import select_backbone
     P = _P()
@@ -27,13 +27,15 @@ def test_backbone_features(gpu, net, dtype, tol):
     m, _ = select_backbone(net)
     P.procedural_init(m)
     m.set_compute_dtype(dtype).train().to(gpu)
-    x = P.procedural_clips(2, 1, **CLIP)[:, 0].to(gpu)
+    x = P.procedural_clips(4, 1, **CLIP)[:, 0].to(gpu)
     with torch.no_grad():
         pooled = m.forward_pooled(x)
         fmap = m(x)
     e1 = rel_err(pooled.cpu().numpy(), g[net + '/pooled'])
     e2 = rel_err(fmap.cpu().numpy(), g[net + '/feat'])
-    print(f'{net} {dtype}: pooled rel err {e1:.2e}, map rel err {e2:.2e}')
+    cond = float(g[net + '/fp32_vs_fp64'])          # the reference's own fp32 result vs fp64 on this case
+    print(f'{net} {dtype}: pooled rel err {e1:.2e}, map rel err {e2:.2e} (reference fp32-vs-fp64 {cond:.1e})')
+    tol = max(tol, 4 * cond)
     assert e1 < tol and e2 < 2 * tol
 
 

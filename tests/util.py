@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CLIP = dict(T=8, H=64, W=64)
+CLIP = dict(T=8, H=112, W=112)
 
 
 def gold(name):
