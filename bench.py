@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py -- clips/sec of the DualVar pretrain step (S3D-G 8x112x112 SimCLR) on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = ingest + forward + NT-Xent + backward + (gradient all-reduce) + SGD on one synthetic batch per GPU
+(weak scaling: per-GPU batch fixed).  Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     : the kernel with the largest share of the step, its algorithmic bytes (or flops) per launch over
+                 its HIP-event duration measured inside the timed region
+  cpu_baseline : the CPU oracle (oracle/torch_ref.py, validated == the reference) timed on this host on a bounded
+                 sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TF = {'bf16': 2500.0, 'fp32': 157.3}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--net', default='s3dg')
+    ap.add_argument('--model', default='simclr_naked',
+                    choices=['simclr_naked', 'simclr_timeseriesv4', 'moco_naked', 'moco_timeseriesv4'])
+    ap.add_argument('--batch', type=int, default=64, help='samples per GPU (each sample = 2 or 3 clip views)')
+    ap.add_argument('--frames', type=int, default=8)
+    ap.add_argument('--size', type=int, default=112)
+    ap.add_argument('--moco-k', type=int, default=65536)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    return ap.parse_args()
+
+
+def build_model(args, distributed):
+    import types
+    from dualvar_amd import model as M
+    a = types.SimpleNamespace(shufflerank_theta=0.05)
+    if args.model == 'simclr_naked':
+        return M.SimCLR_Naked(args.net, 128, 0.07, distributed)
+    if args.model == 'simclr_timeseriesv4':
+        return M.SimCLR_TimeSeriesV4(args.net, 128, 0.07, distributed, args=a)
+    if args.model == 'moco_naked':
+        return M.MoCo_Naked(args.net, 128, args.moco_k, 0.999, 0.07, distributed)
+    return M.MoCo_TimeSeriesV4(args.net, 128, args.moco_k, 0.999, 0.07, distributed, args=a)
+
+
+def total_loss(ret):
+    loss = ret['clip_contrast_loss']
+    for k in ret:
+        if 'loss' in k and 'clip' not in k:
+            loss = loss + ret[k]
+    return loss
+
+
+class KernelTimer:
+    """HIP-event timing of plan launches on the stream they are launched on (torch's current stream)."""
+
+    def __init__(self, only=None):
+        self.only = only               # None: time every launch (calibration); else a kernel-name
+        self.rec = []                  # (launch, start, end)
+
+    def __call__(self, launch, stream):
+        if self.only is not None and launch.kname != self.only:
+            launch(stream)
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        launch(stream)
+        b.record()
+        self.rec.append((launch, a, b))
+
+    def summary(self):
+        """{kname: [n, total_ms, total_bytes, total_flops]} (call after a device sync)"""
+        out = {}
+        for l, a, b in self.rec:
+            e = out.setdefault(l.kname, [0, 0.0, 0, 0])
+            e[0] += 1
+            e[1] += a.elapsed_time(b)
+            e[2] += l.bytes
+            e[3] += l.flops
+        return out
+
+
+def all_plans(model):
+    for m in model.modules():
+        if hasattr(m, '_plans'):
+            for lst in m._plans.values():
+                for p in lst:
+                    yield p
+
+
+def cpu_baseline(args, V):
+    """The oracle restatement (== reference, oracle/gen_golden.py) on this host's cores: same model, same clip
+    shape, bounded batch / steps."""
+    from oracle import torch_ref as O
+    import types
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(ncpu)
+    a = types.SimpleNamespace(shufflerank_theta=0.05)
+    torch.manual_seed(0)
+    if args.model == 'simclr_naked':
+        m = O.SimCLR_Naked(args.net, 128, 0.07, False)
+    elif args.model == 'simclr_timeseriesv4':
+        m = O.SimCLR_TimeSeriesV4(args.net, 128, 0.07, False, args=a)
+    elif args.model == 'moco_naked':
+        m = O.MoCo_Naked(args.net, 128, min(args.moco_k, 4096), 0.999, 0.07, False)
+    else:
+        m = O.MoCo_TimeSeriesV4(args.net, 128, min(args.moco_k, 4096), 0.999, 0.07, False, args=a)
+    m.train()
+    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.003, momentum=0.9, weight_decay=1e-4)
+    B = args.cpu_batch
+    block = torch.randn(B, V, 3, args.frames, args.size, args.size, generator=torch.Generator().manual_seed(1234))
+    best = None
+    for it in range(args.cpu_steps + 1):
+        t0 = time.time()
+        O.train_step(m, block, opt)
+        dt = time.time() - t0
+        if it > 0:
+            best = dt if best is None else min(best, dt)
+    return {'value': round(B * V / best, 2), 'unit': 'clips/s', 'cores': ncpu, 'kind': 'port',
+            'sample': f'oracle/torch_ref.py {args.model}/{args.net} fp32, batch {B}x{V} clips of {args.frames}x{args.size}x{args.size}, '
+                      f'best of {args.cpu_steps} full train steps after 1 warm-up, torch {torch.__version__} CPU, {ncpu} threads'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from dualvar_amd.optim import SGD
+    from dualvar_amd.parallel import GradSync
+    torch.manual_seed(0)
+    np.random.seed(1234 + rank)
+    model = build_model(args, distributed)
+    model.set_compute_dtype(args.dtype).train().to(dev)
+    V = 2 if args.model.endswith('naked') else 3
+    B = args.batch
+    g = torch.Generator().manual_seed(1234 + rank)
+    block = torch.randn(B, V, 3, args.frames, args.size, args.size, generator=g).to(dev)
+    opt = SGD([p for p in model.parameters() if p.requires_grad], lr=0.003, momentum=0.9, weight_decay=1e-4,
+              stores=model.stores(), grad_sync=GradSync() if distributed else None)
+
+    def step():
+        ret = model(block)
+        loss = total_loss(ret)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(max(args.warmup - 1, 1)):
+        step()
+    # calibration step: time every launch once to find the kernel with the largest share
+    cal = KernelTimer()
+    for p in all_plans(model):
+        p.timer = cal
+    step()
+    torch.cuda.synchronize()
+    csum = cal.summary()
+    dominant = max((k for k in csum if not k.startswith('host:')), key=lambda k: csum[k][1])
+    probe = KernelTimer(only=dominant)
+    for p in all_plans(model):
+        p.timer = probe
+
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    for p in all_plans(model):
+        p.timer = None
+
+    if rank == 0:
+        clips = world * B * V * args.steps
+        ps = probe.summary()[dominant]
+        n, ms, nbytes, flops = ps
+        avg_ms = ms / n
+        bw = nbytes / n / (avg_ms * 1e-3) / 1e9              # GB/s algorithmic
+        tf = flops / n / (avg_ms * 1e-3) / 1e12
+        f_hbm, f_mfma = bw / HBM_PEAK_GBS, tf / MFMA_PEAK_TF[args.dtype]
+        if f_mfma > f_hbm:
+            roof = {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': MFMA_PEAK_TF[args.dtype], 'unit': 'TFLOP/s',
+                    'frac': round(f_mfma, 4)}
+        else:
+            roof = {'bound': 'hbm', 'achieved': round(bw, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(f_hbm, 4)}
+        tot_ms = sum(v[1] for k, v in csum.items() if not k.startswith('host:'))
+        roof.update({'traffic': None, 'kernel': dominant, 'launches_per_step': n // args.steps,
+                     'avg_launch_us': round(avg_ms * 1e3, 2), 'share_of_kernel_time': round(csum[dominant][1] / tot_ms, 3),
+                     'other_bound_frac': round(min(f_hbm, f_mfma), 4)})
+        out = {
+            'metric': 'clips/sec (whole node), S3D-G 8x112^2 SimCLR pretrain step', 'value': round(clips / dt, 2),
+            'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'{args.net} {args.model} pretrain step (fwd+loss+bwd+SGD), {args.frames}x{args.size}x{args.size} '
+                                   f'RGB clips, {B} samples x {V} views per GPU, random-init weights',
+                       'global_batch': world * B, 'clips_per_step': world * B * V, 'parallelism': f'dp{world}'},
+            'loss': round(float(loss), 4),
+            'roofline': roof,
+            'kernel_time_ms_per_step': {k: round(v[1], 3) for k, v in sorted(csum.items(), key=lambda kv: -kv[1][1])[:12]},
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, V)
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

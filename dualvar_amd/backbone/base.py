@@ -38,14 +38,30 @@ class IngestOp(Op):
         self.src, self.perm, self.mean, self.istd = x, perm, mean, istd
         self.stride_n = x.stride(0) if x.dim() == 5 else 3 * self.T * self.H * self.W
 
-    def forward(self):
+    def _launch(self, stream):
         p = self.plan
         L.check(p.lib.dv_ingest_ncdhw(p.dtype, self.src.data_ptr(), self.y.ptr, self.N, 3, self.T, self.H, self.W,
                                       self.stride_n, self.y.ld,
                                       self.mean.data_ptr() if self.mean is not None else 0,
                                       self.istd.data_ptr() if self.istd is not None else 0,
                                       self.perm.data_ptr() if self.perm is not None else 0,
-                                      self.n_seg if self.perm is not None else 0, ops.stream_ptr()), 'dv_ingest_ncdhw')
+                                      self.n_seg if self.perm is not None else 0, stream), 'dv_ingest_ncdhw')
+
+    def launches(self):
+        return [_IngestStep(self)], []
+
+
+class _IngestStep:
+    """the source pointer changes per call, so this step binds its arguments when it runs"""
+    __slots__ = ('name', 'kname', 'op', 'bytes', 'flops')
+
+    def __init__(self, op):
+        self.op, self.name, self.flops = op, 'ingest', 0
+        self.kname = 'ingest<%s>' % ('f32' if op.plan.dtype == DV_F32 else 'bf16')
+        self.bytes = op.N * op.T * op.H * op.W * (12 + 4 * ops.ESIZE[op.plan.dtype])
+
+    def __call__(self, stream):
+        self.op._launch(stream)
 
 
 class _Token:
@@ -164,7 +180,7 @@ class HipBackbone(nn.Module):
         pl.mean_op = None
         if not want_map:
             pl.pooled = pl.spatial_mean(out)
-            pl.mean_op = pl.fwd[-1]
+            pl.mean_op = pl.ops[-1]
         pl.finalize()
         pl._busy_ref = None
         pl.after_backward = None

@@ -226,17 +226,53 @@ class Comm:
         self.rank = dist.get_rank(group) if self.world > 1 else 0
 
 
+class Launch:
+    """One kernel launch of a plan: a bound C-ABI call plus its algorithmic cost (for the roofline report)."""
+    __slots__ = ('name', 'kname', 'fn', 'args', 'bytes', 'flops')
+
+    def __init__(self, name, kname, fn, args, nbytes=0, flops=0):
+        self.name, self.kname, self.fn, self.args, self.bytes, self.flops = name, kname, fn, args, nbytes, flops
+
+    def __call__(self, stream):
+        rc = self.fn(*self.args, stream)
+        if rc:
+            L.check(rc, self.name)
+
+
+class HostStep:
+    """A host-side step inside a plan (a torch.distributed collective on the current stream)."""
+    __slots__ = ('name', 'kname', 'call', 'bytes', 'flops')
+
+    def __init__(self, name, call):
+        self.name, self.kname, self.call, self.bytes, self.flops = name, 'host:' + name, call, 0, 0
+
+    def __call__(self, stream):
+        self.call()
+
+
+def _pick_bn(np_):
+    if np_ <= 32:
+        return 32
+    if np_ <= 64:
+        return 64
+    return 128 if (np_ + 127) // 128 * 128 <= (np_ + 63) // 64 * 64 else 64
+
+
+def _dt(dtype):
+    return 'f32' if dtype == DV_F32 else 'bf16'
+
+
 class Plan:
     """Static forward/backward launch lists for one backbone at one input shape."""
 
     def __init__(self, store, dtype, device, with_grad=True, comm=None):
         self.store, self.dtype, self.device, self.with_grad = store, dtype, device, with_grad
         self.comm = comm if comm is not None else Comm()
-        self.fwd, self.bwd_ops = [], []
-        self._acts = []
-        self.busy = False
+        self.ops = []
+        self.f_list, self.b_list = [], []
         self.bytes = 0
         self.lib = L.load()
+        self.timer = None            # set by bench.py: callable(launch) -> context recording HIP events
 
     # ------------------------------------------------------------------ buffers
     def act(self, N, T, H, W, C_, dtype=None, cpitch=None, grad=None, zero=False):
@@ -247,7 +283,6 @@ class Plan:
         if want_grad:
             a.grad = ops.new_act(N, T, H, W, C_, dtype, self.device, cpitch=cpitch, zero=True)
             self.bytes += a.buf.numel() * a.buf.element_size()
-        self._acts.append(a)
         return a
 
     def slice(self, a, off, C_):
@@ -263,12 +298,11 @@ class Plan:
 
     # ------------------------------------------------------------------ graph ops
     def _push(self, op):
-        self.fwd.append(op)
-        self.bwd_ops.append(op)
+        self.ops.append(op)
         return op
 
-    def conv(self, slot, x, k, s, p, out=None, stats=True, dtype=None, bias=None, act_flags=0):
-        op = self._push(ConvOp(self, slot, x, k, s, p, out, stats, dtype, bias, act_flags))
+    def conv(self, slot, x, k, s, p, out=None, stats=True):
+        op = self._push(ConvOp(self, slot, x, k, s, p, out, stats))
         op.y.producer = op
         return op.y
 
@@ -287,22 +321,39 @@ class Plan:
     def finalize(self):
         # the last consumer (forward order) of an activation is the first writer of its gradient
         seen = set()
-        for op in reversed(self.fwd):
+        for op in reversed(self.ops):
             for name, a in op.grad_targets():
                 key = (a.buf.data_ptr(), a.off)
                 op.acc[name] = key in seen
                 seen.add(key)
-        for op in self.fwd:
-            op.prepare()
+        for op in self.ops:
+            f, b = op.launches()
+            self.f_list += f
+            op._b = b
+        for op in reversed(self.ops):
+            self.b_list += op._b
 
     # ------------------------------------------------------------------ execution
+    def _run(self, lst):
+        s = ops.stream_ptr()
+        t = self.timer
+        if t is None:
+            for l in lst:
+                l(s)
+        else:
+            for l in lst:
+                t(l, s)
+
     def run_forward(self):
-        for op in self.fwd:
-            op.forward()
+        self._run(self.f_list)
 
     def run_backward(self):
-        for op in reversed(self.bwd_ops):
-            op.backward()
+        self._run(self.b_list)
+
+    def cost(self):
+        """(algorithmic bytes, flops) of one forward+backward replay."""
+        ls = self.f_list + self.b_list
+        return sum(l.bytes for l in ls), sum(l.flops for l in ls)
 
 
 class Op:
@@ -313,76 +364,67 @@ class Op:
     def grad_targets(self):
         return []
 
-    def prepare(self):
-        pass
-
-    def forward(self):
+    def launches(self):
+        """-> (forward launches, backward launches) in execution order"""
         raise NotImplementedError
 
-    def backward(self):
-        pass
+
+def _abytes(a, c=None):
+    return a.rows * (a.C if c is None else c) * ops.ESIZE[a.dtype]
 
 
 class ConvOp(Op):
     """conv (bias-free, BN partial statistics in the epilogue) with wgrad + dgrad."""
 
-    def __init__(self, plan, slot, x, k, s, p, out, stats, dtype, bias, act_flags):
+    def __init__(self, plan, slot, x, k, s, p, out, stats):
         super().__init__(plan)
-        self.slot, self.x = slot, x
-        dtype = plan.dtype if dtype is None else dtype
-        self.dtype = dtype
+        self.slot, self.x, self.k, self.s, self.p = slot, x, k, s, p
+        self.dtype = plan.dtype
         To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
-        self.y = out if out is not None else plan.act(x.N, To, Ho, Wo, slot.Cout, dtype=dtype)
+        self.y = out if out is not None else plan.act(x.N, To, Ho, Wo, slot.Cout)
         assert x.cpitch == slot.cin_pitch, (x.cpitch, slot.cin_pitch)
-        flags = act_flags | (DV_STATS if stats else 0) | (DV_BIAS if bias is not None else 0)
-        self.d = ops.conv_desc(dtype, x, self.y, k, s, p, flags=flags)
-        self.d_b = ops.conv_desc(dtype, x, self.y, k, s, p, flags=0)
-        self.bias = bias
+        self.d = ops.conv_desc(self.dtype, x, self.y, k, s, p, flags=DV_STATS if stats else 0)
         self.tiles = ops.stat_tiles(self.d)
         self.stats = plan.f32(self.tiles, 2, slot.Cout) if stats else None
         self.need_dx = plan.with_grad and x.grad is not None and slot.wd_off >= 0
-        self.f32_weights = dtype == DV_F32 and plan.dtype != DV_F32
 
     def grad_targets(self):
         return [('x', self.x)] if self.need_dx else []
 
-    def prepare(self):
-        st, lib, d = self.plan.store, self.plan.lib, self.d
-        w = st.w_master(self.slot) if self.f32_weights else st.w_fwd(self.slot)
-        bias = self.bias.data_ptr() if self.bias is not None else 0
-        self._f = (lib.dv_conv3d_fwd, C.byref(d), self.x.ptr, w, bias, self.y.ptr,
-                   self.stats.data_ptr() if self.stats is not None else 0)
-        if self.plan.with_grad:
-            self._wg = (lib.dv_conv3d_wgrad, C.byref(self.d_b), self.x.ptr, self.y.grad.ptr, st.w_grad(self.slot))
+    def launches(self):
+        p, st, lib, sl, x, y = self.plan, self.plan.store, self.plan.lib, self.slot, self.x, self.y
+        es = ops.ESIZE[self.dtype]
+        taps = self.k[0] * self.k[1] * self.k[2]
+        flops = 2 * y.rows * sl.Cout * taps * sl.Cin
+        wbytes = sl.Cout * taps * sl.Cin * es
+        gv = 8 if (self.dtype == DV_BF16 and sl.cin_pitch % 8) else 16
+        kf = 'conv_gemm<%s,FWD,%d,128,%d>' % (_dt(self.dtype), gv, _pick_bn(y.cpitch))
+        f = [Launch('conv_fwd', kf, lib.dv_conv3d_fwd,
+                    (C.byref(self.d), x.ptr, st.w_fwd(sl), 0, y.ptr, self.stats.data_ptr() if self.stats is not None else 0),
+                    _abytes(x) + wbytes + _abytes(y), flops)]
+        b = []
+        if p.with_grad:
+            self.d_w = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=0)
+            b.append(Launch('conv_wgrad', 'conv_wgrad<%s,%d,128,64>' % (_dt(self.dtype), gv), lib.dv_conv3d_wgrad,
+                            (C.byref(self.d_w), x.ptr, y.grad.ptr, st.w_grad(sl)),
+                            _abytes(x) + _abytes(y) + sl.Cout * taps * sl.Cin * 4, flops))
             if self.need_dx:
-                self.d_b2 = ops.conv_desc(self.dtype, self.x, self.y, (self.d.kt, self.d.kh, self.d.kw),
-                                          (self.d.st, self.d.sh, self.d.sw), (self.d.pt, self.d.ph, self.d.pw),
-                                          flags=DV_ACCUM if self.acc.get('x') else 0)
-                self._dg = (lib.dv_conv3d_dgrad, C.byref(self.d_b2), self.y.grad.ptr, st.w_dgrad(self.slot), self.x.grad.ptr)
-
-    def forward(self):
-        f = self._f
-        L.check(f[0](*f[1:], ops.stream_ptr()), 'dv_conv3d_fwd')
-
-    def backward(self):
-        s = ops.stream_ptr()
-        f = self._wg
-        L.check(f[0](*f[1:], s), 'dv_conv3d_wgrad')
-        if self.need_dx:
-            f = self._dg
-            L.check(f[0](*f[1:], s), 'dv_conv3d_dgrad')
+                acc = bool(self.acc.get('x'))
+                self.d_g = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=DV_ACCUM if acc else 0)
+                b.append(Launch('conv_dgrad', 'conv_gemm<%s,DGRAD,16,128,%d>' % (_dt(self.dtype), _pick_bn(x.cpitch)),
+                                lib.dv_conv3d_dgrad, (C.byref(self.d_g), y.grad.ptr, st.w_dgrad(sl), x.grad.ptr),
+                                _abytes(y) + wbytes + _abytes(x) * (2 if acc else 1), flops))
+        return f, b
 
 
 class BNOp(Op):
     """training-mode BatchNorm (+residual) (+ReLU); cross-rank statistics when world > 1."""
 
-    def __init__(self, plan, bn, x, relu, residual, out, stats_from):
+    def __init__(self, plan, bn, x, relu, residual, out, conv):
         super().__init__(plan)
-        self.bn, self.x, self.relu, self.res = bn, x, relu, residual
-        self.C = x.C
-        self.M = x.rows
+        self.bn, self.x, self.relu, self.res, self.conv = bn, x, relu, residual, conv
+        self.C, self.M = x.C, x.rows
         self.y = out if out is not None else plan.act(x.N, x.T, x.H, x.W, x.C)
-        self.conv = stats_from
         Cn, R = self.C, plan.comm.world
         self.local = plan.f32(2 * Cn + 1)
         self.gathered = plan.f32(R, 2 * Cn + 1) if R > 1 else self.local
@@ -396,53 +438,55 @@ class BNOp(Op):
     def grad_targets(self):
         return [('res', self.res)] if (self.res is not None and self.res.grad is not None and self.plan.with_grad) else []
 
-    def prepare(self):
-        p, st, bn = self.plan, self.plan.store, self.bn
-        self.gslot, self.bslot = st.slot(bn.weight), st.slot(bn.bias)
-        self.flags = DV_RELU if self.relu else 0
-        self.bflags = 0 if self.relu else DV_NO_RELU_MASK
-        if self.res is not None and self.acc.get('res'):
-            self.bflags |= DV_ACCUM
-        self.rm = bn.running_mean.data_ptr() if bn.running_mean is not None else 0
-        self.rv = bn.running_var.data_ptr() if bn.running_var is not None else 0
-        self.eps, self.mom = float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1)
-
-    def forward(self):
-        p, lib, s = self.plan, self.plan.lib, ops.stream_ptr()
-        Cn, x, y = self.C, self.x, self.y
-        st = p.store
-        L.check(lib.dv_bn_reduce_stats(self.conv.stats.data_ptr(), self.conv.tiles, 128, self.M, Cn,
-                                       self.local.data_ptr(), s), 'dv_bn_reduce_stats')
-        R = p.comm.world
+    def launches(self):
+        p, st, lib, bn, x, y, res = self.plan, self.plan.store, self.plan.lib, self.bn, self.x, self.y, self.res
+        Cn, M, R = self.C, self.M, p.comm.world
+        gs, bs = st.slot(bn.weight), st.slot(bn.bias)
+        rm = bn.running_mean.data_ptr() if bn.running_mean is not None else 0
+        rv = bn.running_var.data_ptr() if bn.running_var is not None else 0
+        eps, mom = float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1)
+        dt = _dt(p.dtype)
+        f = [Launch('bn_reduce_stats', 'bn_reduce_stats', lib.dv_bn_reduce_stats,
+                    (self.conv.stats.data_ptr(), self.conv.tiles, 128, M, Cn, self.local.data_ptr()),
+                    self.conv.tiles * 2 * Cn * 4)]
         if R > 1:
-            dist.all_gather_into_tensor(self.gathered.view(-1), self.local, group=p.comm.group)
-        L.check(lib.dv_bn_finalize(self.gathered.data_ptr(), R, Cn, st.w_master(self.gslot), st.w_master(self.bslot),
-                                   self.eps, self.mom, self.rm, self.rv, self.mean.data_ptr(), self.invstd.data_ptr(),
-                                   self.scale.data_ptr(), self.shift.data_ptr(), s), 'dv_bn_finalize')
-        res = self.res
-        L.check(lib.dv_bn_apply(p.dtype, x.ptr, x.ld, self.scale.data_ptr(), self.shift.data_ptr(),
-                                res.ptr if res is not None else 0, res.ld if res is not None else 0, y.ptr, y.ld,
-                                self.M, Cn, self.flags, s), 'dv_bn_apply')
+            local, gathered, group = self.local, self.gathered, p.comm.group
+            f.append(HostStep('syncbn_allgather', lambda: dist.all_gather_into_tensor(gathered.view(-1), local, group=group)))
+        f.append(Launch('bn_finalize', 'bn_finalize', lib.dv_bn_finalize,
+                        (self.gathered.data_ptr(), R, Cn, st.w_master(gs), st.w_master(bs), eps, mom, rm, rv,
+                         self.mean.data_ptr(), self.invstd.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr())))
+        f.append(Launch('bn_apply', 'bn_apply<%s>' % dt, lib.dv_bn_apply,
+                        (p.dtype, x.ptr, x.ld, self.scale.data_ptr(), self.shift.data_ptr(),
+                         res.ptr if res is not None else 0, res.ld if res is not None else 0, y.ptr, y.ld, M, Cn,
+                         DV_RELU if self.relu else 0),
+                        _abytes(x) * (3 if res is not None else 2)))
+        b = []
+        if p.with_grad:
+            dy = y.grad
+            mflag = 0 if self.relu else DV_NO_RELU_MASK
+            nact = 3 if self.relu else 2
+            b.append(Launch('bn_bwd_reduce', 'bn_bwd_reduce<%s>' % dt, lib.dv_bn_bwd_reduce,
+                            (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, self.mean.data_ptr(), self.invstd.data_ptr(),
+                             M, Cn, mflag, self.part.data_ptr()), _abytes(x) * nact))
+            b.append(Launch('bn_bwd_finalize', 'reduce_rows', lib.dv_bn_bwd_finalize,
+                            (self.part.data_ptr(), self.nb, Cn, self.sums.data_ptr()), self.nb * 2 * Cn * 4))
+            if R > 1:
+                sums, sums_g, group = self.sums, self.sums_g, p.comm.group
 
-    def backward(self):
-        p, lib, s = self.plan, self.plan.lib, ops.stream_ptr()
-        Cn, x, y, st = self.C, self.x, self.y, self.plan.store
-        dy = y.grad
-        L.check(lib.dv_bn_bwd_reduce(p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, self.mean.data_ptr(),
-                                     self.invstd.data_ptr(), self.M, Cn, self.bflags & DV_NO_RELU_MASK,
-                                     self.part.data_ptr(), s), 'dv_bn_bwd_reduce')
-        L.check(lib.dv_bn_bwd_finalize(self.part.data_ptr(), self.nb, Cn, self.sums.data_ptr(), s), 'dv_bn_bwd_finalize')
-        R = p.comm.world
-        if R > 1:
-            self.sums_g.copy_(self.sums)
-            dist.all_reduce(self.sums_g, group=p.comm.group)
-        res = self.res
-        dres = res.grad if (res is not None and res.grad is not None) else None
-        L.check(lib.dv_bn_bwd_apply(p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, self.mean.data_ptr(),
-                                    self.invstd.data_ptr(), st.w_master(self.gslot), self.sums_g.data_ptr(),
-                                    self.sums.data_ptr(), 1.0 / (self.M * R), st.w_grad(self.gslot), st.w_grad(self.bslot),
-                                    x.grad.ptr, x.grad.ld, dres.ptr if dres is not None else 0,
-                                    dres.ld if dres is not None else 0, self.M, Cn, self.bflags, s), 'dv_bn_bwd_apply')
+                def _allreduce():
+                    sums_g.copy_(sums)
+                    dist.all_reduce(sums_g, group=group)
+                b.append(HostStep('syncbn_allreduce', _allreduce))
+            dres = res.grad if (res is not None and res.grad is not None) else None
+            bflags = mflag | (DV_ACCUM if (dres is not None and self.acc.get('res')) else 0)
+            nres = 0 if dres is None else (2 if bflags & DV_ACCUM else 1)
+            b.append(Launch('bn_bwd_apply', 'bn_bwd_apply<%s>' % dt, lib.dv_bn_bwd_apply,
+                            (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, self.mean.data_ptr(), self.invstd.data_ptr(),
+                             st.w_master(gs), self.sums_g.data_ptr(), self.sums.data_ptr(), 1.0 / (M * R),
+                             st.w_grad(gs), st.w_grad(bs), x.grad.ptr, x.grad.ld,
+                             dres.ptr if dres is not None else 0, dres.ld if dres is not None else 0, M, Cn, bflags),
+                            _abytes(x) * (nact + 1 + nres)))
+        return f, b
 
 
 class PoolOp(Op):
@@ -459,15 +503,18 @@ class PoolOp(Op):
     def grad_targets(self):
         return [('x', self.x)] if self.need_dx else []
 
-    def forward(self):
-        L.check(self.plan.lib.dv_maxpool3d_fwd(C.byref(self.d), self.x.ptr, self.y.ptr, self.idx.data_ptr(),
-                                               ops.stream_ptr()), 'dv_maxpool3d_fwd')
-
-    def backward(self):
+    def launches(self):
+        p, lib, x, y = self.plan, self.plan.lib, self.x, self.y
+        dt = _dt(p.dtype)
+        f = [Launch('maxpool_fwd', 'maxpool_fwd<%s>' % dt, lib.dv_maxpool3d_fwd,
+                    (C.byref(self.d), x.ptr, y.ptr, self.idx.data_ptr()), _abytes(x) + _abytes(y) + y.rows * x.C)]
+        b = []
         if self.need_dx:
-            L.check(self.plan.lib.dv_maxpool3d_bwd(C.byref(self.d), self.y.grad.ptr, self.idx.data_ptr(), self.x.grad.ptr,
-                                                   DV_ACCUM if self.acc.get('x') else 0, ops.stream_ptr()),
-                    'dv_maxpool3d_bwd')
+            acc = bool(self.acc.get('x'))
+            b.append(Launch('maxpool_bwd', 'maxpool_bwd<%s>' % dt, lib.dv_maxpool3d_bwd,
+                            (C.byref(self.d), y.grad.ptr, self.idx.data_ptr(), x.grad.ptr, DV_ACCUM if acc else 0),
+                            _abytes(y) + y.rows * x.C + _abytes(x) * (2 if acc else 1)))
+        return f, b
 
 
 class GateOp(Op):
@@ -479,42 +526,41 @@ class GateOp(Op):
         N, Cn = x.N, x.C
         self.mean = plan.f32(N, Cn)
         self.g = plan.f32(N, Cn)
+        a_mean = Act(self.mean, N, 1, 1, 1, Cn, Cn, 0, DV_F32, Cn)
+        a_g = Act(self.g, N, 1, 1, 1, Cn, Cn, 0, DV_F32, Cn)
         # fc as a 1x1x1 fp32 conv over [N,1,1,1,C] with bias + sigmoid epilogue
-        self.a_mean = Act(self.mean, N, 1, 1, 1, Cn, Cn, 0, DV_F32, Cn)
-        self.a_g = Act(self.g, N, 1, 1, 1, Cn, Cn, 0, DV_F32, Cn)
-        self.d = ops.conv_desc(DV_F32, self.a_mean, self.a_g, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=DV_BIAS | DV_SIGMOID)
+        self.d = ops.conv_desc(DV_F32, a_mean, a_g, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=DV_BIAS | DV_SIGMOID)
         if plan.with_grad:
             self.dpre = plan.f32(N, Cn)
             self.dmean = plan.f32(N, Cn)
 
-    def grad_targets(self):
-        return []          # x (the branch's BN output) has this op as its only consumer
-
-    def prepare(self):
-        st = self.plan.store
-        self.ws, self.bs = st.slot(self.fc.weight), st.slot(self.fc.bias)
-
-    def forward(self):
-        p, lib, s, x, y = self.plan, self.plan.lib, ops.stream_ptr(), self.x, self.y
-        st = p.store
-        L.check(lib.dv_spatial_mean(p.dtype, x.ptr, x.ld, x.N, x.S, x.C, self.mean.data_ptr(), s), 'dv_spatial_mean')
-        L.check(lib.dv_conv3d_fwd(C.byref(self.d), self.mean.data_ptr(), st.w_master(self.ws), st.w_master(self.bs),
-                                  self.g.data_ptr(), 0, s), 'gate fc')
-        L.check(lib.dv_gate_scale(p.dtype, x.ptr, x.ld, self.g.data_ptr(), x.N, x.S, x.C, y.ptr, y.ld, s), 'dv_gate_scale')
-
-    def backward(self):
-        p, lib, s, x, y = self.plan, self.plan.lib, ops.stream_ptr(), self.x, self.y
-        st, N, Cn = p.store, x.N, x.C
-        dy = y.grad
-        L.check(lib.dv_gate_bwd_reduce(p.dtype, dy.ptr, dy.ld, x.ptr, x.ld, self.g.data_ptr(), N, x.S, Cn,
-                                       self.dpre.data_ptr(), s), 'dv_gate_bwd_reduce')
-        w, cinp = st.w_master(self.ws), self.ws.cin_pitch
-        # dmean = dpre @ W ; dW += dpre^T @ mean ; db += colsum(dpre)
-        L.check(lib.dv_gemm_f32(N, Cn, Cn, self.dpre.data_ptr(), Cn, 1, w, cinp, 1, self.dmean.data_ptr(), Cn, 1.0, 0, s), 'gate dmean')
-        L.check(lib.dv_gemm_f32(Cn, Cn, N, self.dpre.data_ptr(), 1, Cn, self.mean.data_ptr(), Cn, 1, st.w_grad(self.ws), cinp, 1.0, 1, s), 'gate dW')
-        L.check(lib.dv_colsum_f32(self.dpre.data_ptr(), Cn, N, Cn, st.w_grad(self.bs), s), 'gate db')
-        L.check(lib.dv_gate_bwd_apply(p.dtype, dy.ptr, dy.ld, self.g.data_ptr(), self.dmean.data_ptr(), N, x.S, Cn,
-                                      x.grad.ptr, x.grad.ld, 0, s), 'dv_gate_bwd_apply')
+    def launches(self):
+        p, st, lib, x, y = self.plan, self.plan.store, self.plan.lib, self.x, self.y
+        ws, bs = st.slot(self.fc.weight), st.slot(self.fc.bias)
+        assert ws.cin_pitch == x.C, 'gating widths are multiples of 8 in S3D-G'
+        N, Cn, S, dt = x.N, x.C, x.S, _dt(p.dtype)
+        w, cinp = st.w_master(ws), ws.cin_pitch
+        f = [Launch('gate_mean', 'spatial_mean<%s>' % dt, lib.dv_spatial_mean,
+                    (p.dtype, x.ptr, x.ld, N, S, Cn, self.mean.data_ptr()), _abytes(x)),
+             Launch('gate_fc', 'conv_gemm<f32,FWD,16,128,%d>' % _pick_bn(Cn), lib.dv_conv3d_fwd,
+                    (C.byref(self.d), self.mean.data_ptr(), w, st.w_master(bs), self.g.data_ptr(), 0),
+                    Cn * Cn * 4, 2 * N * Cn * Cn),
+             Launch('gate_scale', 'rowscale<%s,0>' % dt, lib.dv_gate_scale,
+                    (p.dtype, x.ptr, x.ld, self.g.data_ptr(), N, S, Cn, y.ptr, y.ld), 2 * _abytes(x))]
+        b = []
+        if p.with_grad:
+            dy = y.grad
+            b = [Launch('gate_bwd_reduce', 'gate_bwd_reduce<%s>' % dt, lib.dv_gate_bwd_reduce,
+                        (p.dtype, dy.ptr, dy.ld, x.ptr, x.ld, self.g.data_ptr(), N, S, Cn, self.dpre.data_ptr()), 2 * _abytes(x)),
+                 Launch('gate_dmean', 'gemm_f32', lib.dv_gemm_f32,
+                        (N, Cn, Cn, self.dpre.data_ptr(), Cn, 1, w, cinp, 1, self.dmean.data_ptr(), Cn, 1.0, 0), Cn * Cn * 4),
+                 Launch('gate_dW', 'gemm_f32', lib.dv_gemm_f32,
+                        (Cn, Cn, N, self.dpre.data_ptr(), 1, Cn, self.mean.data_ptr(), Cn, 1, st.w_grad(ws), cinp, 1.0, 1), Cn * Cn * 8),
+                 Launch('gate_db', 'colsum', lib.dv_colsum_f32, (self.dpre.data_ptr(), Cn, N, Cn, st.w_grad(bs))),
+                 Launch('gate_bwd_apply', 'rowscale<%s,1>' % dt, lib.dv_gate_bwd_apply,
+                        (p.dtype, dy.ptr, dy.ld, self.g.data_ptr(), self.dmean.data_ptr(), N, S, Cn, x.grad.ptr, x.grad.ld, 0),
+                        2 * _abytes(x))]
+        return f, b
 
 
 class MeanOp(Op):
@@ -529,11 +575,14 @@ class MeanOp(Op):
     def grad_targets(self):
         return [('x', self.x)] if (self.plan.with_grad and self.x.grad is not None) else []
 
-    def forward(self):
-        p, x = self.plan, self.x
-        L.check(p.lib.dv_spatial_mean(p.dtype, x.ptr, x.ld, x.N, x.S, x.C, self.out.data_ptr(), ops.stream_ptr()), 'dv_spatial_mean')
-
-    def backward(self):
-        p, x = self.plan, self.x
-        L.check(p.lib.dv_spatial_mean_bwd(p.dtype, self.dout.data_ptr(), x.N, x.S, x.C, x.grad.ptr, x.grad.ld,
-                                          DV_ACCUM if self.acc.get('x') else 0, ops.stream_ptr()), 'dv_spatial_mean_bwd')
+    def launches(self):
+        p, x, dt = self.plan, self.x, _dt(self.plan.dtype)
+        f = [Launch('avgpool', 'spatial_mean<%s>' % dt, p.lib.dv_spatial_mean,
+                    (p.dtype, x.ptr, x.ld, x.N, x.S, x.C, self.out.data_ptr()), _abytes(x))]
+        b = []
+        if p.with_grad and x.grad is not None:
+            acc = bool(self.acc.get('x'))
+            b = [Launch('avgpool_bwd', 'rowscale<%s,2>' % dt, p.lib.dv_spatial_mean_bwd,
+                        (p.dtype, self.dout.data_ptr(), x.N, x.S, x.C, x.grad.ptr, x.grad.ld, DV_ACCUM if acc else 0),
+                        _abytes(x) * (2 if acc else 1))]
+        return f, b
