@@ -111,8 +111,13 @@ def cpu_baseline(args, V):
     shape, bounded batch / steps."""
     from oracle import torch_ref as O
     import types
-    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    ncpu = max(1, min(ncpu, int(os.environ.get('DUALVAR_CPU_THREADS', 16))))   # a 1-GPU box has a 16-core share
     torch.set_num_threads(ncpu)
+    print(f'[bench] cpu baseline: {ncpu} threads', file=sys.stderr, flush=True)
     a = types.SimpleNamespace(shufflerank_theta=0.05)
     torch.manual_seed(0)
     if args.model == 'simclr_naked':
@@ -132,6 +137,7 @@ def cpu_baseline(args, V):
         t0 = time.time()
         O.train_step(m, block, opt)
         dt = time.time() - t0
+        print(f'[bench] cpu step {it}: {dt:.2f} s', file=sys.stderr, flush=True)
         if it > 0:
             best = dt if best is None else min(best, dt)
     return {'value': round(B * V / best, 2), 'unit': 'clips/s', 'cores': ncpu, 'kind': 'port',
@@ -204,6 +210,7 @@ def main():
         p.timer = None
 
     if rank == 0:
+        print(f'[bench] timed region: {args.steps} steps in {dt:.3f} s', file=sys.stderr, flush=True)
         clips = world * B * V * args.steps
         ps = probe.summary()[dominant]
         n, ms, nbytes, flops = ps
@@ -228,7 +235,7 @@ def main():
             'config': {'workload': f'{args.net} {args.model} pretrain step (fwd+loss+bwd+SGD), {args.frames}x{args.size}x{args.size} '
                                    f'RGB clips, {B} samples x {V} views per GPU, random-init weights',
                        'global_batch': world * B, 'clips_per_step': world * B * V, 'parallelism': f'dp{world}'},
-            'loss': round(float(loss), 4),
+            'loss': round(float(loss.detach()), 4),
             'roofline': roof,
             'kernel_time_ms_per_step': {k: round(v[1], 3) for k, v in sorted(csum.items(), key=lambda kv: -kv[1][1])[:12]},
         }

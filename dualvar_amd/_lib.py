@@ -93,6 +93,9 @@ def load():
         raise DualVarHipError(
             f'{LIB_PATH} is missing: run `python -m dualvar_amd.build` (hipcc --offload-arch=gfx950). '
             'dualvar_amd has no CPU or PyTorch fallback.')
+    # torch bundles its own libamdhip64; it must be in the process BEFORE our library so that both resolve to the
+    # same HIP runtime (loading ours first binds it to /opt/rocm's copy and every launch then reports "no device")
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI and this table disagree
@@ -115,9 +118,11 @@ def require_device():
     import torch
     if not torch.cuda.is_available():
         raise DualVarHipError('dualvar_amd needs an MI355X (gfx950) GPU; none is visible and there is no fallback path')
-    rc = load().dv_check_device()
-    if rc != 0:
-        raise DualVarHipError('current device is not gfx950; the kernels are built for MI355X only')
+    lib = load()
+    arch = getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), 'gcnArchName', '')
+    if not arch.startswith('gfx950'):
+        raise DualVarHipError('current device is %r, not gfx950; the kernels are built for MI355X only '
+                              '(dv_check_device rc=%d)' % (arch, lib.dv_check_device()))
     _device_ok = True
 
 
