@@ -50,10 +50,10 @@ SIGNATURES = {
     'dv_ingest_ncdhw': [I32, P, P, I32, I32, I32, I32, I32, I64, I32, P, P, P, I32, P],
     'dv_bn_reduce_stats': [P, I32, I32, I64, I32, P, P],
     'dv_bn_finalize': [P, I32, I32, P, P, F, F, P, P, P, P, P, P, P],
+    'dv_bn_stats_finalize': [P, I32, I32, I64, I32, P, P, P, F, F, P, P, P, P, P, P, P],
     'dv_bn_apply': [I32, P, I32, P, P, P, I32, P, I32, I64, I32, I32, P],
     'dv_bn_bwd_blocks': [I64, I32],
     'dv_bn_bwd_reduce': [I32, P, I32, P, I32, P, I32, P, P, I64, I32, I32, P, P],
-    'dv_bn_bwd_finalize': [P, I32, I32, P, P],
     'dv_bn_bwd_apply': [I32, P, I32, P, I32, P, I32, P, P, P, P, P, F, P, P, P, I32, P, I32, I64, I32, I32, P],
     'dv_maxpool3d_fwd': [PD, P, P, P, P],
     'dv_maxpool3d_bwd': [PD, P, P, P, I32, P],

@@ -60,9 +60,14 @@ __device__ __forceinline__ float block_sum(float v, float* sh /*>= 4 floats*/) {
 }
 
 // ------------------------------------------------------------------ BN forward statistics
-// one block per channel: partials [tiles][2][C] -> local [2C+1]
+// one block per channel: partials [tiles][2][C] -> local [2C+1]; with `fin` set (single rank) the block also
+// finalises the channel (mean / invstd / scale / shift / running statistics), saving a launch per BN layer
+struct BnFinalize {
+  const float* gamma; const float* beta; float eps, momentum;
+  float* running_mean; float* running_var; float* mean; float* invstd; float* scale; float* shift;
+};
 __global__ void bn_reduce_stats_kernel(const float* __restrict__ part, int n_tiles, int tile_rows, int64_t M, int C,
-                                       float* __restrict__ out) {
+                                       float* __restrict__ out, int fin, BnFinalize f) {
   __shared__ float sh[8];
   const int c = blockIdx.x;
   float s = 0.f;
@@ -81,6 +86,21 @@ __global__ void bn_reduce_stats_kernel(const float* __restrict__ part, int n_til
     out[c] = S;
     out[C + c] = M2;
     if (c == 0) out[2 * C] = (float)M;
+    if (fin) {
+      const float cnt = (float)M;
+      const float var = M2 / cnt;
+      const float invstd = rsqrtf(var + f.eps);
+      f.mean[c] = mean;
+      f.invstd[c] = invstd;
+      const float sc = f.gamma[c] * invstd;
+      f.scale[c] = sc;
+      f.shift[c] = f.beta[c] - mean * sc;
+      if (f.running_mean) {
+        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean;
+        const float unbiased = cnt > 1.f ? M2 / (cnt - 1.f) : var;
+        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
+      }
+    }
   }
 }
 
@@ -115,31 +135,39 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int R, int C
 }
 
 // ------------------------------------------------------------------ BN apply (+residual) (+ReLU)
+// i (vector index) -> (row, first channel) with one mulhi; parameters as 16-byte vector loads (the per-channel
+// arrays are padded to a multiple of 8 floats)
+template <int V>
+__device__ __forceinline__ void load_params(const float* __restrict__ p, int c0, float (&v)[V]) {
+#pragma unroll
+  for (int q = 0; q < V / 4; ++q) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p + c0 + 4 * q);
+    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
+}
+
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
                                 const float* __restrict__ shift, const T* __restrict__ res, int ldr,
-                                T* __restrict__ y, int ldy, int64_t M, int C, int CP, int flags) {
+                                T* __restrict__ y, int ldy, uint32_t total, int C, FastDiv fcv, int flags) {
   constexpr int V = DT<T>::VEC;
-  const int CV = CP / V;
-  const int64_t total = M * CV;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / CV;
-    const int c0 = (int)(i % CV) * V;
-    float v[V], r[V];
-    Pack16<T>::load(x + row * ldx + c0, v);
-    if (res) Pack16<T>::load(res + row * ldr + c0, r);
+  const uint32_t CV = fcv.d;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t row = fd_div(i, fcv);
+    const int c0 = (int)(i - row * CV) * V;
+    float v[V], r[V], sc[V], sh[V];
+    Pack16<T>::load(x + (size_t)row * ldx + c0, v);
+    if (res) Pack16<T>::load(res + (size_t)row * ldr + c0, r);
+    load_params<V>(scale, c0, sc);
+    load_params<V>(shift, c0, sh);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      const int c = c0 + e;
-      float o = 0.f;
-      if (c < C) {
-        o = v[e] * scale[c] + shift[c];
-        if (res) o += r[e];
-        if (flags & DV_RELU) o = fmaxf(o, 0.f);
-      }
-      v[e] = o;
+      float o = v[e] * sc[e] + sh[e];
+      if (res) o += r[e];
+      if (flags & DV_RELU) o = fmaxf(o, 0.f);
+      v[e] = (c0 + e < C) ? o : 0.f;
     }
-    Pack16<T>::store(y + row * ldy + c0, v);
+    Pack16<T>::store(y + (size_t)row * ldy + c0, v);
   }
 }
 
@@ -196,93 +224,110 @@ template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
                                      const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                      const float* __restrict__ invstd, int64_t M, int C, int CP, int flags,
-                                     int64_t rows_per_block, float* __restrict__ part) {
+                                     int64_t rows_per_block, float* __restrict__ sums) {
   constexpr int V = DT<T>::VEC;
   const int64_t r0 = blockIdx.x * rows_per_block;
   const int64_t r1 = min(M, r0 + rows_per_block);
   const bool mask = !(flags & DV_NO_RELU_MASK);
-  float* outp = part + (size_t)blockIdx.x * 2 * C;
   column_reduce<V, 2>(
       r0, r1, CP,
       [&](int64_t r, int c0, float(&acc)[2][V]) {
-        float g[V], yy[V], xx[V];
+        float g[V], yy[V], xx[V], mu[V], is[V];
         Pack16<T>::load(dy + r * lddy + c0, g);
         if (mask) Pack16<T>::load(y + r * ldy + c0, yy);
         Pack16<T>::load(x + r * ldx + c0, xx);
+        load_params<V>(mean, c0, mu);
+        load_params<V>(invstd, c0, is);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          const int c = c0 + e;
-          if (c < C) {
-            float gg = (mask && !(yy[e] > 0.f)) ? 0.f : g[e];
-            acc[0][e] += gg;
-            acc[1][e] += gg * (xx[e] - mean[c]) * invstd[c];
-          }
+          float gg = (mask && !(yy[e] > 0.f)) ? 0.f : g[e];
+          acc[0][e] += gg;
+          acc[1][e] += gg * (xx[e] - mu[e]) * is[e];
         }
       },
       [&](int c0, float(&acc)[2][V]) {
 #pragma unroll
         for (int e = 0; e < V; ++e)
-          if (c0 + e < C) { outp[c0 + e] = acc[0][e]; outp[C + c0 + e] = acc[1][e]; }
+          if (c0 + e < C) { atomicAdd(sums + c0 + e, acc[0][e]); atomicAdd(sums + CP + c0 + e, acc[1][e]); }
       });
 }
 
-// partials [n_blocks][W] -> sums[W] (W = 2C): 32 columns x 8 row lanes per block
-__global__ void reduce_rows_kernel(const float* __restrict__ part, int n_blocks, int Wd, float* __restrict__ out) {
+// partials [n_blocks][W] -> out[W] (+=): 32 columns x 8 row lanes per block
+__global__ void reduce_rows_kernel(const float* __restrict__ part, int64_t ld, int n_rows, int Wd, float* __restrict__ out,
+                                   int accumulate) {
   __shared__ float sh[8][33];
   const int col = blockIdx.x * 32 + (threadIdx.x & 31);
   const int rl = threadIdx.x >> 5;
-  float a = 0.f;
-  if (col < Wd)
-    for (int r = rl; r < n_blocks; r += 8) a += part[(size_t)r * Wd + col];
-  sh[rl][threadIdx.x & 31] = a;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < Wd) {
+    int r = rl;
+    for (; r + 24 < n_rows; r += 32) {
+      a0 += part[(size_t)r * ld + col];
+      a1 += part[(size_t)(r + 8) * ld + col];
+      a2 += part[(size_t)(r + 16) * ld + col];
+      a3 += part[(size_t)(r + 24) * ld + col];
+    }
+    for (; r < n_rows; r += 8) a0 += part[(size_t)r * ld + col];
+  }
+  sh[rl][threadIdx.x & 31] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (rl == 0 && col < Wd) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += sh[i][threadIdx.x & 31];
-    out[col] = s;
+    out[col] = accumulate ? out[col] + s : s;
   }
 }
 
+// dx = k1[c]*g + k2[c]*x + k3[c] with  k1 = gamma*invstd, k2 = -k1*invstd*sgx/M, k3 = -k1*sg/M - k2*mean
+// (sg, sgx = global sums of g and g*xhat).  The table is built once per block in LDS.
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
                                     const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ sums_g, const float* __restrict__ sums_l,
                                     float inv_count, float* dgamma, float* dbeta, T* __restrict__ dx, int lddx,
-                                    T* __restrict__ dres, int lddres, int64_t M, int C, int CP, int flags) {
+                                    T* __restrict__ dres, int lddres, uint32_t total, int C, int CP, FastDiv fcv,
+                                    int flags) {
   constexpr int V = DT<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) float coef[];      // [3][CP]
   if (blockIdx.x == 0 && dgamma) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       dbeta[c] += sums_l[c];
-      dgamma[c] += sums_l[C + c];
+      dgamma[c] += sums_l[CP + c];
     }
   }
-  const int CV = CP / V;
-  const int64_t total = M * CV;
+  for (int c = threadIdx.x; c < CP; c += blockDim.x) {
+    float k1 = 0.f, k2 = 0.f, k3 = 0.f;
+    if (c < C) {
+      k1 = gamma[c] * invstd[c];
+      k2 = -k1 * invstd[c] * sums_g[CP + c] * inv_count;
+      k3 = -k1 * sums_g[c] * inv_count - k2 * mean[c];
+    }
+    coef[c] = k1; coef[CP + c] = k2; coef[2 * CP + c] = k3;
+  }
+  __syncthreads();
+  const uint32_t CV = fcv.d;
   const bool mask = !(flags & DV_NO_RELU_MASK);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / CV;
-    const int c0 = (int)(i % CV) * V;
-    float g[V], yy[V], xx[V], o[V], ro[V];
-    Pack16<T>::load(dy + row * lddy + c0, g);
-    if (mask) Pack16<T>::load(y + row * ldy + c0, yy);
-    Pack16<T>::load(x + row * ldx + c0, xx);
-    if (dres && (flags & DV_ACCUM)) Pack16<T>::load(dres + row * lddres + c0, ro);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t row = fd_div(i, fcv);
+    const int c0 = (int)(i - row * CV) * V;
+    float g[V], yy[V], xx[V], o[V], ro[V], k1[V], k2[V], k3[V];
+    Pack16<T>::load(dy + (size_t)row * lddy + c0, g);
+    if (mask) Pack16<T>::load(y + (size_t)row * ldy + c0, yy);
+    Pack16<T>::load(x + (size_t)row * ldx + c0, xx);
+    if (dres && (flags & DV_ACCUM)) Pack16<T>::load(dres + (size_t)row * lddres + c0, ro);
+    load_params<V>(coef, c0, k1);
+    load_params<V>(coef + CP, c0, k2);
+    load_params<V>(coef + 2 * CP, c0, k3);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      const int c = c0 + e;
-      float gg = 0.f, d = 0.f;
-      if (c < C) {
-        gg = (mask && !(yy[e] > 0.f)) ? 0.f : g[e];
-        const float xh = (xx[e] - mean[c]) * invstd[c];
-        d = gamma[c] * invstd[c] * (gg - sums_g[c] * inv_count - xh * sums_g[C + c] * inv_count);
-      }
-      o[e] = d;
+      const float gg = (mask && !(yy[e] > 0.f)) ? 0.f : g[e];
+      o[e] = k1[e] * gg + k2[e] * xx[e] + k3[e];
       if (dres) ro[e] = (flags & DV_ACCUM) ? ro[e] + gg : gg;
     }
-    Pack16<T>::store(dx + row * lddx + c0, o);
-    if (dres) Pack16<T>::store(dres + row * lddres + c0, ro);
+    Pack16<T>::store(dx + (size_t)row * lddx + c0, o);
+    if (dres) Pack16<T>::store(dres + (size_t)row * lddres + c0, ro);
   }
 }
 
@@ -292,20 +337,22 @@ struct PoolArgs {
   int To, Ho, Wo;
   int kt, kh, kw, st, sh, sw, pt, ph, pw;
   int ldx, ldy;
+  FastDiv fcv, fWo, fHo, fTo, fWi, fHi, fTi;
 };
 
 template <typename T>
 __global__ void maxpool_fwd_kernel(PoolArgs a, const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx) {
   constexpr int V = DT<T>::VEC;
-  const int CV = a.CP / V;
-  const int64_t total = (int64_t)a.N * a.To * a.Ho * a.Wo * CV;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % CV) * V;
-    int64_t m = i / CV;
-    const int wo = (int)(m % a.Wo); int64_t q = m / a.Wo;
-    const int ho = (int)(q % a.Ho); q /= a.Ho;
-    const int to = (int)(q % a.To);
-    const int n = (int)(q / a.To);
+  const uint32_t CV = a.fcv.d;
+  const uint32_t total = (uint32_t)a.N * a.To * a.Ho * a.Wo * CV;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    uint32_t m, cvi, q, wo_, ho_, to_, n_;
+    fd_divmod(i, a.fcv, m, cvi);
+    const int c0 = (int)cvi * V;
+    fd_divmod(m, a.fWo, q, wo_);
+    fd_divmod(q, a.fHo, q, ho_);
+    fd_divmod(q, a.fTo, n_, to_);
+    const int wo = (int)wo_, ho = (int)ho_, to = (int)to_, n = (int)n_;
     float best[V]; int bi[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) { best[e] = -INFINITY; bi[e] = 0; }
@@ -329,8 +376,8 @@ __global__ void maxpool_fwd_kernel(PoolArgs a, const T* __restrict__ x, T* __res
     }
 #pragma unroll
     for (int e = 0; e < V; ++e) if (c0 + e >= a.C) best[e] = 0.f;
-    Pack16<T>::store(y + m * a.ldy + c0, best);
-    uint8_t* ip = idx + m * a.CP + c0;
+    Pack16<T>::store(y + (size_t)m * a.ldy + c0, best);
+    uint8_t* ip = idx + (size_t)m * a.CP + c0;
 #pragma unroll
     for (int e = 0; e < V; ++e) ip[e] = (uint8_t)bi[e];
   }
@@ -340,17 +387,18 @@ template <typename T>
 __global__ void maxpool_bwd_kernel(PoolArgs a, const T* __restrict__ dy, const uint8_t* __restrict__ idx,
                                    T* __restrict__ dx, int accumulate) {
   constexpr int V = DT<T>::VEC;
-  const int CV = a.CP / V;
-  const int64_t total = (int64_t)a.N * a.Ti * a.Hi * a.Wi * CV;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % CV) * V;
-    int64_t m = i / CV;
-    const int wi = (int)(m % a.Wi); int64_t q = m / a.Wi;
-    const int hi = (int)(q % a.Hi); q /= a.Hi;
-    const int ti = (int)(q % a.Ti);
-    const int n = (int)(q / a.Ti);
+  const uint32_t CV = a.fcv.d;
+  const uint32_t total = (uint32_t)a.N * a.Ti * a.Hi * a.Wi * CV;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    uint32_t m, cvi, q, wi_, hi_, ti_, n_;
+    fd_divmod(i, a.fcv, m, cvi);
+    const int c0 = (int)cvi * V;
+    fd_divmod(m, a.fWi, q, wi_);
+    fd_divmod(q, a.fHi, q, hi_);
+    fd_divmod(q, a.fTi, n_, ti_);
+    const int wi = (int)wi_, hi = (int)hi_, ti = (int)ti_, n = (int)n_;
     float acc[V];
-    if (accumulate) Pack16<T>::load(dx + m * a.ldx + c0, acc);
+    if (accumulate) Pack16<T>::load(dx + (size_t)m * a.ldx + c0, acc);
     else {
 #pragma unroll
       for (int e = 0; e < V; ++e) acc[e] = 0.f;
@@ -363,8 +411,9 @@ __global__ void maxpool_bwd_kernel(PoolArgs a, const T* __restrict__ dy, const u
         for (int dw = 0; dw < a.kw; ++dw, ++tap) {
           const int wn = wi + a.pw - dw;
           if ((tn | hn | wn) < 0) continue;
-          if ((tn % a.st) | (hn % a.sh) | (wn % a.sw)) continue;
-          const int to = tn / a.st, ho = hn / a.sh, wo = wn / a.sw;
+          // strides are 1 or 2 (checked on the host)
+          if ((tn & (a.st - 1)) | (hn & (a.sh - 1)) | (wn & (a.sw - 1))) continue;
+          const int to = tn >> (a.st - 1), ho = hn >> (a.sh - 1), wo = wn >> (a.sw - 1);
           if (to >= a.To || ho >= a.Ho || wo >= a.Wo) continue;
           const int64_t mo = (int64_t)((n * a.To + to) * a.Ho + ho) * a.Wo + wo;
           float g[V];
@@ -376,7 +425,7 @@ __global__ void maxpool_bwd_kernel(PoolArgs a, const T* __restrict__ dy, const u
         }
       }
     }
-    Pack16<T>::store(dx + m * a.ldx + c0, acc);
+    Pack16<T>::store(dx + (size_t)m * a.ldx + c0, acc);
   }
 }
 
@@ -430,19 +479,18 @@ __global__ void gate_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const
 // MODE 2: dx (+)= dout[n][c]/S    (spatial_mean_bwd)
 template <typename T, int MODE>
 __global__ void rowscale_kernel(const T* __restrict__ a, int lda, const float* __restrict__ g,
-                                const float* __restrict__ dm, int N, int S, int C, int CP, T* __restrict__ o,
-                                int ldo, int accumulate) {
+                                const float* __restrict__ dm, uint32_t total, FastDiv fcv, FastDiv fS, int C,
+                                T* __restrict__ o, int ldo, int accumulate) {
   constexpr int V = DT<T>::VEC;
-  const int CV = CP / V;
-  const int64_t total = (int64_t)N * S * CV;
-  const float invS = 1.f / (float)S;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / CV;
-    const int c0 = (int)(i % CV) * V;
-    const int n = (int)(row / S);
+  const uint32_t CV = fcv.d;
+  const float invS = 1.f / (float)fS.d;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t row = fd_div(i, fcv);
+    const int c0 = (int)(i - row * CV) * V;
+    const int n = (int)fd_div(row, fS);
     float v[V], old[V];
-    if (MODE != 2) Pack16<T>::load(a + row * lda + c0, v);
-    if (accumulate) Pack16<T>::load(o + row * ldo + c0, old);
+    if (MODE != 2) Pack16<T>::load(a + (size_t)row * lda + c0, v);
+    if (accumulate) Pack16<T>::load(o + (size_t)row * ldo + c0, old);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const int c = c0 + e;
@@ -454,19 +502,11 @@ __global__ void rowscale_kernel(const T* __restrict__ a, int lda, const float* _
       }
       v[e] = accumulate ? old[e] + r : r;
     }
-    Pack16<T>::store(o + row * ldo + c0, v);
+    Pack16<T>::store(o + (size_t)row * ldo + c0, v);
   }
 }
 
 // ------------------------------------------------------------------ small fp32 helpers
-__global__ void colsum_kernel(const float* __restrict__ x, int ldx, int R, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int r = 0; r < R; ++r) s += x[(size_t)r * ldx + c];
-  out[c] += s;
-}
-
 // one wave per row
 __global__ void l2norm_fwd_kernel(const float* __restrict__ x, int R, int D, float eps, float* __restrict__ y,
                                   float* __restrict__ norm) {
@@ -600,8 +640,22 @@ extern "C" int dv_ingest_ncdhw(int32_t dtype, const float* x, void* y, int32_t N
 extern "C" int dv_bn_reduce_stats(const float* partials, int32_t n_tiles, int32_t tile_rows, int64_t M, int32_t C,
                                   float* local_stats, void* stream) {
   if (!partials || !local_stats || n_tiles <= 0 || C <= 0 || M <= 0) return DV_EINVAL;
+  BnFinalize f = {};
   hipLaunchKernelGGL(bn_reduce_stats_kernel, dim3(C), dim3(kThreads), 0, ST(stream), partials, n_tiles, tile_rows, M, C,
-                     local_stats);
+                     local_stats, 0, f);
+  return dv_launch_status();
+}
+
+extern "C" int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int32_t tile_rows, int64_t M, int32_t C,
+                                    float* local_stats, const float* gamma, const float* beta, float eps, float momentum,
+                                    float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                                    float* shift, void* stream) {
+  if (!partials || !local_stats || n_tiles <= 0 || C <= 0 || M <= 0) return DV_EINVAL;
+  if (!gamma || !beta || !mean || !invstd || !scale || !shift) return DV_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return DV_EINVAL;
+  BnFinalize f = {gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
+  hipLaunchKernelGGL(bn_reduce_stats_kernel, dim3(C), dim3(kThreads), 0, ST(stream), partials, n_tiles, tile_rows, M, C,
+                     local_stats, 1, f);
   return dv_launch_status();
 }
 
@@ -621,18 +675,22 @@ extern "C" int dv_bn_apply(int32_t dtype, const void* x, int32_t ldx, const floa
   const int CP = cp8(C);
   if (!x || !y || !scale || !shift || M <= 0 || C <= 0 || ldx < CP || ldy < CP || (residual && ldr < CP)) return DV_EINVAL;
   if (!aligned16(x) || !aligned16(y) || (residual && !aligned16(residual))) return DV_EALIGN;
+  if (!aligned16(scale) || !aligned16(shift)) return DV_EALIGN;
   DISPATCH_T(dtype, {
     constexpr int V = DT<T>::VEC;
     if (ldx % V || ldy % V || (residual && ldr % V)) return DV_EALIGN;
-    hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(M * (CP / V))), dim3(kThreads), 0, ST(stream), (const T*)x,
-                       ldx, scale, shift, (const T*)residual, ldr, (T*)y, ldy, M, C, CP, flags);
+    const int64_t total = M * (CP / V);
+    if (total >= (1ll << 31)) return DV_EINVAL;
+    hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0, ST(stream), (const T*)x,
+                       ldx, scale, shift, (const T*)residual, ldr, (T*)y, ldy, (uint32_t)total, C,
+                       make_fastdiv((uint32_t)(CP / V)), flags);
   });
   return dv_launch_status();
 }
 
 extern "C" int dv_bn_bwd_blocks(int64_t M, int32_t C) {
   (void)C;
-  int64_t b = (M + 63) / 64;
+  int64_t b = (M + 127) / 128;
   if (b > 1024) b = 1024;
   if (b < 1) b = 1;
   return (int)b;
@@ -640,26 +698,20 @@ extern "C" int dv_bn_bwd_blocks(int64_t M, int32_t C) {
 
 extern "C" int dv_bn_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                                 int32_t ldx, const float* mean, const float* invstd, int64_t M, int32_t C, int32_t flags,
-                                float* partials, void* stream) {
+                                float* sums, void* stream) {
   const int CP = cp8(C);
   const bool mask = !(flags & DV_NO_RELU_MASK);
-  if (!dy || !x || (mask && !y) || !mean || !invstd || !partials || M <= 0 || C <= 0) return DV_EINVAL;
+  if (!dy || !x || (mask && !y) || !mean || !invstd || !sums || M <= 0 || C <= 0) return DV_EINVAL;
   if (lddy < CP || ldx < CP || (mask && ldy < CP)) return DV_EINVAL;
-  if (!aligned16(dy) || !aligned16(x) || (mask && !aligned16(y))) return DV_EALIGN;
+  if (!aligned16(dy) || !aligned16(x) || (mask && !aligned16(y)) || !aligned16(mean) || !aligned16(invstd)) return DV_EALIGN;
   const int blocks = dv_bn_bwd_blocks(M, C);
   const int64_t rpb = (M + blocks - 1) / blocks;
   DISPATCH_T(dtype, {
     constexpr int V = DT<T>::VEC;
     if (lddy % V || ldx % V || (mask && ldy % V)) return DV_EALIGN;
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(blocks), dim3(kThreads), 0, ST(stream), (const T*)dy, lddy,
-                       (const T*)y, ldy, (const T*)x, ldx, mean, invstd, M, C, CP, flags, rpb, partials);
+                       (const T*)y, ldy, (const T*)x, ldx, mean, invstd, M, C, CP, flags, rpb, sums);
   });
-  return dv_launch_status();
-}
-
-extern "C" int dv_bn_bwd_finalize(const float* partials, int32_t n_blocks, int32_t C, float* sums, void* stream) {
-  if (!partials || !sums || n_blocks <= 0 || C <= 0) return DV_EINVAL;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, ST(stream), partials, n_blocks, 2 * C, sums);
   return dv_launch_status();
 }
 
@@ -674,12 +726,17 @@ extern "C" int dv_bn_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, cons
   if ((dgamma == nullptr) != (dbeta == nullptr) || (dgamma && !sums_local)) return DV_EINVAL;
   if (lddy < CP || ldx < CP || lddx < CP || (mask && ldy < CP) || (dres && lddres < CP)) return DV_EINVAL;
   if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || (mask && !aligned16(y)) || (dres && !aligned16(dres))) return DV_EALIGN;
+  if (3 * CP * 4 > 60 * 1024) return DV_EUNSUPPORTED;
   DISPATCH_T(dtype, {
     constexpr int V = DT<T>::VEC;
     if (lddy % V || ldx % V || lddx % V || (mask && ldy % V) || (dres && lddres % V)) return DV_EALIGN;
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid_for(M * (CP / V))), dim3(kThreads), 0, ST(stream),
+    const int64_t total = M * (CP / V);
+    if (total >= (1ll << 31)) return DV_EINVAL;
+    int grid = grid_for(total, 2048);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid), dim3(kThreads), 3 * CP * sizeof(float), ST(stream),
                        (const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, mean, invstd, gamma, sums_global,
-                       sums_local, inv_count, dgamma, dbeta, (T*)dx, lddx, (T*)dres, lddres, M, C, CP, flags);
+                       sums_local, inv_count, dgamma, dbeta, (T*)dx, lddx, (T*)dres, lddres, (uint32_t)total, C, CP,
+                       make_fastdiv((uint32_t)(CP / V)), flags);
   });
   return dv_launch_status();
 }
@@ -698,6 +755,11 @@ static int pool_args(const dv_pool_desc* d, PoolArgs& a) {
   if (a.ldx < a.CP || a.ldy < a.CP) return DV_EINVAL;
   const int V = d->dtype == DV_F32 ? 4 : 8;
   if (a.ldx % V || a.ldy % V) return DV_EALIGN;
+  if (d->st > 2 || d->sh > 2 || d->sw > 2) return DV_EUNSUPPORTED;
+  if ((int64_t)a.N * a.Ti * a.Hi * a.Wi * (a.CP / V) >= (1ll << 31)) return DV_EINVAL;
+  a.fcv = make_fastdiv((uint32_t)(a.CP / V));
+  a.fWo = make_fastdiv((uint32_t)a.Wo); a.fHo = make_fastdiv((uint32_t)a.Ho); a.fTo = make_fastdiv((uint32_t)a.To);
+  a.fWi = make_fastdiv((uint32_t)a.Wi); a.fHi = make_fastdiv((uint32_t)a.Hi); a.fTi = make_fastdiv((uint32_t)a.Ti);
   return DV_OK;
 }
 
@@ -750,9 +812,11 @@ extern "C" int dv_spatial_mean_bwd(int32_t dtype, const float* dout, int32_t N, 
   DISPATCH_T(dtype, {
     constexpr int V = DT<T>::VEC;
     if (lddx % V) return DV_EALIGN;
-    hipLaunchKernelGGL((rowscale_kernel<T, 2>), dim3(grid_for((int64_t)N * S * (CP / V))), dim3(kThreads), 0, ST(stream),
-                       (const T*)nullptr, 0, (const float*)nullptr, dout, N, S, C, CP, (T*)dx, lddx,
-                       (flags & DV_ACCUM) ? 1 : 0);
+    const int64_t total = (int64_t)N * S * (CP / V);
+    if (total >= (1ll << 31)) return DV_EINVAL;
+    hipLaunchKernelGGL((rowscale_kernel<T, 2>), dim3(grid_for(total)), dim3(kThreads), 0, ST(stream),
+                       (const T*)nullptr, 0, (const float*)nullptr, dout, (uint32_t)total, make_fastdiv((uint32_t)(CP / V)),
+                       make_fastdiv((uint32_t)S), C, (T*)dx, lddx, (flags & DV_ACCUM) ? 1 : 0);
   });
   return dv_launch_status();
 }
@@ -765,8 +829,11 @@ extern "C" int dv_gate_scale(int32_t dtype, const void* x, int32_t ldx, const fl
   DISPATCH_T(dtype, {
     constexpr int V = DT<T>::VEC;
     if (ldx % V || ldy % V) return DV_EALIGN;
-    hipLaunchKernelGGL((rowscale_kernel<T, 0>), dim3(grid_for((int64_t)N * S * (CP / V))), dim3(kThreads), 0, ST(stream),
-                       (const T*)x, ldx, g, (const float*)nullptr, N, S, C, CP, (T*)y, ldy, 0);
+    const int64_t total = (int64_t)N * S * (CP / V);
+    if (total >= (1ll << 31)) return DV_EINVAL;
+    hipLaunchKernelGGL((rowscale_kernel<T, 0>), dim3(grid_for(total)), dim3(kThreads), 0, ST(stream),
+                       (const T*)x, ldx, g, (const float*)nullptr, (uint32_t)total, make_fastdiv((uint32_t)(CP / V)),
+                       make_fastdiv((uint32_t)S), C, (T*)y, ldy, 0);
   });
   return dv_launch_status();
 }
@@ -792,15 +859,18 @@ extern "C" int dv_gate_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, co
   DISPATCH_T(dtype, {
     constexpr int V = DT<T>::VEC;
     if (lddy % V || lddx % V) return DV_EALIGN;
-    hipLaunchKernelGGL((rowscale_kernel<T, 1>), dim3(grid_for((int64_t)N * S * (CP / V))), dim3(kThreads), 0, ST(stream),
-                       (const T*)dy, lddy, g, dmean, N, S, C, CP, (T*)dx, lddx, (flags & DV_ACCUM) ? 1 : 0);
+    const int64_t total = (int64_t)N * S * (CP / V);
+    if (total >= (1ll << 31)) return DV_EINVAL;
+    hipLaunchKernelGGL((rowscale_kernel<T, 1>), dim3(grid_for(total)), dim3(kThreads), 0, ST(stream),
+                       (const T*)dy, lddy, g, dmean, (uint32_t)total, make_fastdiv((uint32_t)(CP / V)),
+                       make_fastdiv((uint32_t)S), C, (T*)dx, lddx, (flags & DV_ACCUM) ? 1 : 0);
   });
   return dv_launch_status();
 }
 
 extern "C" int dv_colsum_f32(const float* x, int32_t ldx, int32_t R, int32_t C, float* out, void* stream) {
   if (!x || !out || R <= 0 || C <= 0 || ldx < C) return DV_EINVAL;
-  hipLaunchKernelGGL(colsum_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), x, ldx, R, C, out);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 31) / 32), dim3(256), 0, ST(stream), x, (int64_t)ldx, R, C, out, 1);
   return dv_launch_status();
 }
 extern "C" int dv_l2norm_fwd(const float* x, int32_t R, int32_t D, float eps, float* y, float* norm, void* stream) {

@@ -23,7 +23,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k = 0; k < K; k += 2) {
+  // 8 k-steps per trip: the 16 loads are issued before the first MFMA consumes them (the operands come
+  // straight from global memory / L2, so the loop is latency-bound without this ILP)
+  int k = 0;
+  for (; k + 16 <= K; k += 16) {
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = k + 2 * u + h;
+      a[u] = (m < M) ? ap[(int64_t)kk * sak] : 0.f;
+      b[u] = (n < N) ? bp[(int64_t)kk * sbk] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; k < K; k += 2) {
     const int kk = k + h;
     float a = (m < M && kk < K) ? ap[(int64_t)kk * sak] : 0.f;
     float b = (n < N && kk < K) ? bp[(int64_t)kk * sbk] : 0.f;

@@ -272,7 +272,9 @@ class Plan:
         self.f_list, self.b_list = [], []
         self.bytes = 0
         self.lib = L.load()
-        self.timer = None            # set by bench.py: callable(launch) -> context recording HIP events
+        self.timer = None            # set by bench.py: callable(launch, stream) recording HIP events
+        self._zero_words = 0         # fp32 words that must be zero at the start of every backward (atomic targets)
+        self.zero_arena = None
 
     # ------------------------------------------------------------------ buffers
     def act(self, N, T, H, W, C_, dtype=None, cpitch=None, grad=None, zero=False):
@@ -295,6 +297,14 @@ class Plan:
         t = (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=self.device)
         self.bytes += t.numel() * 4
         return t
+
+    def reserve_zero(self, n):
+        off = self._zero_words
+        self._zero_words += (n + 7) & ~7
+        return off
+
+    def zero_ptr(self, off):
+        return self.zero_arena.data_ptr() + off * 4
 
     # ------------------------------------------------------------------ graph ops
     def _push(self, op):
@@ -326,6 +336,10 @@ class Plan:
                 key = (a.buf.data_ptr(), a.off)
                 op.acc[name] = key in seen
                 seen.add(key)
+        if self.with_grad and self._zero_words:
+            self.zero_arena = self.f32(self._zero_words)
+            arena = self.zero_arena
+            self.b_list.append(HostStep('zero_bwd_sums', arena.zero_))
         for op in self.ops:
             f, b = op.launches()
             self.f_list += f
@@ -426,14 +440,14 @@ class BNOp(Op):
         self.C, self.M = x.C, x.rows
         self.y = out if out is not None else plan.act(x.N, x.T, x.H, x.W, x.C)
         Cn, R = self.C, plan.comm.world
+        self.CP = cp8(Cn)
         self.local = plan.f32(2 * Cn + 1)
         self.gathered = plan.f32(R, 2 * Cn + 1) if R > 1 else self.local
-        self.mean, self.invstd, self.scale, self.shift = (plan.f32(Cn) for _ in range(4))
+        # per-channel arrays are read with 16-byte loads: padded to CP
+        self.mean, self.invstd, self.scale, self.shift = (plan.f32(self.CP) for _ in range(4))
         if plan.with_grad:
-            self.nb = plan.lib.dv_bn_bwd_blocks(self.M, Cn)
-            self.part = plan.f32(self.nb, 2, Cn)
-            self.sums = plan.f32(2, Cn)
-            self.sums_g = plan.f32(2, Cn) if R > 1 else self.sums
+            self.sums_off = plan.reserve_zero(2 * self.CP)
+            self.sums_g = plan.f32(2, self.CP) if R > 1 else None
 
     def grad_targets(self):
         return [('res', self.res)] if (self.res is not None and self.res.grad is not None and self.plan.with_grad) else []
@@ -446,15 +460,20 @@ class BNOp(Op):
         rv = bn.running_var.data_ptr() if bn.running_var is not None else 0
         eps, mom = float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1)
         dt = _dt(p.dtype)
-        f = [Launch('bn_reduce_stats', 'bn_reduce_stats', lib.dv_bn_reduce_stats,
-                    (self.conv.stats.data_ptr(), self.conv.tiles, 128, M, Cn, self.local.data_ptr()),
-                    self.conv.tiles * 2 * Cn * 4)]
-        if R > 1:
+        if R == 1:
+            f = [Launch('bn_stats_finalize', 'bn_reduce_stats', lib.dv_bn_stats_finalize,
+                        (self.conv.stats.data_ptr(), self.conv.tiles, 128, M, Cn, self.local.data_ptr(), st.w_master(gs),
+                         st.w_master(bs), eps, mom, rm, rv, self.mean.data_ptr(), self.invstd.data_ptr(),
+                         self.scale.data_ptr(), self.shift.data_ptr()), self.conv.tiles * 2 * Cn * 4)]
+        else:
+            f = [Launch('bn_reduce_stats', 'bn_reduce_stats', lib.dv_bn_reduce_stats,
+                        (self.conv.stats.data_ptr(), self.conv.tiles, 128, M, Cn, self.local.data_ptr()),
+                        self.conv.tiles * 2 * Cn * 4)]
             local, gathered, group = self.local, self.gathered, p.comm.group
             f.append(HostStep('syncbn_allgather', lambda: dist.all_gather_into_tensor(gathered.view(-1), local, group=group)))
-        f.append(Launch('bn_finalize', 'bn_finalize', lib.dv_bn_finalize,
-                        (self.gathered.data_ptr(), R, Cn, st.w_master(gs), st.w_master(bs), eps, mom, rm, rv,
-                         self.mean.data_ptr(), self.invstd.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr())))
+            f.append(Launch('bn_finalize', 'bn_finalize', lib.dv_bn_finalize,
+                            (self.gathered.data_ptr(), R, Cn, st.w_master(gs), st.w_master(bs), eps, mom, rm, rv,
+                             self.mean.data_ptr(), self.invstd.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr())))
         f.append(Launch('bn_apply', 'bn_apply<%s>' % dt, lib.dv_bn_apply,
                         (p.dtype, x.ptr, x.ld, self.scale.data_ptr(), self.shift.data_ptr(),
                          res.ptr if res is not None else 0, res.ld if res is not None else 0, y.ptr, y.ld, M, Cn,
@@ -465,24 +484,26 @@ class BNOp(Op):
             dy = y.grad
             mflag = 0 if self.relu else DV_NO_RELU_MASK
             nact = 3 if self.relu else 2
+            sums = p.zero_ptr(self.sums_off)
             b.append(Launch('bn_bwd_reduce', 'bn_bwd_reduce<%s>' % dt, lib.dv_bn_bwd_reduce,
                             (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, self.mean.data_ptr(), self.invstd.data_ptr(),
-                             M, Cn, mflag, self.part.data_ptr()), _abytes(x) * nact))
-            b.append(Launch('bn_bwd_finalize', 'reduce_rows', lib.dv_bn_bwd_finalize,
-                            (self.part.data_ptr(), self.nb, Cn, self.sums.data_ptr()), self.nb * 2 * Cn * 4))
+                             M, Cn, mflag, sums), _abytes(x) * nact))
+            sums_gp = sums
             if R > 1:
-                sums, sums_g, group = self.sums, self.sums_g, p.comm.group
+                sums_g, group = self.sums_g, p.comm.group
+                src = p.zero_arena.narrow(0, self.sums_off, 2 * self.CP)
 
                 def _allreduce():
-                    sums_g.copy_(sums)
+                    sums_g.view(-1).copy_(src)
                     dist.all_reduce(sums_g, group=group)
                 b.append(HostStep('syncbn_allreduce', _allreduce))
+                sums_gp = sums_g.data_ptr()
             dres = res.grad if (res is not None and res.grad is not None) else None
             bflags = mflag | (DV_ACCUM if (dres is not None and self.acc.get('res')) else 0)
             nres = 0 if dres is None else (2 if bflags & DV_ACCUM else 1)
             b.append(Launch('bn_bwd_apply', 'bn_bwd_apply<%s>' % dt, lib.dv_bn_bwd_apply,
                             (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, self.mean.data_ptr(), self.invstd.data_ptr(),
-                             st.w_master(gs), self.sums_g.data_ptr(), self.sums.data_ptr(), 1.0 / (M * R),
+                             st.w_master(gs), sums_gp, sums, 1.0 / (M * R),
                              st.w_grad(gs), st.w_grad(bs), x.grad.ptr, x.grad.ld,
                              dres.ptr if dres is not None else 0, dres.ld if dres is not None else 0, M, Cn, bflags),
                             _abytes(x) * (nact + 1 + nres)))

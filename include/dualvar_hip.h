@@ -123,16 +123,24 @@ int dv_ingest_ncdhw(int32_t dtype, const float* x, void* y, int32_t N, int32_t C
  *   dv_bn_finalize     : R ranks' (sum, M2, count) -> mean, invstd, scale=gamma*invstd,
  *                        shift=beta-mean*scale; running stats updated with momentum
  *                        (unbiased variance, PyTorch semantics).
+ *   dv_bn_stats_finalize : both of the above in one launch for the single-rank case.
  *   dv_bn_apply        : y = act(x*scale + shift [+ residual]) into a (possibly sliced) view.
  * Backward:
- *   dv_bn_bwd_reduce   : g = dy*(y>0); per-block partials of sum(g), sum(g*xhat)
- *   dv_bn_bwd_finalize : partials -> local sums [2][C]
+ *   dv_bn_bwd_reduce   : g = dy*(y>0); sums[0][c] += sum(g), sums[1][c] += sum(g*xhat)  (block-reduced, then
+ *                        one fp32 atomic per block and channel; the caller zeroes `sums` [2][CP] first)
  *   dv_bn_bwd_apply    : dgamma += sum(g*xhat)_local, dbeta += sum(g)_local (local sums);
  *                        dx = scale*(g - sum_g/M - xhat*sum_gx/M) with the GLOBAL sums/M;
  *                        optional dres (+)= g for the residual branch.
  */
+/* Per-channel fp32 arrays read by the apply / backward kernels (scale, shift, mean, invstd, gamma, sums) are
+ * accessed with 16-byte loads: they must be 16-byte aligned and readable up to CP = round_up(C, 8) floats;
+ * `sums` arrays are laid out [2][CP]. */
 int dv_bn_reduce_stats(const float* partials, int32_t n_tiles, int32_t tile_rows, int64_t M, int32_t C,
                        float* local_stats /*[2*C+1]*/, void* stream);
+int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int32_t tile_rows, int64_t M, int32_t C,
+                         float* local_stats /*[2*C+1]*/, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                         float* scale, float* shift, void* stream);
 int dv_bn_finalize(const float* stats /*[R][2*C+1]*/, int32_t R, int32_t C, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                    float* mean, float* invstd, float* scale, float* shift, void* stream);
@@ -142,11 +150,10 @@ int dv_bn_apply(int32_t dtype, const void* x, int32_t ldx, const float* scale, c
 int dv_bn_bwd_blocks(int64_t M, int32_t C);
 int dv_bn_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                      int32_t ldx, const float* mean, const float* invstd, int64_t M, int32_t C,
-                     int32_t flags, float* partials /*[blocks][2][C]*/, void* stream);
-int dv_bn_bwd_finalize(const float* partials, int32_t n_blocks, int32_t C, float* sums /*[2][C]*/, void* stream);
+                     int32_t flags, float* sums /*[2][CP], pre-zeroed, accumulated atomically*/, void* stream);
 int dv_bn_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                     int32_t ldx, const float* mean, const float* invstd, const float* gamma,
-                    const float* sums_global /*[2][C]*/, const float* sums_local /*[2][C]*/, float inv_count,
+                    const float* sums_global /*[2][CP]*/, const float* sums_local /*[2][CP]*/, float inv_count,
                     float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres, int32_t lddres,
                     int64_t M, int32_t C, int32_t flags, void* stream);
 

@@ -205,8 +205,21 @@ def test_batchnorm_fwd_bwd(gpu, dtype, C_, residual, relu):
     ops.call('dv_bn_reduce_stats', part, tiles, 128, M, C_, local)
     # two "ranks" with half the data each must give the same result as one (SyncBN identity)
     rm, rv = torch.zeros(C_, device=gpu), torch.ones(C_, device=gpu)
-    mean, invstd, scale, shift = (torch.empty(C_, device=gpu) for _ in range(4))
-    ops.call('dv_bn_finalize', local, 1, C_, gamma.to(gpu), beta.to(gpu), 1e-5, 0.1, rm, rv, mean, invstd, scale, shift)
+    CP = ops.cp8(C_)
+
+    def padded(t):                  # per-channel arrays are read with 16-byte loads up to round_up(C, 8)
+        o = torch.zeros(CP, device=gpu)
+        o[:C_] = t.to(gpu)
+        return o
+    mean, invstd, scale, shift = (torch.zeros(CP, device=gpu) for _ in range(4))
+    gam, bet = padded(gamma), padded(beta)
+    ops.call('dv_bn_finalize', local, 1, C_, gam, bet, 1e-5, 0.1, rm, rv, mean, invstd, scale, shift)
+    # the fused single-rank variant must agree with reduce + finalize
+    rm2, rv2, local2 = torch.zeros(C_, device=gpu), torch.ones(C_, device=gpu), torch.zeros(2 * C_ + 1, device=gpu)
+    o2 = [torch.zeros(CP, device=gpu) for _ in range(4)]
+    ops.call('dv_bn_stats_finalize', part, tiles, 128, M, C_, local2, gam, bet, 1e-5, 0.1, rm2, rv2, *o2)
+    for a_, b_ in zip((mean, invstd, scale, shift, rm, rv, local), (*o2, rm2, rv2, local2)):
+        assert torch.equal(a_, b_)
     close(rm, bn.running_mean, DV_F32, 'running_mean', factor=10)
     close(rv, bn.running_var, DV_F32, 'running_var', factor=10)
     ya = ops.new_act(N, T, H, W, C_, dtype, gpu)
@@ -216,15 +229,12 @@ def test_batchnorm_fwd_bwd(gpu, dtype, C_, residual, relu):
 
     dya = ops.act_from_ncdhw(gy.to(gpu), dtype)
     flags = 0 if relu else ops.DV_NO_RELU_MASK
-    nb = ops.L.load().dv_bn_bwd_blocks(M, C_)
-    partb = torch.zeros(nb, 2, C_, device=gpu)
-    ops.call('dv_bn_bwd_reduce', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, M, C_, flags, partb)
-    sums = torch.zeros(2, C_, device=gpu)
-    ops.call('dv_bn_bwd_finalize', partb, nb, C_, sums)
+    sums = torch.zeros(2, CP, device=gpu)
+    ops.call('dv_bn_bwd_reduce', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, M, C_, flags, sums)
     dg, db = torch.zeros(C_, device=gpu), torch.zeros(C_, device=gpu)
     dxa = ops.new_act(N, T, H, W, C_, dtype, gpu)
     dra = ops.new_act(N, T, H, W, C_, dtype, gpu) if residual else None
-    ops.call('dv_bn_bwd_apply', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, gamma.to(gpu), sums, sums,
+    ops.call('dv_bn_bwd_apply', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, gam, sums, sums,
              1.0 / M, dg, db, dxa, dxa.ld, dra, dra.ld if dra else 0, M, C_, flags)
     f = 3 if dtype == DV_BF16 else 20
     close(ops.act_to_ncdhw(dxa), xr.grad, dtype, 'bn dx', factor=f)
@@ -245,6 +255,10 @@ def test_bn_two_rank_combine(gpu):
     ops.call('dv_bn_finalize', st, 2, C_, torch.ones(C_, device=gpu), torch.zeros(C_, device=gpu), 1e-5, 0.1, None, None, *outs)
     close(outs[0], x.mean(0), DV_F32, 'mean 2-rank', factor=5)
     close(outs[1], (x.var(0, unbiased=False) + 1e-5).rsqrt(), DV_F32, 'invstd 2-rank', factor=5)
+    # the host-side restatement used by the gloo tests agrees
+    from dualvar_amd.parallel import combine_bn_stats
+    m_h, v_h = combine_bn_stats(st.cpu())
+    close(outs[0], m_h, DV_F32, 'host combine mean', factor=5)
 
 
 POOL_CASES = [((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((3, 3, 3), (1, 1, 1), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)),
