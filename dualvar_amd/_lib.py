@@ -53,8 +53,8 @@ SIGNATURES = {
     'dv_bn_stats_finalize': [P, I32, I32, I64, I32, P, P, P, F, F, P, P, P, P, P, P, P],
     'dv_bn_apply': [I32, P, I32, P, P, P, I32, P, I32, I64, I32, I32, P],
     'dv_bn_bwd_blocks': [I64, I32],
-    'dv_bn_bwd_reduce': [I32, P, I32, P, I32, P, I32, P, P, I64, I32, I32, P, P],
-    'dv_bn_bwd_apply': [I32, P, I32, P, I32, P, I32, P, P, P, P, P, F, P, P, P, I32, P, I32, I64, I32, I32, P],
+    'dv_bn_bwd_reduce': [I32, P, I32, P, I32, P, I32, P, P, I64, I32, I32, P, I32, P],
+    'dv_bn_bwd_apply': [I32, P, I32, P, I32, P, I32, P, P, P, P, I32, P, I32, F, P, P, P, I32, P, I32, I64, I32, I32, P],
     'dv_maxpool3d_fwd': [PD, P, P, P, P],
     'dv_maxpool3d_bwd': [PD, P, P, P, I32, P],
     'dv_spatial_mean': [I32, P, I32, I32, I32, I32, P, P],

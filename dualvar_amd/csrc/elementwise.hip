@@ -224,8 +224,10 @@ template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
                                      const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                      const float* __restrict__ invstd, int64_t M, int C, int CP, int flags,
-                                     int64_t rows_per_block, float* __restrict__ sums) {
+                                     int64_t rows_per_block, float* __restrict__ sums_all, int n_rep) {
   constexpr int V = DT<T>::VEC;
+  // atomics on one address serialise at the memory side (~12 ns each): spread the blocks over n_rep replicas
+  float* sums = sums_all + (size_t)(blockIdx.x % n_rep) * 2 * CP;
   const int64_t r0 = blockIdx.x * rows_per_block;
   const int64_t r1 = min(M, r0 + rows_per_block);
   const bool mask = !(flags & DV_NO_RELU_MASK);
@@ -285,24 +287,28 @@ template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
                                     const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ sums_g, const float* __restrict__ sums_l,
-                                    float inv_count, float* dgamma, float* dbeta, T* __restrict__ dx, int lddx,
+                                    const float* __restrict__ sums_g, int rep_g, const float* __restrict__ sums_l,
+                                    int rep_l, float inv_count, float* dgamma, float* dbeta, T* __restrict__ dx, int lddx,
                                     T* __restrict__ dres, int lddres, uint32_t total, int C, int CP, FastDiv fcv,
                                     int flags) {
   constexpr int V = DT<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) float coef[];      // [3][CP]
   if (blockIdx.x == 0 && dgamma) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      dbeta[c] += sums_l[c];
-      dgamma[c] += sums_l[CP + c];
+      float sb = 0.f, sg = 0.f;
+      for (int r = 0; r < rep_l; ++r) { sb += sums_l[(size_t)r * 2 * CP + c]; sg += sums_l[(size_t)r * 2 * CP + CP + c]; }
+      dbeta[c] += sb;
+      dgamma[c] += sg;
     }
   }
   for (int c = threadIdx.x; c < CP; c += blockDim.x) {
     float k1 = 0.f, k2 = 0.f, k3 = 0.f;
     if (c < C) {
+      float sg = 0.f, sgx = 0.f;
+      for (int r = 0; r < rep_g; ++r) { sg += sums_g[(size_t)r * 2 * CP + c]; sgx += sums_g[(size_t)r * 2 * CP + CP + c]; }
       k1 = gamma[c] * invstd[c];
-      k2 = -k1 * invstd[c] * sums_g[CP + c] * inv_count;
-      k3 = -k1 * sums_g[c] * inv_count - k2 * mean[c];
+      k2 = -k1 * invstd[c] * sgx * inv_count;
+      k3 = -k1 * sg * inv_count - k2 * mean[c];
     }
     coef[c] = k1; coef[CP + c] = k2; coef[2 * CP + c] = k3;
   }
@@ -698,10 +704,10 @@ extern "C" int dv_bn_bwd_blocks(int64_t M, int32_t C) {
 
 extern "C" int dv_bn_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                                 int32_t ldx, const float* mean, const float* invstd, int64_t M, int32_t C, int32_t flags,
-                                float* sums, void* stream) {
+                                float* sums, int32_t n_rep, void* stream) {
   const int CP = cp8(C);
   const bool mask = !(flags & DV_NO_RELU_MASK);
-  if (!dy || !x || (mask && !y) || !mean || !invstd || !sums || M <= 0 || C <= 0) return DV_EINVAL;
+  if (!dy || !x || (mask && !y) || !mean || !invstd || !sums || M <= 0 || C <= 0 || n_rep <= 0) return DV_EINVAL;
   if (lddy < CP || ldx < CP || (mask && ldy < CP)) return DV_EINVAL;
   if (!aligned16(dy) || !aligned16(x) || (mask && !aligned16(y)) || !aligned16(mean) || !aligned16(invstd)) return DV_EALIGN;
   const int blocks = dv_bn_bwd_blocks(M, C);
@@ -710,20 +716,20 @@ extern "C" int dv_bn_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, con
     constexpr int V = DT<T>::VEC;
     if (lddy % V || ldx % V || (mask && ldy % V)) return DV_EALIGN;
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(blocks), dim3(kThreads), 0, ST(stream), (const T*)dy, lddy,
-                       (const T*)y, ldy, (const T*)x, ldx, mean, invstd, M, C, CP, flags, rpb, sums);
+                       (const T*)y, ldy, (const T*)x, ldx, mean, invstd, M, C, CP, flags, rpb, sums, n_rep);
   });
   return dv_launch_status();
 }
 
 extern "C" int dv_bn_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                                int32_t ldx, const float* mean, const float* invstd, const float* gamma,
-                               const float* sums_global, const float* sums_local, float inv_count, float* dgamma,
-                               float* dbeta, void* dx, int32_t lddx, void* dres, int32_t lddres, int64_t M, int32_t C,
-                               int32_t flags, void* stream) {
+                               const float* sums_global, int32_t rep_global, const float* sums_local, int32_t rep_local,
+                               float inv_count, float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres,
+                               int32_t lddres, int64_t M, int32_t C, int32_t flags, void* stream) {
   const int CP = cp8(C);
   const bool mask = !(flags & DV_NO_RELU_MASK);
   if (!dy || !x || (mask && !y) || !mean || !invstd || !gamma || !sums_global || !dx || M <= 0 || C <= 0) return DV_EINVAL;
-  if ((dgamma == nullptr) != (dbeta == nullptr) || (dgamma && !sums_local)) return DV_EINVAL;
+  if ((dgamma == nullptr) != (dbeta == nullptr) || (dgamma && (!sums_local || rep_local <= 0)) || rep_global <= 0) return DV_EINVAL;
   if (lddy < CP || ldx < CP || lddx < CP || (mask && ldy < CP) || (dres && lddres < CP)) return DV_EINVAL;
   if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || (mask && !aligned16(y)) || (dres && !aligned16(dres))) return DV_EALIGN;
   if (3 * CP * 4 > 60 * 1024) return DV_EUNSUPPORTED;
@@ -735,7 +741,7 @@ extern "C" int dv_bn_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, cons
     int grid = grid_for(total, 2048);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid), dim3(kThreads), 3 * CP * sizeof(float), ST(stream),
                        (const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, mean, invstd, gamma, sums_global,
-                       sums_local, inv_count, dgamma, dbeta, (T*)dx, lddx, (T*)dres, lddres, (uint32_t)total, C, CP,
+                       rep_global, sums_local, rep_local, inv_count, dgamma, dbeta, (T*)dx, lddx, (T*)dres, lddres, (uint32_t)total, C, CP,
                        make_fastdiv((uint32_t)(CP / V)), flags);
   });
   return dv_launch_status();

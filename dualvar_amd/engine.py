@@ -22,6 +22,9 @@ from . import ops
 from .ops import DV_ACCUM, DV_BF16, DV_BIAS, DV_F32, DV_NO_RELU_MASK, DV_RELU, DV_SIGMOID, DV_STATS, Act, cp8
 
 
+BN_REPLICAS = 32      # replicas of the BN-backward atomic accumulators (dv_bn_bwd_reduce)
+
+
 def _align8(n):
     return (n + 7) & ~7
 
@@ -446,7 +449,7 @@ class BNOp(Op):
         # per-channel arrays are read with 16-byte loads: padded to CP
         self.mean, self.invstd, self.scale, self.shift = (plan.f32(self.CP) for _ in range(4))
         if plan.with_grad:
-            self.sums_off = plan.reserve_zero(2 * self.CP)
+            self.sums_off = plan.reserve_zero(BN_REPLICAS * 2 * self.CP)
             self.sums_g = plan.f32(2, self.CP) if R > 1 else None
 
     def grad_targets(self):
@@ -487,23 +490,23 @@ class BNOp(Op):
             sums = p.zero_ptr(self.sums_off)
             b.append(Launch('bn_bwd_reduce', 'bn_bwd_reduce<%s>' % dt, lib.dv_bn_bwd_reduce,
                             (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, self.mean.data_ptr(), self.invstd.data_ptr(),
-                             M, Cn, mflag, sums), _abytes(x) * nact))
-            sums_gp = sums
+                             M, Cn, mflag, sums, BN_REPLICAS), _abytes(x) * nact))
+            sums_gp, rep_g = sums, BN_REPLICAS
             if R > 1:
                 sums_g, group = self.sums_g, p.comm.group
-                src = p.zero_arena.narrow(0, self.sums_off, 2 * self.CP)
+                src = p.zero_arena.narrow(0, self.sums_off, BN_REPLICAS * 2 * self.CP).view(BN_REPLICAS, 2, self.CP)
 
                 def _allreduce():
-                    sums_g.view(-1).copy_(src)
+                    torch.sum(src, dim=0, out=sums_g)
                     dist.all_reduce(sums_g, group=group)
                 b.append(HostStep('syncbn_allreduce', _allreduce))
-                sums_gp = sums_g.data_ptr()
+                sums_gp, rep_g = sums_g.data_ptr(), 1
             dres = res.grad if (res is not None and res.grad is not None) else None
             bflags = mflag | (DV_ACCUM if (dres is not None and self.acc.get('res')) else 0)
             nres = 0 if dres is None else (2 if bflags & DV_ACCUM else 1)
             b.append(Launch('bn_bwd_apply', 'bn_bwd_apply<%s>' % dt, lib.dv_bn_bwd_apply,
                             (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, self.mean.data_ptr(), self.invstd.data_ptr(),
-                             st.w_master(gs), sums_gp, sums, 1.0 / (M * R),
+                             st.w_master(gs), sums_gp, rep_g, sums, BN_REPLICAS, 1.0 / (M * R),
                              st.w_grad(gs), st.w_grad(bs), x.grad.ptr, x.grad.ld,
                              dres.ptr if dres is not None else 0, dres.ld if dres is not None else 0, M, Cn, bflags),
                             _abytes(x) * (nact + 1 + nres)))

@@ -127,7 +127,8 @@ int dv_ingest_ncdhw(int32_t dtype, const float* x, void* y, int32_t N, int32_t C
  *   dv_bn_apply        : y = act(x*scale + shift [+ residual]) into a (possibly sliced) view.
  * Backward:
  *   dv_bn_bwd_reduce   : g = dy*(y>0); sums[0][c] += sum(g), sums[1][c] += sum(g*xhat)  (block-reduced, then
- *                        one fp32 atomic per block and channel; the caller zeroes `sums` [2][CP] first)
+ *                        one fp32 atomic per block and channel, block b into replica b % n_rep so that the
+ *                        memory-side atomics do not serialise; the caller zeroes `sums` [n_rep][2][CP] first)
  *   dv_bn_bwd_apply    : dgamma += sum(g*xhat)_local, dbeta += sum(g)_local (local sums);
  *                        dx = scale*(g - sum_g/M - xhat*sum_gx/M) with the GLOBAL sums/M;
  *                        optional dres (+)= g for the residual branch.
@@ -150,10 +151,12 @@ int dv_bn_apply(int32_t dtype, const void* x, int32_t ldx, const float* scale, c
 int dv_bn_bwd_blocks(int64_t M, int32_t C);
 int dv_bn_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                      int32_t ldx, const float* mean, const float* invstd, int64_t M, int32_t C,
-                     int32_t flags, float* sums /*[2][CP], pre-zeroed, accumulated atomically*/, void* stream);
+                     int32_t flags, float* sums /*[n_rep][2][CP], pre-zeroed, accumulated atomically*/, int32_t n_rep,
+                     void* stream);
 int dv_bn_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                     int32_t ldx, const float* mean, const float* invstd, const float* gamma,
-                    const float* sums_global /*[2][CP]*/, const float* sums_local /*[2][CP]*/, float inv_count,
+                    const float* sums_global /*[rep_global][2][CP]*/, int32_t rep_global,
+                    const float* sums_local /*[rep_local][2][CP]*/, int32_t rep_local, float inv_count,
                     float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres, int32_t lddres,
                     int64_t M, int32_t C, int32_t flags, void* stream);
 

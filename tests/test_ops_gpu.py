@@ -229,12 +229,12 @@ def test_batchnorm_fwd_bwd(gpu, dtype, C_, residual, relu):
 
     dya = ops.act_from_ncdhw(gy.to(gpu), dtype)
     flags = 0 if relu else ops.DV_NO_RELU_MASK
-    sums = torch.zeros(2, CP, device=gpu)
-    ops.call('dv_bn_bwd_reduce', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, M, C_, flags, sums)
+    sums = torch.zeros(4, 2, CP, device=gpu)          # 4 replicas of the atomic accumulators
+    ops.call('dv_bn_bwd_reduce', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, M, C_, flags, sums, 4)
     dg, db = torch.zeros(C_, device=gpu), torch.zeros(C_, device=gpu)
     dxa = ops.new_act(N, T, H, W, C_, dtype, gpu)
     dra = ops.new_act(N, T, H, W, C_, dtype, gpu) if residual else None
-    ops.call('dv_bn_bwd_apply', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, gam, sums, sums,
+    ops.call('dv_bn_bwd_apply', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, gam, sums, 4, sums, 4,
              1.0 / M, dg, db, dxa, dxa.ld, dra, dra.ld if dra else 0, M, C_, flags)
     f = 3 if dtype == DV_BF16 else 20
     close(ops.act_to_ncdhw(dxa), xr.grad, dtype, 'bn dx', factor=f)
