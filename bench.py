@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--size', type=int, default=112)
     ap.add_argument('--moco-k', type=int, default=65536)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dump-launches', default='', help='write a per-launch timing table (calibration step) to this file')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=2)
     return ap.parse_args()
@@ -187,6 +188,13 @@ def main():
     step()
     torch.cuda.synchronize()
     csum = cal.summary()
+    if args.dump_launches and rank == 0:
+        with open(args.dump_launches, 'w') as fh:
+            fh.write('name\tkernel\tus\tGB/s\tTFLOP/s\tbytes\tflops\tshape\n')
+            for l, a, b in cal.rec:
+                us = a.elapsed_time(b) * 1e3
+                fh.write('%s\t%s\t%.1f\t%.0f\t%.1f\t%d\t%d\t%s\n' % (l.name, l.kname, us, l.bytes / us / 1e3, l.flops / us / 1e6,
+                                                                     l.bytes, l.flops, getattr(l, 'shape', '')))
     dominant = max((k for k in csum if not k.startswith('host:')), key=lambda k: csum[k][1])
     probe = KernelTimer(only=dominant)
     for p in all_plans(model):

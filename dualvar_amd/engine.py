@@ -22,7 +22,7 @@ from . import ops
 from .ops import DV_ACCUM, DV_BF16, DV_BIAS, DV_F32, DV_NO_RELU_MASK, DV_RELU, DV_SIGMOID, DV_STATS, Act, cp8
 
 
-BN_REPLICAS = 32      # replicas of the BN-backward atomic accumulators (dv_bn_bwd_reduce)
+BN_REPLICAS = 8       # replicas of the BN-backward atomic accumulators (dv_bn_bwd_reduce)
 
 
 def _align8(n):
@@ -101,7 +101,6 @@ class ParamStore:
         return torch.as_strided(arena, s.shape, s.strides, s.off)
 
     def materialize(self, device, dtype):
-        L.require_device()
         off = 0
         wd_off = 0
         for s in self.slots:
@@ -231,10 +230,10 @@ class Comm:
 
 class Launch:
     """One kernel launch of a plan: a bound C-ABI call plus its algorithmic cost (for the roofline report)."""
-    __slots__ = ('name', 'kname', 'fn', 'args', 'bytes', 'flops')
+    __slots__ = ('name', 'kname', 'fn', 'args', 'bytes', 'flops', 'shape')
 
-    def __init__(self, name, kname, fn, args, nbytes=0, flops=0):
-        self.name, self.kname, self.fn, self.args, self.bytes, self.flops = name, kname, fn, args, nbytes, flops
+    def __init__(self, name, kname, fn, args, nbytes=0, flops=0, shape=''):
+        self.name, self.kname, self.fn, self.args, self.bytes, self.flops, self.shape = name, kname, fn, args, nbytes, flops, shape
 
     def __call__(self, stream):
         rc = self.fn(*self.args, stream)
@@ -416,21 +415,22 @@ class ConvOp(Op):
         wbytes = sl.Cout * taps * sl.Cin * es
         gv = 8 if (self.dtype == DV_BF16 and sl.cin_pitch % 8) else 16
         kf = 'conv_gemm<%s,FWD,%d,128,%d>' % (_dt(self.dtype), gv, _pick_bn(y.cpitch))
+        shp = 'M%d Cin%d Cout%d k%s s%s' % (y.rows, sl.Cin, sl.Cout, 'x'.join(map(str, self.k)), 'x'.join(map(str, self.s)))
         f = [Launch('conv_fwd', kf, lib.dv_conv3d_fwd,
                     (C.byref(self.d), x.ptr, st.w_fwd(sl), 0, y.ptr, self.stats.data_ptr() if self.stats is not None else 0),
-                    _abytes(x) + wbytes + _abytes(y), flops)]
+                    _abytes(x) + wbytes + _abytes(y), flops, shp)]
         b = []
         if p.with_grad:
             self.d_w = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=0)
             b.append(Launch('conv_wgrad', 'conv_wgrad<%s,%d,128,64>' % (_dt(self.dtype), gv), lib.dv_conv3d_wgrad,
                             (C.byref(self.d_w), x.ptr, y.grad.ptr, st.w_grad(sl)),
-                            _abytes(x) + _abytes(y) + sl.Cout * taps * sl.Cin * 4, flops))
+                            _abytes(x) + _abytes(y) + sl.Cout * taps * sl.Cin * 4, flops, shp))
             if self.need_dx:
                 acc = bool(self.acc.get('x'))
                 self.d_g = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=DV_ACCUM if acc else 0)
                 b.append(Launch('conv_dgrad', 'conv_gemm<%s,DGRAD,16,128,%d>' % (_dt(self.dtype), _pick_bn(x.cpitch)),
                                 lib.dv_conv3d_dgrad, (C.byref(self.d_g), y.grad.ptr, st.w_dgrad(sl), x.grad.ptr),
-                                _abytes(y) + wbytes + _abytes(x) * (2 if acc else 1), flops))
+                                _abytes(y) + wbytes + _abytes(x) * (2 if acc else 1), flops, shp))
         return f, b
 
 

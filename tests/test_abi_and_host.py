@@ -1,0 +1,148 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dualvar_hip.h declares (no compute calls),
+the ctypes table matches the header, and the host-side logic (parameter arenas, plan bookkeeping,
+fail-loudly behaviour, CLI) works without a GPU."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, 'include', 'dualvar_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\bint\s+(dv_\w+)\s*\((.*?)\)\s*;', src, flags=re.S):
+        args = [a.strip() for a in m.group(2).split(',') if a.strip() and a.strip() != 'void']
+        out[m.group(1)] = args
+    return out
+
+
+def test_library_exports_every_declared_symbol():
+    from dualvar_amd import _lib
+    lib = _lib.load()
+    decl = _header_functions()
+    assert len(decl) >= 35
+    for name, args in decl.items():
+        assert hasattr(lib, name), f'{name} declared in dualvar_hip.h but not exported'
+        assert name in _lib.SIGNATURES, f'{name} missing from the ctypes table'
+        assert len(_lib.SIGNATURES[name]) == len(args), (name, len(_lib.SIGNATURES[name]), args)
+    assert set(_lib.SIGNATURES) == set(decl)
+    assert lib.dv_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    """rejected arguments return DV_E* before anything is launched, so this is safe on a CPU-only host"""
+    from dualvar_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    assert lib.dv_conv3d_fwd(None, 0, 0, 0, 0, 0, 0) == -1
+    d.dtype = 7
+    assert lib.dv_conv3d_stat_tiles(None) == -1
+    assert lib.dv_bn_apply(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == -1
+    assert lib.dv_gemm_f32(0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1.0, 0, 0) == -1
+
+
+def test_product_fails_loudly_without_gpu():
+    from dualvar_amd import _lib
+    from dualvar_amd.backbone import select_backbone
+    from dualvar_amd import functional as DF
+    m, param = select_backbone('r3d')
+    assert param == {'feature_size': 512}
+    with pytest.raises(_lib.DualVarHipError):
+        m(torch.zeros(1, 3, 8, 32, 32))
+    with pytest.raises(_lib.DualVarHipError):
+        DF.l2_normalize(torch.zeros(2, 8))
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.DualVarHipError):
+            _lib.require_device()
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'dualvar_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), f
+    assert not re.search(r'^\s*(from|import)\s+oracle\b', open(os.path.join(ROOT, 'pretrain.py')).read(), flags=re.M)
+
+
+@pytest.mark.parametrize('net', ['s3dg', 'r21d', 'r50'])
+def test_state_dict_matches_oracle_names(net):
+    from dualvar_amd.backbone import select_backbone
+    from oracle import torch_ref as O
+    a, _ = select_backbone(net)
+    b, _ = O.select_backbone(net)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa.keys()) == list(sb.keys())
+    assert all(sa[k].shape == sb[k].shape for k in sa)
+
+
+def test_param_store_arena_views_cpu():
+    """nn.Parameters become strided views of one [Cout][taps][Cin_pad] arena; state_dict round-trips."""
+    from dualvar_amd import model as M
+    from dualvar_amd.ops import DV_F32
+    from oracle import procedural as P
+    m = M.SimCLR_TimeSeriesV4('r21d', 128, 0.07, False)
+    P.procedural_init(m)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    st = m.store
+    st.materialize(torch.device('cpu'), DV_F32)
+    assert st.ready(torch.device('cpu'), DV_F32)
+    after = m.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)
+    w = m.encoder_q[0].conv2.block1.conv1.spatial_conv.weight          # [144, 64, 1, 3, 3]
+    s = st.slot(w)
+    assert w.data_ptr() == st.master.data_ptr() + 4 * s.off and w.stride(1) == 1
+    packed = st.master[s.off:s.off + s.size].view(s.Cout, s.taps, s.cin_pitch)
+    assert torch.equal(packed[:, :, :s.Cin], w.detach().reshape(s.Cout, s.Cin, s.taps).permute(0, 2, 1))
+    # odd channel count (83) is zero padded to 88 in the consumer's weight rows
+    w2 = m.encoder_q[0].conv1.temporal_conv.weight                     # [64, 83, 3, 1, 1]
+    s2 = st.slot(w2)
+    assert s2.cin_pitch == 88 and float(st.master[s2.off:s2.off + s2.size].view(64, 3, 88)[:, :, 83:].abs().max()) == 0
+    # gradients are views of the twin arena; an in-place load keeps the aliasing
+    assert w.grad is not None and w.grad.data_ptr() == st.grad.data_ptr() + 4 * s.off
+    m.load_state_dict(before)
+    assert st.ready(torch.device('cpu'), DV_F32)
+    # S3D registers its stem twice: one slot per tensor
+    m2 = M.SimCLR_Naked('s3dg', 128, 0.07, False)
+    assert len(m2.store.slots) == len(list(m2.parameters())) == 307
+    assert sum(p.numel() for p in m2.parameters()) == 9098000 + 1024 * 1024 + 1024 + 128 * 1024 + 128
+
+
+def test_moco_query_and_key_arenas_have_identical_layout():
+    from dualvar_amd import model as M
+    from dualvar_amd.ops import DV_F32
+    m = M.MoCo_TimeSeriesV4('r3d', 128, 64, 0.999, 0.07, False)
+    m.store.materialize(torch.device('cpu'), DV_F32)
+    m.store_k.materialize(torch.device('cpu'), DV_F32)
+    assert m.store.total == m.store_k.total
+    assert [(a.off, a.size) for a in m.store.slots] == [(b.off, b.size) for b in m.store_k.slots]
+    assert torch.equal(m.store.master, m.store_k.master)               # key encoder starts as a copy
+    assert all(not p.requires_grad for p in m.encoder_k.parameters())
+
+
+def test_pretrain_cli_parses_reference_flags():
+    import pretrain
+    a = pretrain.parse_args(['--net', 's3dg', '--model', 'simclr_timeseriesv4', '--series_mode', 'clip-sr', '--moco-k', '16384',
+                             '--seq_len', '8', '--num_seq', '3', '--batch_size', '8', '--lr', '0.003', '--wd', '1e-4',
+                             '--local_rank', '0', '--schedule', '120', '160'])
+    assert a.mode == 'clip-sr' and a.moco_k == 16384 and a.n_proto == 1 and a.schedule == [120, 160]
+    a.distributed = False
+    m = pretrain.get_model(a)
+    assert type(m).__name__ == 'SimCLR_TimeSeriesV4' and not m.with_tc
+    ds = pretrain.SyntheticClips(a, 4)
+    assert ds[0]['seq'].shape == (3, 24, 112, 112)
+
+
+def test_bench_cli_and_bucket_ranges():
+    from dualvar_amd.parallel import bucket_ranges
+    r = bucket_ranges(100, 32)
+    assert r[0] == (68, 100) and r[-1] == (0, 4) and sum(b - a for a, b in r) == 100
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True)
+    assert out.returncode == 0 and '--gpus' in out.stdout and '--warmup' in out.stdout

@@ -1,0 +1,102 @@
+"""CPU: the oracle (oracle/torch_ref.py) reproduces the committed golden vectors, i.e. the outputs of the
+REFERENCE's own classes (oracle/gen_golden.py).  Where /root/reference is present (the build container) the
+oracle is additionally re-checked against a live import of the reference."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import CLIP, gold, grad_summary, param_checksum, total_loss
+
+
+def _build(kind, net, distributed=False):
+    from oracle import torch_ref as O
+    a = types.SimpleNamespace(shufflerank_theta=0.05)
+    if kind == 'simclr_naked':
+        return O.SimCLR_Naked(net, 128, 0.07, distributed)
+    if kind == 'simclr_timeseriesv4':
+        return O.SimCLR_TimeSeriesV4(net, 128, 0.07, distributed, args=a)
+    if kind == 'moco_naked':
+        return O.MoCo_Naked(net, 128, 64, 0.999, 0.07, distributed)
+    return O.MoCo_TimeSeriesV4(net, 128, 64, 0.999, 0.07, distributed, args=a)
+
+
+@pytest.mark.parametrize('net', ['s3dg', 'r21d', 'r3d', 'r50'])
+def test_backbone_fixture(net):
+    from oracle import procedural as P, torch_ref as O
+    g = gold('backbones')
+    m, _ = O.select_backbone(net)
+    P.procedural_init(m).train()
+    x = P.procedural_clips(4, 1, **CLIP)[:, 0]
+    with torch.no_grad():
+        y = m(x)
+    tol = max(2e-5, 3 * float(g[net + '/fp32_vs_fp64']))     # thread-count dependent summation order on other hosts
+    assert np.max(np.abs(y.numpy() - g[net + '/feat'])) <= tol * np.max(np.abs(g[net + '/feat']))
+
+
+@pytest.mark.parametrize('kind,net,B', [('simclr_naked', 'r3d', 2), ('simclr_timeseriesv4', 'r21d', 2),
+                                        ('simclr_naked', 's3dg', 4), ('moco_timeseriesv4', 's3dg', 4)])
+def test_model_first_step_fixture(kind, net, B):
+    """forward outputs, total loss and gradient checksums of step 0 (pretrain.py:394-449)."""
+    from oracle import procedural as P
+    g = gold(f'model_{kind}_{net}')
+    torch.manual_seed(0)
+    m = _build(kind, net)
+    P.procedural_init(m).train()
+    V = 2 if kind.endswith('naked') else 3
+    block = P.procedural_clips(B, V, **CLIP)
+    np.random.seed(1234)
+    ret = m(block)
+    loss = total_loss(ret)
+    loss.backward()
+    if V == 3:
+        np.random.seed(1234)
+        perm = np.array([np.random.permutation(2) for _ in range(B)])
+        assert np.array_equal(perm, g['first/perm'])
+    for k in g.files:
+        if k.startswith('first/out/'):
+            got = ret[k.split('/', 2)[2]].detach().numpy()
+            sens = float(g['sens/' + k]) if ('sens/' + k) in g.files else 0.0
+            assert np.max(np.abs(got - g[k])) <= max(1e-4, 5 * sens), k
+    assert abs(float(loss) - float(g['first/total_loss'])) < max(1e-4, 5 * float(g['sens/loss_step0']))
+    for k, v in grad_summary(m, P).items():
+        ref, sens = g[f'first/grad/{k}'], float(g[f'sens/first/grad/{k}'])
+        assert abs(v[0] - ref[0]) <= max(1e-3 * abs(ref[0]) + 1e-7, 5 * sens), k
+
+
+def test_loss_fixture_world1():
+    """loss-only fixtures from unit features (reference's calc_* functions), incl. gradients."""
+    from oracle import procedural as P, torch_ref as O
+    g = gold('losses')
+    m = O.SimCLR_TimeSeriesV4.__new__(O.SimCLR_TimeSeriesV4)
+    torch.nn.Module.__init__(m)
+    m.distributed, m.T, m.aligned_T, m.n_series, m.series_dim, m.dim = False, 0.07, 0.07, 2, 64, 128
+    m.args = types.SimpleNamespace(shufflerank_theta=0.05)
+    clip = P.procedural_unit_features(8, 2, 128, seed=11).requires_grad_(True)
+    ser = P.procedural_unit_features(8, 2, 2, 64, seed=13).requires_grad_(True)
+    rk = P.procedural_unit_features(8, 2, 2, 64, seed=17).requires_grad_(True)
+    r1, r2, r3 = m.calc_clip_contrast_loss(clip, 2), m.calc_tc_contrast_loss(ser), m.calc_ranking_loss(rk, 2, 'rank_', 0.5)
+    (r1['clip_contrast_loss'] + r2['tc_contrast_loss'] + r3['rank_margin_contrast_loss']).backward()
+    for r in (r1, r2, r3):
+        for k, v in r.items():
+            assert np.allclose(v.detach().numpy(), g[f'w1/r0/{k}'], atol=1e-5), k
+    for name, t in (('grad_clip', clip), ('grad_ser', ser), ('grad_rank', rk)):
+        assert np.allclose(t.grad.numpy(), g[f'w1/r0/{name}'], atol=1e-6), name
+
+
+def test_oracle_equals_live_reference():
+    from oracle import harness
+    if not harness.available():
+        pytest.skip('reference tree not present (GPU box)')
+    from oracle import procedural as P, torch_ref as O
+    ref = harness.load_reference()
+    for net in ('r3d', 'r21d'):
+        a, _ = ref.select_backbone(net)
+        b, _ = O.select_backbone(net)
+        assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+        P.procedural_init(a).train()
+        P.procedural_init(b).train()
+        x = P.procedural_clips(2, 1, 8, 64, 64)[:, 0]
+        with torch.no_grad():
+            assert torch.equal(a(x), b(x))
