@@ -473,7 +473,7 @@ class BNOp(Op):
                         (self.conv.stats.data_ptr(), self.conv.tiles, 128, M, Cn, self.local.data_ptr()),
                         self.conv.tiles * 2 * Cn * 4)]
             local, gathered, group = self.local, self.gathered, p.comm.group
-            f.append(HostStep('syncbn_allgather', lambda: dist.all_gather_into_tensor(gathered.view(-1), local, group=group)))
+            f.append(HostStep('syncbn_allgather', lambda: dist.all_gather(list(gathered.unbind(0)), local, group=group)))
             f.append(Launch('bn_finalize', 'bn_finalize', lib.dv_bn_finalize,
                             (self.gathered.data_ptr(), R, Cn, st.w_master(gs), st.w_master(bs), eps, mom, rm, rv,
                              self.mean.data_ptr(), self.invstd.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr())))

@@ -1,0 +1,108 @@
+"""GPU: the data-parallel path end to end with 2 ranks sharing the one GPU of the test box (gloo backend, so no
+RCCL "duplicate device" restriction; the collectives are the same torch.distributed calls RCCL serves on a node).
+
+Identity checked: with SyncBatchNorm statistics and the GatherLayer feature exchange, the
+clip loss on every rank equals the single-process loss on the concatenated batch, and the SUM over ranks of the
+parameter gradients equals the single-process gradient (DDP then averages it: GradSync + SGD grad_scale)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+NET, B, T, H = 'r3d', 4, 8, 64
+
+
+def _grads(model):
+    return {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def _run(model, block):
+    ret = model(block)
+    loss = ret['clip_contrast_loss']
+    for k in ret:
+        if 'loss' in k and 'clip' not in k:
+            loss = loss + ret[k]
+    for st in model.stores():
+        st.zero_grad()
+    loss.backward()
+    return {k: v.detach().float().cpu() for k, v in ret.items() if 'loss' in k or 'logits' in k}, _grads(model)
+
+
+def _worker(rank, world, port, kind, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from dualvar_amd import model as M
+        from dualvar_amd.parallel import GradSync
+        from oracle import procedural as P
+        dev = torch.device('cuda:0')
+        m = getattr(M, kind)(NET, 128, 0.07, True)
+        P.procedural_init(m)
+        m.set_compute_dtype('fp32').train().to(dev)
+        V = 2 if kind.endswith('Naked') else 3
+        full = P.procedural_clips(B, V, T, H, H)
+        n = B // world
+        np.random.seed(1234)
+        if V == 3:          # every rank draws the permutations of ITS samples: replay the single-process stream
+            perms = [np.random.permutation(2) for _ in range(B)]
+            np.random.seed(1234)
+            for _ in range(rank * n):
+                np.random.permutation(2)
+        outs, grads = _run(m, full[rank * n:(rank + 1) * n].to(dev))
+        sync = GradSync(side_stream=False)
+        scale = sync(m.store)
+        torch.cuda.synchronize()
+        synced = {k: (p.grad.detach().float().cpu() * scale).numpy() for k, p in m.named_parameters()}
+        q.put((rank, {k: v.numpy() for k, v in outs.items()}, {k: v.numpy() for k, v in grads.items()}, synced))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['SimCLR_Naked', 'SimCLR_TimeSeriesV4'])
+def test_two_ranks_equal_one_process(gpu, kind):
+    from dualvar_amd import model as M
+    from oracle import procedural as P
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29711 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = {}
+    for _ in range(2):
+        r, outs, grads, synced = q.get(timeout=600)
+        t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}    # noqa: E731
+        res[r] = (t(outs), t(grads), t(synced))
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+
+    m = getattr(M, kind)(NET, 128, 0.07, False)
+    P.procedural_init(m)
+    m.set_compute_dtype('fp32').train().to(gpu)
+    V = 2 if kind.endswith('Naked') else 3
+    np.random.seed(1234)
+    outs1, grads1 = _run(m, P.procedural_clips(B, V, T, H, H).to(gpu))
+
+    for r in range(2):
+        assert torch.allclose(res[r][0]['clip_logits'], outs1['clip_logits'], atol=2e-4)
+        assert abs(float(res[r][0]['clip_contrast_loss']) - float(outs1['clip_contrast_loss'])) < 1e-5
+    if V == 3:      # tc rows are per-rank: the mean over ranks is the single-process loss
+        tc = np.mean([float(res[r][0]['tc_contrast_loss']) for r in range(2)])
+        assert abs(tc - float(outs1['tc_contrast_loss'])) < 1e-5
+    if kind == 'SimCLR_Naked':
+        worst = 0.0
+        for k, g1 in grads1.items():
+            gsum = res[0][1][k] + res[1][1][k]
+            worst = max(worst, float((gsum - g1).abs().max() / (g1.abs().max() + 1e-12)))
+            # after GradSync every rank holds the same averaged gradient = single-process gradient / world
+            assert torch.allclose(res[0][2][k], res[1][2][k])
+            assert torch.allclose(res[0][2][k], gsum / 2, rtol=1e-5, atol=1e-8)
+        print('sum-over-ranks param grad vs single process: worst rel err', worst)
+        assert worst < 2e-3
