@@ -34,6 +34,13 @@ class PackDesc(C.Structure):
                 ('taps', C.c_int32), ('cin_pitch', C.c_int32), ('cout_pitch', C.c_int32), ('_pad', C.c_int32)]
 
 
+class GemmDesc(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('bias', C.c_void_p),
+                ('sam', C.c_int64), ('sak', C.c_int64), ('sbk', C.c_int64), ('sbn', C.c_int64), ('ldc', C.c_int64),
+                ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('flags', C.c_int32), ('tile_end', C.c_int32),
+                ('alpha', C.c_float)]
+
+
 P, I32, I64, F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 CD, PD = C.POINTER(ConvDesc), C.POINTER(PoolDesc)
 
@@ -49,18 +56,18 @@ SIGNATURES = {
     'dv_cast_arena': [I32, P, P, I64, P],
     'dv_ingest_ncdhw': [I32, P, P, I32, I32, I32, I32, I32, I64, I32, P, P, P, I32, P],
     'dv_bn_reduce_stats': [P, I32, I32, I64, I32, P, P],
-    'dv_bn_finalize': [P, I32, I32, P, P, F, F, P, P, P, P, P, P, P],
+    'dv_bn_finalize': [P, I32, I32, I32, P, P, F, F, P, P, P, P, P, P, P],
     'dv_bn_stats_finalize': [P, I32, I32, I64, I32, P, P, P, F, F, P, P, P, P, P, P, P],
     'dv_bn_apply': [I32, P, I32, P, P, P, I32, P, I32, I64, I32, I32, P],
     'dv_bn_bwd_blocks': [I64, I32],
     'dv_bn_bwd_reduce': [I32, P, I32, P, I32, P, I32, P, P, I64, I32, I32, P, I32, P],
-    'dv_bn_bwd_apply': [I32, P, I32, P, I32, P, I32, P, P, P, P, I32, P, I32, F, P, P, P, I32, P, I32, I64, I32, I32, P],
+    'dv_bn_bwd_apply': [I32, P, I32, P, I32, P, I32, P, P, P, P, I32, F, F, P, P, P, I32, P, I32, I64, I32, I32, P],
     'dv_maxpool3d_fwd': [PD, P, P, P, P],
     'dv_maxpool3d_bwd': [PD, P, P, P, I32, P],
     'dv_spatial_mean': [I32, P, I32, I32, I32, I32, P, P],
     'dv_spatial_mean_bwd': [I32, P, I32, I32, I32, P, I32, I32, P],
     'dv_gate_scale': [I32, P, I32, P, I32, I32, I32, P, I32, P],
-    'dv_gate_bwd_reduce': [I32, P, I32, P, I32, P, I32, I32, I32, P, P],
+    'dv_gate_bwd_reduce': [I32, P, I32, P, I32, P, I32, I32, I32, P, I32, P],
     'dv_gate_bwd_apply': [I32, P, I32, P, P, I32, I32, I32, P, I32, I32, P],
     'dv_colsum_f32': [P, I32, I32, I32, P, P],
     'dv_l2norm_fwd': [P, I32, I32, F, P, P, P],
@@ -71,6 +78,7 @@ SIGNATURES = {
     'dv_infonce_fwd': [P, P, P, I32, I32, I32, F, P, P, P, P, P, P],
     'dv_rank_margin': [P, I32, I32, I32, F, F, F, P, P, P, P, P],
     'dv_gemm_f32': [I32, I32, I32, P, I64, I64, P, I64, I64, P, I64, F, I32, P],
+    'dv_gemm_f32_grouped': [P, I32, I32, P],
     'dv_group_mean_f32': [P, I32, I32, I32, P, P],
     'dv_group_mean_bwd_f32': [P, I32, I32, I32, P, P],
     'dv_sgd_momentum': [P, P, P, I64, F, F, F, F, I32, P, P],

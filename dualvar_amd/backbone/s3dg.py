@@ -6,7 +6,7 @@ The network itself is `emit()`: per SepInception, the four branches write their 
 channel slices of one NDHWC buffer (no torch.cat), self-gating scales while writing the slice."""
 import torch.nn as nn
 
-from .base import HipBackbone, emit_conv_bn, register_conv_bn
+from .base import HipBackbone, conv_geometry, emit_conv_bn, register_conv_bn
 
 
 def _holder_init(conv, bn):
@@ -89,36 +89,44 @@ class SepInception(nn.Module):
         return (self.gating_b0, self.gating_b1, self.gating_b2, self.gating_b3) if self.gating else (None,) * 4
 
     def register(self, store):
-        gates = self._gates()
         self.branch0[0].register(store)
-        if gates[0]: gates[0].register(store)
         self.branch1[0].register(store); self.branch1[1].register(store)
-        if gates[1]: gates[1].register(store)
         self.branch2[0].register(store); self.branch2[1].register(store)
-        if gates[2]: gates[2].register(store)
         self.branch3[1].register(store)
-        if gates[3]: gates[3].register(store)
+        if self.gating:
+            # the four FC weights, then the four biases back to back: the bias gradient of the whole block is then one
+            # column sum over [N, C_total] (the widths are multiples of 8, so slot offsets equal the concat offsets)
+            for g in self._gates():
+                store.add_conv(g.fc.weight, need_dgrad=False)
+            for g in self._gates():
+                store.add_vec(g.fc.bias)
 
     def emit(self, plan, x):
+        """Level by level rather than branch by branch, so that the BatchNorms of one level share a single
+        SyncBN statistics exchange: {b0, b1.0, b2.0, b3.1}, {b1.1.bn1, b2.1.bn1}, {b1.1.bn2, b2.1.bn2}."""
         cat = plan.act(x.N, x.T, x.H, x.W, self.out_channels)
-        gates = self._gates()
-        off = 0
-        for i, width in enumerate(self.widths):
-            dst = plan.slice(cat, off, width)
-            off += width
-            direct = dst if gates[i] is None else None      # without gating the last BN writes the slice itself
-            if i == 0:
-                y = self.branch0[0].emit(plan, x, out=direct)
-            elif i == 1:
-                y = self.branch1[1].emit(plan, self.branch1[0].emit(plan, x), out=direct)
-            elif i == 2:
-                y = self.branch2[1].emit(plan, self.branch2[0].emit(plan, x), out=direct)
-            else:
-                mp = self.branch3[0]
-                k, s, p = (mp.kernel_size,) * 3, (mp.stride,) * 3, (mp.padding,) * 3
-                y = self.branch3[1].emit(plan, plan.maxpool(x, k, s, p), out=direct)
-            if gates[i] is not None:
-                plan.gate(gates[i].fc, y, dst)
+        offs = [0]
+        for w in self.widths:
+            offs.append(offs[-1] + w)
+        dst = [plan.slice(cat, offs[i], self.widths[i]) for i in range(4)]
+        slot = plan.store.slot
+
+        def conv(c, inp):
+            return plan.conv(slot(c.weight), inp, *conv_geometry(c))
+
+        b0, b1a, b2a, b3 = self.branch0[0], self.branch1[0], self.branch2[0], self.branch3[1]
+        st1, st2 = self.branch1[1], self.branch2[1]
+        mp = self.branch3[0]
+        px = plan.maxpool(x, (mp.kernel_size,) * 3, (mp.stride,) * 3, (mp.padding,) * 3)
+        r0, r1, r2, r3 = conv(b0.conv, x), conv(b1a.conv, x), conv(b2a.conv, x), conv(b3.conv, px)
+        _, y1, y2, _ = plan.bn_group([(b0.bn, r0, True, None, dst[0]), (b1a.bn, r1, True, None, None),
+                                      (b2a.bn, r2, True, None, None), (b3.bn, r3, True, None, dst[3])])
+        y1, y2 = plan.bn_group([(st1.bn1, conv(st1.conv1, y1), True, None, None),
+                                (st2.bn1, conv(st2.conv1, y2), True, None, None)])
+        plan.bn_group([(st1.bn2, conv(st1.conv2, y1), True, None, dst[1]),
+                       (st2.bn2, conv(st2.conv2, y2), True, None, dst[2])])
+        if self.gating:
+            plan.gate_group([(g.fc, offs[i], self.widths[i]) for i, g in enumerate(self._gates())], cat)
         return cat
 
 

@@ -104,13 +104,12 @@ __global__ void bn_reduce_stats_kernel(const float* __restrict__ part, int n_til
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int R, int C, const float* gamma,
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int R, int stride, int C, const float* gamma,
                                    const float* beta, float eps, float momentum, float* running_mean,
                                    float* running_var, float* mean_o, float* invstd_o, float* scale_o,
                                    float* shift_o) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const int stride = 2 * C + 1;
   float cnt = 0.f, S = 0.f;
   for (int r = 0; r < R; ++r) { cnt += stats[r * stride + 2 * C]; S += stats[r * stride + c]; }
   const float mean = S / cnt;
@@ -287,8 +286,8 @@ template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
                                     const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ sums_g, int rep_g, const float* __restrict__ sums_l,
-                                    int rep_l, float inv_count, float* dgamma, float* dbeta, T* __restrict__ dx, int lddx,
+                                    const float* __restrict__ sums_g, int rep_g, float inv_count, float dscale,
+                                    float* dgamma, float* dbeta, T* __restrict__ dx, int lddx,
                                     T* __restrict__ dres, int lddres, uint32_t total, int C, int CP, FastDiv fcv,
                                     int flags) {
   constexpr int V = DT<T>::VEC;
@@ -296,9 +295,9 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T*
   if (blockIdx.x == 0 && dgamma) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float sb = 0.f, sg = 0.f;
-      for (int r = 0; r < rep_l; ++r) { sb += sums_l[(size_t)r * 2 * CP + c]; sg += sums_l[(size_t)r * 2 * CP + CP + c]; }
-      dbeta[c] += sb;
-      dgamma[c] += sg;
+      for (int r = 0; r < rep_g; ++r) { sb += sums_g[(size_t)r * 2 * CP + c]; sg += sums_g[(size_t)r * 2 * CP + CP + c]; }
+      dbeta[c] += dscale * sb;
+      dgamma[c] += dscale * sg;
     }
   }
   for (int c = threadIdx.x; c < CP; c += blockDim.x) {
@@ -458,7 +457,8 @@ __global__ void spatial_mean_kernel(const T* __restrict__ x, int ldx, int S, int
 
 template <typename T>
 __global__ void gate_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
-                                       const float* __restrict__ g, int S, int C, int CP, float* __restrict__ dpre) {
+                                       const float* __restrict__ g, int S, int C, int CP, float* __restrict__ dpre,
+                                       int x_is_output) {
   constexpr int V = DT<T>::VEC;
   const int n = blockIdx.x;
   column_reduce<V, 1>(
@@ -475,7 +475,7 @@ __global__ void gate_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const
         for (int e = 0; e < V; ++e)
           if (c0 + e < C) {
             float gg = g[(size_t)n * C + c0 + e];
-            dpre[(size_t)n * C + c0 + e] = acc[0][e] * gg * (1.f - gg);
+            dpre[(size_t)n * C + c0 + e] = x_is_output ? acc[0][e] * (1.f - gg) : acc[0][e] * gg * (1.f - gg);
           }
       });
 }
@@ -665,12 +665,12 @@ extern "C" int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int3
   return dv_launch_status();
 }
 
-extern "C" int dv_bn_finalize(const float* stats, int32_t R, int32_t C, const float* gamma, const float* beta, float eps,
+extern "C" int dv_bn_finalize(const float* stats, int32_t R, int32_t stride, int32_t C, const float* gamma, const float* beta, float eps,
                               float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
                               float* scale, float* shift, void* stream) {
-  if (!stats || R <= 0 || C <= 0 || !gamma || !beta || !mean || !invstd || !scale || !shift) return DV_EINVAL;
+  if (!stats || R <= 0 || C <= 0 || stride < 2 * C + 1 || !gamma || !beta || !mean || !invstd || !scale || !shift) return DV_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return DV_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), stats, R, C, gamma, beta, eps,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), stats, R, stride, C, gamma, beta, eps,
                      momentum, running_mean, running_var, mean, invstd, scale, shift);
   return dv_launch_status();
 }
@@ -723,13 +723,13 @@ extern "C" int dv_bn_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, con
 
 extern "C" int dv_bn_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                                int32_t ldx, const float* mean, const float* invstd, const float* gamma,
-                               const float* sums_global, int32_t rep_global, const float* sums_local, int32_t rep_local,
-                               float inv_count, float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres,
+                               const float* sums_global, int32_t rep_global, float inv_count, float dparam_scale,
+                               float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres,
                                int32_t lddres, int64_t M, int32_t C, int32_t flags, void* stream) {
   const int CP = cp8(C);
   const bool mask = !(flags & DV_NO_RELU_MASK);
   if (!dy || !x || (mask && !y) || !mean || !invstd || !gamma || !sums_global || !dx || M <= 0 || C <= 0) return DV_EINVAL;
-  if ((dgamma == nullptr) != (dbeta == nullptr) || (dgamma && (!sums_local || rep_local <= 0)) || rep_global <= 0) return DV_EINVAL;
+  if ((dgamma == nullptr) != (dbeta == nullptr) || rep_global <= 0) return DV_EINVAL;
   if (lddy < CP || ldx < CP || lddx < CP || (mask && ldy < CP) || (dres && lddres < CP)) return DV_EINVAL;
   if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || (mask && !aligned16(y)) || (dres && !aligned16(dres))) return DV_EALIGN;
   if (3 * CP * 4 > 60 * 1024) return DV_EUNSUPPORTED;
@@ -741,7 +741,7 @@ extern "C" int dv_bn_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, cons
     int grid = grid_for(total, 2048);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid), dim3(kThreads), 3 * CP * sizeof(float), ST(stream),
                        (const T*)dy, lddy, (const T*)y, ldy, (const T*)x, ldx, mean, invstd, gamma, sums_global,
-                       rep_global, sums_local, rep_local, inv_count, dgamma, dbeta, (T*)dx, lddx, (T*)dres, lddres, (uint32_t)total, C, CP,
+                       rep_global, inv_count, dparam_scale, dgamma, dbeta, (T*)dx, lddx, (T*)dres, lddres, (uint32_t)total, C, CP,
                        make_fastdiv((uint32_t)(CP / V)), flags);
   });
   return dv_launch_status();
@@ -845,14 +845,14 @@ extern "C" int dv_gate_scale(int32_t dtype, const void* x, int32_t ldx, const fl
 }
 
 extern "C" int dv_gate_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* x, int32_t ldx, const float* g,
-                                  int32_t N, int32_t S, int32_t C, float* dpre, void* stream) {
+                                  int32_t N, int32_t S, int32_t C, float* dpre, int32_t x_is_output, void* stream) {
   const int CP = cp8(C);
   if (!dy || !x || !g || !dpre || N <= 0 || S <= 0 || C <= 0 || lddy < CP || ldx < CP) return DV_EINVAL;
   if (!aligned16(dy) || !aligned16(x)) return DV_EALIGN;
   DISPATCH_T(dtype, {
     if (lddy % DT<T>::VEC || ldx % DT<T>::VEC) return DV_EALIGN;
     hipLaunchKernelGGL((gate_bwd_reduce_kernel<T>), dim3(N), dim3(kThreads), 0, ST(stream), (const T*)dy, lddy,
-                       (const T*)x, ldx, g, S, C, CP, dpre);
+                       (const T*)x, ldx, g, S, C, CP, dpre, x_is_output);
   });
   return dv_launch_status();
 }

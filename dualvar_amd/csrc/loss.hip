@@ -56,6 +56,60 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
   }
 }
 
+// Several independent small GEMMs in one launch (the four self-gating FCs of an Inception block and their
+// backward products).  Descriptors live in device memory and are static per plan.
+__global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const dv_gemm_desc* __restrict__ descs, int n_groups) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int tile = blockIdx.x * 4 + wave;
+  int gi = 0;
+  while (gi < n_groups && tile >= descs[gi].tile_end) ++gi;
+  if (gi >= n_groups) return;
+  const dv_gemm_desc d = descs[gi];
+  tile -= (gi == 0 ? 0 : descs[gi - 1].tile_end);
+  const int tiles_n = (d.N + 31) / 32;
+  const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int m = m0 + l31, n = n0 + l31;
+  const float* ap = d.A + (int64_t)m * d.sam;
+  const float* bp = d.B + (int64_t)n * d.sbn;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  int k = 0;
+  for (; k + 16 <= d.K; k += 16) {
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = k + 2 * u + h;
+      a[u] = (m < d.M) ? ap[(int64_t)kk * d.sak] : 0.f;
+      b[u] = (n < d.N) ? bp[(int64_t)kk * d.sbk] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; k < d.K; k += 2) {
+    const int kk = k + h;
+    float a = (m < d.M && kk < d.K) ? ap[(int64_t)kk * d.sak] : 0.f;
+    float b = (n < d.N && kk < d.K) ? bp[(int64_t)kk * d.sbk] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  if (n < d.N) {
+    const float bv = d.bias ? d.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < d.M) {
+        float* p = d.C + (int64_t)row * d.ldc + n;
+        float v = d.alpha * acc[r] + bv;
+        if (d.flags & DV_ACCUM) v += *p;
+        if (d.flags & DV_SIGMOID) v = 1.f / (1.f + __expf(-v));
+        if (d.flags & DV_RELU) v = fmaxf(v, 0.f);
+        *p = v;
+      }
+    }
+  }
+}
+
 static int launch_gemm_f32(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
                            int64_t sbn, float* C, int64_t ldc, float alpha, int accumulate, hipStream_t s) {
   const int tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32;
@@ -259,6 +313,12 @@ extern "C" int dv_gemm_f32(int32_t M, int32_t N, int32_t K, const float* A, int6
                            void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return DV_EINVAL;
   return launch_gemm_f32(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, alpha, accumulate, ST(stream));
+}
+
+extern "C" int dv_gemm_f32_grouped(const dv_gemm_desc* descs_dev, int32_t n_groups, int32_t total_tiles, void* stream) {
+  if (!descs_dev || n_groups <= 0 || total_tiles <= 0) return DV_EINVAL;
+  hipLaunchKernelGGL(gemm_f32_grouped_kernel, dim3((total_tiles + 3) / 4), dim3(256), 0, ST(stream), descs_dev, n_groups);
+  return dv_launch_status();
 }
 
 extern "C" int dv_ntxent_fwd(const float* rows, const float* cols, int32_t R, int32_t n_local, int32_t N, int32_t D,

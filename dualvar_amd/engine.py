@@ -318,14 +318,22 @@ class Plan:
         op.y.producer = op
         return op.y
 
+    def bn_group(self, specs):
+        """specs: [(bn_module, raw_conv_output, relu, residual_or_None, out_or_None), ...] of mutually independent
+        layers -> their outputs.  One statistics exchange for the whole group."""
+        op = self._push(BNGroupOp(self, specs))
+        return [m.y for m in op.members]
+
     def bn(self, bn_mod, x, relu=True, residual=None, out=None):
-        return self._push(BNOp(self, bn_mod, x, relu, residual, out, x.producer)).y
+        return self.bn_group([(bn_mod, x, relu, residual, out)])[0]
 
     def maxpool(self, x, k, s, p):
         return self._push(PoolOp(self, x, k, s, p)).y
 
-    def gate(self, fc, x, out):
-        return self._push(GateOp(self, fc, x, out)).y
+    def gate_group(self, fcs, cat):
+        """in-place self gating of a concat buffer: fcs = [(nn.Linear, channel offset, width), ...]"""
+        self._push(GateGroupOp(self, fcs, cat))
+        return cat
 
     def spatial_mean(self, x):
         return self._push(MeanOp(self, x)).out
@@ -434,82 +442,102 @@ class ConvOp(Op):
         return f, b
 
 
-class BNOp(Op):
-    """training-mode BatchNorm (+residual) (+ReLU); cross-rank statistics when world > 1."""
+class BNMember:
+    """one BatchNorm of a BNGroupOp (state only; the group emits the launches)"""
 
-    def __init__(self, plan, bn, x, relu, residual, out, conv):
-        super().__init__(plan)
-        self.bn, self.x, self.relu, self.res, self.conv = bn, x, relu, residual, conv
+    def __init__(self, plan, bn, x, relu, residual, out):
+        self.bn, self.x, self.relu, self.res, self.conv = bn, x, relu, residual, x.producer
         self.C, self.M = x.C, x.rows
+        self.CP = cp8(self.C)
         self.y = out if out is not None else plan.act(x.N, x.T, x.H, x.W, x.C)
-        Cn, R = self.C, plan.comm.world
-        self.CP = cp8(Cn)
-        self.local = plan.f32(2 * Cn + 1)
-        self.gathered = plan.f32(R, 2 * Cn + 1) if R > 1 else self.local
         # per-channel arrays are read with 16-byte loads: padded to CP
         self.mean, self.invstd, self.scale, self.shift = (plan.f32(self.CP) for _ in range(4))
-        if plan.with_grad:
-            self.sums_off = plan.reserve_zero(BN_REPLICAS * 2 * self.CP)
-            self.sums_g = plan.f32(2, self.CP) if R > 1 else None
+        self.width = 2 * self.C + 1
+        self.sums_off = plan.reserve_zero(BN_REPLICAS * 2 * self.CP) if plan.with_grad else 0
+        self.sums_len = BN_REPLICAS * 2 * self.CP
+
+
+class BNGroupOp(Op):
+    """Training-mode BatchNorm (+residual) (+ReLU) for one or several independent layers.
+
+    With world > 1 the members' statistics travel in ONE all-gather forward and ONE all-reduce backward
+    (SyncBatchNorm, torch/nn/modules/_functions.py:39-200): the four branch-entry BNs of an Inception block cost
+    one small collective instead of four."""
+
+    def __init__(self, plan, specs):
+        super().__init__(plan)
+        self.members = [BNMember(plan, *sp) for sp in specs]
+        R = plan.comm.world
+        self.width = sum(m.width for m in self.members)
+        self.local = plan.f32(self.width)
+        self.gathered = plan.f32(R, self.width) if R > 1 else self.local
+        off = 0
+        for m in self.members:
+            m.loff = off
+            off += m.width
 
     def grad_targets(self):
-        return [('res', self.res)] if (self.res is not None and self.res.grad is not None and self.plan.with_grad) else []
+        if not self.plan.with_grad:
+            return []
+        return [('res%d' % i, m.res) for i, m in enumerate(self.members) if m.res is not None and m.res.grad is not None]
 
     def launches(self):
-        p, st, lib, bn, x, y, res = self.plan, self.plan.store, self.plan.lib, self.bn, self.x, self.y, self.res
-        Cn, M, R = self.C, self.M, p.comm.world
-        gs, bs = st.slot(bn.weight), st.slot(bn.bias)
-        rm = bn.running_mean.data_ptr() if bn.running_mean is not None else 0
-        rv = bn.running_var.data_ptr() if bn.running_var is not None else 0
-        eps, mom = float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1)
-        dt = _dt(p.dtype)
-        if R == 1:
-            f = [Launch('bn_stats_finalize', 'bn_reduce_stats', lib.dv_bn_stats_finalize,
-                        (self.conv.stats.data_ptr(), self.conv.tiles, 128, M, Cn, self.local.data_ptr(), st.w_master(gs),
-                         st.w_master(bs), eps, mom, rm, rv, self.mean.data_ptr(), self.invstd.data_ptr(),
-                         self.scale.data_ptr(), self.shift.data_ptr()), self.conv.tiles * 2 * Cn * 4)]
-        else:
-            f = [Launch('bn_reduce_stats', 'bn_reduce_stats', lib.dv_bn_reduce_stats,
-                        (self.conv.stats.data_ptr(), self.conv.tiles, 128, M, Cn, self.local.data_ptr()),
-                        self.conv.tiles * 2 * Cn * 4)]
+        p, st, lib = self.plan, self.plan.store, self.plan.lib
+        R, dt = p.comm.world, _dt(p.dtype)
+        f_red, f_fin, f_app, b_red, b_app = [], [], [], [], []
+        for i, m in enumerate(self.members):
+            bn, x, y, res, Cn, M = m.bn, m.x, m.y, m.res, m.C, m.M
+            gs, bs = st.slot(bn.weight), st.slot(bn.bias)
+            rm = bn.running_mean.data_ptr() if bn.running_mean is not None else 0
+            rv = bn.running_var.data_ptr() if bn.running_var is not None else 0
+            eps, mom = float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1)
+            local = self.local.data_ptr() + 4 * m.loff
+            outs = (m.mean.data_ptr(), m.invstd.data_ptr(), m.scale.data_ptr(), m.shift.data_ptr())
+            if R == 1:
+                f_red.append(Launch('bn_stats_finalize', 'bn_reduce_stats', lib.dv_bn_stats_finalize,
+                                    (m.conv.stats.data_ptr(), m.conv.tiles, 128, M, Cn, local, st.w_master(gs), st.w_master(bs),
+                                     eps, mom, rm, rv) + outs, m.conv.tiles * 2 * Cn * 4))
+            else:
+                f_red.append(Launch('bn_reduce_stats', 'bn_reduce_stats', lib.dv_bn_reduce_stats,
+                                    (m.conv.stats.data_ptr(), m.conv.tiles, 128, M, Cn, local), m.conv.tiles * 2 * Cn * 4))
+                f_fin.append(Launch('bn_finalize', 'bn_finalize', lib.dv_bn_finalize,
+                                    (self.gathered.data_ptr() + 4 * m.loff, R, self.width, Cn, st.w_master(gs), st.w_master(bs),
+                                     eps, mom, rm, rv) + outs))
+            f_app.append(Launch('bn_apply', 'bn_apply<%s>' % dt, lib.dv_bn_apply,
+                                (p.dtype, x.ptr, x.ld, m.scale.data_ptr(), m.shift.data_ptr(),
+                                 res.ptr if res is not None else 0, res.ld if res is not None else 0, y.ptr, y.ld, M, Cn,
+                                 DV_RELU if m.relu else 0), _abytes(x) * (3 if res is not None else 2)))
+            if p.with_grad:
+                dy = y.grad
+                mflag = 0 if m.relu else DV_NO_RELU_MASK
+                nact = 3 if m.relu else 2
+                sums = p.zero_ptr(m.sums_off)
+                b_red.append(Launch('bn_bwd_reduce', 'bn_bwd_reduce<%s>' % dt, lib.dv_bn_bwd_reduce,
+                                    (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, m.mean.data_ptr(), m.invstd.data_ptr(),
+                                     M, Cn, mflag, sums, BN_REPLICAS), _abytes(x) * nact))
+                dres = res.grad if (res is not None and res.grad is not None) else None
+                bflags = mflag | (DV_ACCUM if (dres is not None and self.acc.get('res%d' % i)) else 0)
+                nres = 0 if dres is None else (2 if bflags & DV_ACCUM else 1)
+                b_app.append(Launch('bn_bwd_apply', 'bn_bwd_apply<%s>' % dt, lib.dv_bn_bwd_apply,
+                                    (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, m.mean.data_ptr(), m.invstd.data_ptr(),
+                                     st.w_master(gs), sums, BN_REPLICAS, 1.0 / (M * R), 1.0 / R, st.w_grad(gs), st.w_grad(bs),
+                                     x.grad.ptr, x.grad.ld, dres.ptr if dres is not None else 0,
+                                     dres.ld if dres is not None else 0, M, Cn, bflags), _abytes(x) * (nact + 1 + nres)))
+        f = list(f_red)
+        b = list(b_red)
+        if R > 1:
             local, gathered, group = self.local, self.gathered, p.comm.group
             f.append(HostStep('syncbn_allgather', lambda: dist.all_gather(list(gathered.unbind(0)), local, group=group)))
-            f.append(Launch('bn_finalize', 'bn_finalize', lib.dv_bn_finalize,
-                            (self.gathered.data_ptr(), R, Cn, st.w_master(gs), st.w_master(bs), eps, mom, rm, rv,
-                             self.mean.data_ptr(), self.invstd.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr())))
-        f.append(Launch('bn_apply', 'bn_apply<%s>' % dt, lib.dv_bn_apply,
-                        (p.dtype, x.ptr, x.ld, self.scale.data_ptr(), self.shift.data_ptr(),
-                         res.ptr if res is not None else 0, res.ld if res is not None else 0, y.ptr, y.ld, M, Cn,
-                         DV_RELU if self.relu else 0),
-                        _abytes(x) * (3 if res is not None else 2)))
-        b = []
-        if p.with_grad:
-            dy = y.grad
-            mflag = 0 if self.relu else DV_NO_RELU_MASK
-            nact = 3 if self.relu else 2
-            sums = p.zero_ptr(self.sums_off)
-            b.append(Launch('bn_bwd_reduce', 'bn_bwd_reduce<%s>' % dt, lib.dv_bn_bwd_reduce,
-                            (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, self.mean.data_ptr(), self.invstd.data_ptr(),
-                             M, Cn, mflag, sums, BN_REPLICAS), _abytes(x) * nact))
-            sums_gp, rep_g = sums, BN_REPLICAS
-            if R > 1:
-                sums_g, group = self.sums_g, p.comm.group
-                src = p.zero_arena.narrow(0, self.sums_off, BN_REPLICAS * 2 * self.CP).view(BN_REPLICAS, 2, self.CP)
+            f += f_fin
+            if p.with_grad:
+                first, last = self.members[0], self.members[-1]
+                lo, n = first.sums_off, last.sums_off + last.sums_len - first.sums_off
 
-                def _allreduce():
-                    torch.sum(src, dim=0, out=sums_g)
-                    dist.all_reduce(sums_g, group=group)
+                def _allreduce():           # in place on the (contiguous) replica accumulators of the group
+                    dist.all_reduce(p.zero_arena.narrow(0, lo, n), group=group)
                 b.append(HostStep('syncbn_allreduce', _allreduce))
-                sums_gp, rep_g = sums_g.data_ptr(), 1
-            dres = res.grad if (res is not None and res.grad is not None) else None
-            bflags = mflag | (DV_ACCUM if (dres is not None and self.acc.get('res')) else 0)
-            nres = 0 if dres is None else (2 if bflags & DV_ACCUM else 1)
-            b.append(Launch('bn_bwd_apply', 'bn_bwd_apply<%s>' % dt, lib.dv_bn_bwd_apply,
-                            (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, self.mean.data_ptr(), self.invstd.data_ptr(),
-                             st.w_master(gs), sums_gp, rep_g, sums, BN_REPLICAS, 1.0 / (M * R),
-                             st.w_grad(gs), st.w_grad(bs), x.grad.ptr, x.grad.ld,
-                             dres.ptr if dres is not None else 0, dres.ld if dres is not None else 0, M, Cn, bflags),
-                            _abytes(x) * (nact + 1 + nres)))
+        f += f_app
+        b += b_app
         return f, b
 
 
@@ -541,49 +569,73 @@ class PoolOp(Op):
         return f, b
 
 
-class GateOp(Op):
-    """S3D-G self gating: out = x * sigmoid(fc(mean_thw x)), written into a concat slice."""
+class GateGroupOp(Op):
+    """S3D-G self gating of a whole Inception output, in place on the concat buffer (s3dg.py:68-78,112-128):
+        cat[n,s,c] *= sigmoid(fc_i(mean_s cat[n,:,slice_i]))[c]
+    Three launches forward (mean, the four FCs as ONE grouped fp32 MFMA GEMM with bias+sigmoid epilogue, scale) and
+    four backward.  The un-gated activations are not kept: the gate is positive, so the ReLU mask of the producing
+    BatchNorm is unchanged, and sum_s dy*y = (sum_s dy*out)/g."""
 
-    def __init__(self, plan, fc, x, out):
+    def __init__(self, plan, fcs, cat):
         super().__init__(plan)
-        self.fc, self.x, self.y = fc, x, out
-        N, Cn = x.N, x.C
-        self.mean = plan.f32(N, Cn)
-        self.g = plan.f32(N, Cn)
-        a_mean = Act(self.mean, N, 1, 1, 1, Cn, Cn, 0, DV_F32, Cn)
-        a_g = Act(self.g, N, 1, 1, 1, Cn, Cn, 0, DV_F32, Cn)
-        # fc as a 1x1x1 fp32 conv over [N,1,1,1,C] with bias + sigmoid epilogue
-        self.d = ops.conv_desc(DV_F32, a_mean, a_g, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=DV_BIAS | DV_SIGMOID)
+        self.fcs, self.cat = fcs, cat
+        N, Ct = cat.N, cat.C
+        assert sum(w for _, _, w in fcs) == Ct and all(o % 8 == 0 and w % 8 == 0 for _, o, w in fcs)
+        self.mean, self.g = plan.f32(N, Ct), plan.f32(N, Ct)
         if plan.with_grad:
-            self.dpre = plan.f32(N, Cn)
-            self.dmean = plan.f32(N, Cn)
+            self.dpre, self.dmean = plan.f32(N, Ct), plan.f32(N, Ct)
+
+    def _table(self, descs):
+        arr = (L.GemmDesc * len(descs))()
+        tiles = 0
+        for i, d in enumerate(descs):
+            for k, v in d.items():
+                setattr(arr[i], k, v)
+            tiles += ((d['M'] + 31) // 32) * ((d['N'] + 31) // 32)
+            arr[i].tile_end = tiles
+        dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.plan.device)
+        self.plan.bytes += dev.numel()
+        return dev, tiles
 
     def launches(self):
-        p, st, lib, x, y = self.plan, self.plan.store, self.plan.lib, self.x, self.y
-        ws, bs = st.slot(self.fc.weight), st.slot(self.fc.bias)
-        assert ws.cin_pitch == x.C, 'gating widths are multiples of 8 in S3D-G'
-        N, Cn, S, dt = x.N, x.C, x.S, _dt(p.dtype)
-        w, cinp = st.w_master(ws), ws.cin_pitch
+        p, st, lib, cat = self.plan, self.plan.store, self.plan.lib, self.cat
+        N, Ct, S, dt = cat.N, cat.C, cat.S, _dt(p.dtype)
+        mean, g = self.mean.data_ptr(), self.g.data_ptr()
+        fwd_d, bwd_d = [], []
+        bias0 = None
+        for fc, off, w in self.fcs:
+            ws, bs = st.slot(fc.weight), st.slot(fc.bias)
+            assert ws.cin_pitch == w
+            if bias0 is None:
+                bias0 = bs
+            assert bs.off == bias0.off + off, 'gate biases must be registered back to back (see SepInception.register)'
+            W = st.w_master(ws)
+            fwd_d.append(dict(A=mean + 4 * off, sam=Ct, sak=1, B=W, sbk=1, sbn=w, C=g + 4 * off, ldc=Ct,
+                              bias=st.w_master(bs), M=N, N=w, K=w, flags=DV_SIGMOID, alpha=1.0))
+            if p.with_grad:
+                dpre, dmean = self.dpre.data_ptr() + 4 * off, self.dmean.data_ptr() + 4 * off
+                bwd_d.append(dict(A=dpre, sam=Ct, sak=1, B=W, sbk=w, sbn=1, C=dmean, ldc=Ct, bias=0,
+                                  M=N, N=w, K=w, flags=0, alpha=1.0))                      # dmean = dpre @ W
+                bwd_d.append(dict(A=dpre, sam=1, sak=Ct, B=mean + 4 * off, sbk=Ct, sbn=1, C=st.w_grad(ws), ldc=w, bias=0,
+                                  M=w, N=w, K=N, flags=DV_ACCUM, alpha=1.0))               # dW += dpre^T @ mean
+        self._ft, ftiles = self._table(fwd_d)
         f = [Launch('gate_mean', 'spatial_mean<%s>' % dt, lib.dv_spatial_mean,
-                    (p.dtype, x.ptr, x.ld, N, S, Cn, self.mean.data_ptr()), _abytes(x)),
-             Launch('gate_fc', 'conv_gemm<f32,FWD,16,128,%d>' % _pick_bn(Cn), lib.dv_conv3d_fwd,
-                    (C.byref(self.d), self.mean.data_ptr(), w, st.w_master(bs), self.g.data_ptr(), 0),
-                    Cn * Cn * 4, 2 * N * Cn * Cn),
+                    (p.dtype, cat.ptr, cat.ld, N, S, Ct, mean), _abytes(cat)),
+             Launch('gate_fc', 'gemm_f32_grouped', lib.dv_gemm_f32_grouped, (self._ft.data_ptr(), len(fwd_d), ftiles),
+                    sum(w * w * 4 for _, _, w in self.fcs), sum(2 * N * w * w for _, _, w in self.fcs)),
              Launch('gate_scale', 'rowscale<%s,0>' % dt, lib.dv_gate_scale,
-                    (p.dtype, x.ptr, x.ld, self.g.data_ptr(), N, S, Cn, y.ptr, y.ld), 2 * _abytes(x))]
+                    (p.dtype, cat.ptr, cat.ld, g, N, S, Ct, cat.ptr, cat.ld), 2 * _abytes(cat))]
         b = []
         if p.with_grad:
-            dy = y.grad
+            dy = cat.grad
+            self._bt, btiles = self._table(bwd_d)
             b = [Launch('gate_bwd_reduce', 'gate_bwd_reduce<%s>' % dt, lib.dv_gate_bwd_reduce,
-                        (p.dtype, dy.ptr, dy.ld, x.ptr, x.ld, self.g.data_ptr(), N, S, Cn, self.dpre.data_ptr()), 2 * _abytes(x)),
-                 Launch('gate_dmean', 'gemm_f32', lib.dv_gemm_f32,
-                        (N, Cn, Cn, self.dpre.data_ptr(), Cn, 1, w, cinp, 1, self.dmean.data_ptr(), Cn, 1.0, 0), Cn * Cn * 4),
-                 Launch('gate_dW', 'gemm_f32', lib.dv_gemm_f32,
-                        (Cn, Cn, N, self.dpre.data_ptr(), 1, Cn, self.mean.data_ptr(), Cn, 1, st.w_grad(ws), cinp, 1.0, 1), Cn * Cn * 8),
-                 Launch('gate_db', 'colsum', lib.dv_colsum_f32, (self.dpre.data_ptr(), Cn, N, Cn, st.w_grad(bs))),
+                        (p.dtype, dy.ptr, dy.ld, cat.ptr, cat.ld, g, N, S, Ct, self.dpre.data_ptr(), 1), 2 * _abytes(cat)),
+                 Launch('gate_fc_bwd', 'gemm_f32_grouped', lib.dv_gemm_f32_grouped, (self._bt.data_ptr(), len(bwd_d), btiles),
+                        sum(w * w * 12 for _, _, w in self.fcs), sum(4 * N * w * w for _, _, w in self.fcs)),
+                 Launch('gate_db', 'reduce_rows', lib.dv_colsum_f32, (self.dpre.data_ptr(), Ct, N, Ct, st.w_grad(bias0))),
                  Launch('gate_bwd_apply', 'rowscale<%s,1>' % dt, lib.dv_gate_bwd_apply,
-                        (p.dtype, dy.ptr, dy.ld, self.g.data_ptr(), self.dmean.data_ptr(), N, S, Cn, x.grad.ptr, x.grad.ld, 0),
-                        2 * _abytes(x))]
+                        (p.dtype, dy.ptr, dy.ld, g, self.dmean.data_ptr(), N, S, Ct, dy.ptr, dy.ld, 0), 2 * _abytes(cat))]
         return f, b
 
 

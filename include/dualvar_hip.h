@@ -129,8 +129,10 @@ int dv_ingest_ncdhw(int32_t dtype, const float* x, void* y, int32_t N, int32_t C
  *   dv_bn_bwd_reduce   : g = dy*(y>0); sums[0][c] += sum(g), sums[1][c] += sum(g*xhat)  (block-reduced, then
  *                        one fp32 atomic per block and channel, block b into replica b % n_rep so that the
  *                        memory-side atomics do not serialise; the caller zeroes `sums` [n_rep][2][CP] first)
- *   dv_bn_bwd_apply    : dgamma += sum(g*xhat)_local, dbeta += sum(g)_local (local sums);
- *                        dx = scale*(g - sum_g/M - xhat*sum_gx/M) with the GLOBAL sums/M;
+ *   dv_bn_bwd_apply    : dx = scale*(g - sum_g/M - xhat*sum_gx/M) with the GLOBAL sums over the M = R*M_local rows;
+ *                        dgamma += dparam_scale*sum(g*xhat), dbeta += dparam_scale*sum(g).  dparam_scale = 1/R:
+ *                        every rank then holds (1/R)*SUM_r local_r, which is exactly what DDP's averaging of
+ *                        SyncBatchNorm's per-rank (local-sum) parameter gradients produces.
  *                        optional dres (+)= g for the residual branch.
  */
 /* Per-channel fp32 arrays read by the apply / backward kernels (scale, shift, mean, invstd, gamma, sums) are
@@ -142,7 +144,8 @@ int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int32_t tile_ro
                          float* local_stats /*[2*C+1]*/, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
                          float* scale, float* shift, void* stream);
-int dv_bn_finalize(const float* stats /*[R][2*C+1]*/, int32_t R, int32_t C, const float* gamma,
+int dv_bn_finalize(const float* stats /*[R] rows of (sum[C], M2[C], count), row pitch `stride` floats*/, int32_t R,
+                   int32_t stride, int32_t C, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                    float* mean, float* invstd, float* scale, float* shift, void* stream);
 int dv_bn_apply(int32_t dtype, const void* x, int32_t ldx, const float* scale, const float* shift,
@@ -155,9 +158,8 @@ int dv_bn_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y,
                      void* stream);
 int dv_bn_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                     int32_t ldx, const float* mean, const float* invstd, const float* gamma,
-                    const float* sums_global /*[rep_global][2][CP]*/, int32_t rep_global,
-                    const float* sums_local /*[rep_local][2][CP]*/, int32_t rep_local, float inv_count,
-                    float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres, int32_t lddres,
+                    const float* sums /*[n_rep][2][CP], global (all-reduced) sums*/, int32_t n_rep, float inv_count,
+                    float dparam_scale, float* dgamma, float* dbeta, void* dx, int32_t lddx, void* dres, int32_t lddres,
                     int64_t M, int32_t C, int32_t flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -182,7 +184,8 @@ int dv_maxpool3d_bwd(const dv_pool_desc* d, const void* dy, const uint8_t* idx, 
  *   dv_spatial_mean      : out[n][c] = mean_s x[n][s][c]                      (fp32 out, pitch C)
  *   dv_spatial_mean_bwd  : dx[n][s][c] (+)= dout[n][c]/S
  *   dv_gate_scale        : y[n][s][c] = x[n][s][c]*g[n][c]
- *   dv_gate_bwd_reduce   : dpre[n][c] = (sum_s dy*x) * g*(1-g)
+ *   dv_gate_bwd_reduce   : dpre[n][c] = (sum_s dy*x) * g*(1-g); with x_is_output the second operand is the
+ *                          gated output x*g (in-place gating) and dpre = (sum_s dy*out) * (1-g)
  *   dv_gate_bwd_apply    : dx[n][s][c] (+)= dy*g[n][c] + dmean[n][c]/S
  */
 int dv_spatial_mean(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t S, int32_t C, float* out,
@@ -192,7 +195,7 @@ int dv_spatial_mean_bwd(int32_t dtype, const float* dout, int32_t N, int32_t S, 
 int dv_gate_scale(int32_t dtype, const void* x, int32_t ldx, const float* g, int32_t N, int32_t S, int32_t C,
                   void* y, int32_t ldy, void* stream);
 int dv_gate_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* x, int32_t ldx, const float* g,
-                       int32_t N, int32_t S, int32_t C, float* dpre, void* stream);
+                       int32_t N, int32_t S, int32_t C, float* dpre, int32_t x_is_output, void* stream);
 int dv_gate_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const float* g, const float* dmean,
                       int32_t N, int32_t S, int32_t C, void* dx, int32_t lddx, int32_t flags, void* stream);
 
@@ -241,6 +244,16 @@ int dv_rank_margin(const float* feats /*[Bn][2s][D]*/, int32_t Bn, int32_t s, in
  *   C[m][n] (+)= alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]      (C row pitch ldc) */
 int dv_gemm_f32(int32_t M, int32_t N, int32_t K, const float* A, int64_t sam, int64_t sak, const float* B,
                 int64_t sbk, int64_t sbn, float* C, int64_t ldc, float alpha, int32_t accumulate, void* stream);
+/* Several such GEMMs in one launch (the four self-gating FCs of an Inception block, forward and backward).
+ * `descs` is a DEVICE array; tile_end is the running sum of ceil(M/32)*ceil(N/32) over the groups.
+ *   C = act(alpha*A.B + bias [+ C])   flags: DV_ACCUM, DV_SIGMOID, DV_RELU */
+typedef struct dv_gemm_desc {
+  const float* A; const float* B; float* C; const float* bias;
+  int64_t sam, sak, sbk, sbn, ldc;
+  int32_t M, N, K, flags, tile_end;
+  float alpha;
+} dv_gemm_desc;
+int dv_gemm_f32_grouped(const dv_gemm_desc* descs /*device*/, int32_t n_groups, int32_t total_tiles, void* stream);
 /* y[r][d] = mean_g x[r][g][d]  (series-mean vectors of the tc head, simclr.py:297-304 ==
  * <mean_i row_i, mean_j col_j>);  bwd: dx[r][g][d] = dy[r][d]/G */
 int dv_group_mean_f32(const float* x, int32_t R, int32_t G, int32_t D, float* y, void* stream);

@@ -213,7 +213,7 @@ def test_batchnorm_fwd_bwd(gpu, dtype, C_, residual, relu):
         return o
     mean, invstd, scale, shift = (torch.zeros(CP, device=gpu) for _ in range(4))
     gam, bet = padded(gamma), padded(beta)
-    ops.call('dv_bn_finalize', local, 1, C_, gam, bet, 1e-5, 0.1, rm, rv, mean, invstd, scale, shift)
+    ops.call('dv_bn_finalize', local, 1, 2 * C_ + 1, C_, gam, bet, 1e-5, 0.1, rm, rv, mean, invstd, scale, shift)
     # the fused single-rank variant must agree with reduce + finalize
     rm2, rv2, local2 = torch.zeros(C_, device=gpu), torch.ones(C_, device=gpu), torch.zeros(2 * C_ + 1, device=gpu)
     o2 = [torch.zeros(CP, device=gpu) for _ in range(4)]
@@ -234,8 +234,8 @@ def test_batchnorm_fwd_bwd(gpu, dtype, C_, residual, relu):
     dg, db = torch.zeros(C_, device=gpu), torch.zeros(C_, device=gpu)
     dxa = ops.new_act(N, T, H, W, C_, dtype, gpu)
     dra = ops.new_act(N, T, H, W, C_, dtype, gpu) if residual else None
-    ops.call('dv_bn_bwd_apply', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, gam, sums, 4, sums, 4,
-             1.0 / M, dg, db, dxa, dxa.ld, dra, dra.ld if dra else 0, M, C_, flags)
+    ops.call('dv_bn_bwd_apply', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, gam, sums, 4,
+             1.0 / M, 1.0, dg, db, dxa, dxa.ld, dra, dra.ld if dra else 0, M, C_, flags)
     f = 3 if dtype == DV_BF16 else 20
     close(ops.act_to_ncdhw(dxa), xr.grad, dtype, 'bn dx', factor=f)
     close(dg, bn.weight.grad, dtype, 'dgamma', factor=f)
@@ -252,7 +252,7 @@ def test_bn_two_rank_combine(gpu):
         stats.append(torch.cat([part.sum(0), ((part - part.mean(0)) ** 2).sum(0), torch.tensor([float(part.shape[0])])]))
     st = torch.stack(stats).to(gpu)
     outs = [torch.empty(C_, device=gpu) for _ in range(4)]
-    ops.call('dv_bn_finalize', st, 2, C_, torch.ones(C_, device=gpu), torch.zeros(C_, device=gpu), 1e-5, 0.1, None, None, *outs)
+    ops.call('dv_bn_finalize', st, 2, 2 * C_ + 1, C_, torch.ones(C_, device=gpu), torch.zeros(C_, device=gpu), 1e-5, 0.1, None, None, *outs)
     close(outs[0], x.mean(0), DV_F32, 'mean 2-rank', factor=5)
     close(outs[1], (x.var(0, unbiased=False) + 1e-5).rsqrt(), DV_F32, 'invstd 2-rank', factor=5)
     # the host-side restatement used by the gloo tests agrees
@@ -315,7 +315,24 @@ def test_self_gating_and_mean(gpu, dtype):
     close(ops.act_to_ncdhw(ya), yr, dtype, 'gate scale')
     dya = ops.act_from_ncdhw(gy.to(gpu), dtype)
     dpre = torch.empty(N, C_, device=gpu)
-    ops.call('dv_gate_bwd_reduce', dtype, dya, dya.ld, xa, xa.ld, g, N, S, C_, dpre)
+    ops.call('dv_gate_bwd_reduce', dtype, dya, dya.ld, xa, xa.ld, g, N, S, C_, dpre, 0)
+    # in-place gating variant: the second operand is the gated output
+    dpre2 = torch.empty(N, C_, device=gpu)
+    ops.call('dv_gate_bwd_reduce', dtype, dya, dya.ld, ya, ya.ld, g, N, S, C_, dpre2, 1)
+    close(dpre2, dpre, dtype, 'gate dpre from output', factor=2)
+    # grouped GEMM == the two plain GEMMs
+    import ctypes as C
+    from dualvar_amd import _lib as L
+    arr = (L.GemmDesc * 2)()
+    outA, outB = torch.zeros(N, C_, device=gpu), torch.zeros(C_, C_, device=gpu)
+    for i, dd in enumerate([dict(A=dpre.data_ptr(), sam=C_, sak=1, B=Wt.data_ptr(), sbk=C_, sbn=1, C=outA.data_ptr(), ldc=C_, bias=0, M=N, N=C_, K=C_, flags=0, alpha=1.0),
+                            dict(A=dpre.data_ptr(), sam=1, sak=C_, B=mean.data_ptr(), sbk=C_, sbn=1, C=outB.data_ptr(), ldc=C_, bias=0, M=C_, N=C_, K=N, flags=ops.DV_ACCUM, alpha=1.0)]):
+        for k, v in dd.items():
+            setattr(arr[i], k, v)
+    t0 = ((N + 31) // 32) * ((C_ + 31) // 32)
+    arr[0].tile_end, arr[1].tile_end = t0, t0 + ((C_ + 31) // 32) ** 2
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(gpu)
+    ops.call('dv_gemm_f32_grouped', tab, 2, int(arr[1].tile_end))
     dmean = torch.empty(N, C_, device=gpu)
     ops.call('dv_gemm_f32', N, C_, C_, dpre, C_, 1, Wt, C_, 1, dmean, C_, 1.0, 0)
     dxa = ops.new_act(N, T, H, W, C_, dtype, gpu)
@@ -324,6 +341,8 @@ def test_self_gating_and_mean(gpu, dtype):
     dW = torch.zeros(C_, C_, device=gpu)
     ops.call('dv_gemm_f32', C_, C_, N, dpre, 1, C_, mean, C_, 1, dW, C_, 1.0, 1)
     close(dW, fc.weight.grad, dtype, 'gate dW', factor=2)
+    close(outA, dmean, DV_F32, 'grouped gemm 0')
+    close(outB, dW, DV_F32, 'grouped gemm 1')
     dbias = torch.zeros(C_, device=gpu)
     ops.call('dv_colsum_f32', dpre, C_, N, C_, dbias)
     close(dbias, fc.bias.grad, dtype, 'gate db', factor=2)
