@@ -645,7 +645,9 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
   a.M = d->N * d->To * d->Ho * d->Wo;
   a.Cout = d->Cout; a.CoutP = d->cout_pitch; a.J = a.g.Ktot;
   a.ldx = d->ldx; a.ldy = d->ldy; a.ldw = a.g.Ktot;
-  constexpr int BI = 128, BJ = 64;
+  // 128 output channels x 64 im2col columns per workgroup, or 64 x 128 when the layer has <= 64 output channels
+  const bool narrow = a.Cout <= 64;
+  const int BI = narrow ? 64 : 128, BJ = narrow ? 128 : 64;
   a.nti = (a.Cout + BI - 1) / BI;
   a.ntj = (a.J + BJ - 1) / BJ;
   const int tiles = a.nti * a.ntj;
@@ -659,8 +661,14 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
   const int gvb = gather_bytes(d->dtype, d->cin_pitch);
   if (gvb == 16 && !aligned16(x)) return DV_EALIGN;
   hipStream_t s = (hipStream_t)stream;
-  if (d->dtype == DV_F32) hipLaunchKernelGGL((conv_wgrad_kernel<float, 16, BI, BJ>), dim3(grid), dim3(256), 0, s, a);
-  else if (gvb == 16) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 16, BI, BJ>), dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 8, BI, BJ>), dim3(grid), dim3(256), 0, s, a);
+#define WG_LAUNCH(T_, G_)                                                                                   \
+  do {                                                                                                      \
+    if (narrow) hipLaunchKernelGGL((conv_wgrad_kernel<T_, G_, 64, 128>), dim3(grid), dim3(256), 0, s, a);   \
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T_, G_, 128, 64>), dim3(grid), dim3(256), 0, s, a);          \
+  } while (0)
+  if (d->dtype == DV_F32) WG_LAUNCH(float, 16);
+  else if (gvb == 16) WG_LAUNCH(bf16_t, 16);
+  else WG_LAUNCH(bf16_t, 8);
+#undef WG_LAUNCH
   return dv_launch_status();
 }

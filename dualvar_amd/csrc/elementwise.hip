@@ -173,8 +173,10 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, int ldx, const float* _
 // ------------------------------------------------------------------ column reductions over rows
 // Generic: rows [r_begin, r_end) of a [rows][ld] matrix, lanes along channel vectors.  F maps
 // (row, c0) -> V values for NS sums.  Result: out[s][c] for this block (written by the caller's lambda).
-template <int V, int NS, typename F, typename W>
-__device__ __forceinline__ void column_reduce(int64_t r_begin, int64_t r_end, int CP, F f, W write) {
+struct NoPre { __device__ __forceinline__ void operator()(int) const {} };
+
+template <int V, int NS, typename F, typename W, typename Pre = NoPre>
+__device__ __forceinline__ void column_reduce(int64_t r_begin, int64_t r_end, int CP, F f, W write, Pre pre = Pre()) {
   __shared__ float lds[kThreads * V * NS > 4096 ? 4096 : kThreads * V * NS];
   const int CV = CP / V;
   for (int cvb = 0; cvb < CV; cvb += kThreads) {
@@ -189,8 +191,11 @@ __device__ __forceinline__ void column_reduce(int64_t r_begin, int64_t r_end, in
     for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int e = 0; e < V; ++e) acc[s][e] = 0.f;
-    if (my_rg < rg)
+    if (my_rg < rg) {
+      pre((cvb + my_cv) * V);                       // per-thread constants of this channel vector
+#pragma unroll 2
       for (int64_t r = r_begin + my_rg; r < r_end; r += rg) f(r, (cvb + my_cv) * V, acc);
+    }
     __syncthreads();
     if (rg == 1 && cvc * V * NS > 4096) {
       // too wide for LDS staging (cannot happen for CP <= 4096/NS); write directly
@@ -230,15 +235,14 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T
   const int64_t r0 = blockIdx.x * rows_per_block;
   const int64_t r1 = min(M, r0 + rows_per_block);
   const bool mask = !(flags & DV_NO_RELU_MASK);
+  float mu[V], is[V];
   column_reduce<V, 2>(
       r0, r1, CP,
       [&](int64_t r, int c0, float(&acc)[2][V]) {
-        float g[V], yy[V], xx[V], mu[V], is[V];
+        float g[V], yy[V], xx[V];
         Pack16<T>::load(dy + r * lddy + c0, g);
         if (mask) Pack16<T>::load(y + r * ldy + c0, yy);
         Pack16<T>::load(x + r * ldx + c0, xx);
-        load_params<V>(mean, c0, mu);
-        load_params<V>(invstd, c0, is);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           float gg = (mask && !(yy[e] > 0.f)) ? 0.f : g[e];
@@ -250,7 +254,8 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T
 #pragma unroll
         for (int e = 0; e < V; ++e)
           if (c0 + e < C) { atomicAdd(sums + c0 + e, acc[0][e]); atomicAdd(sums + CP + c0 + e, acc[1][e]); }
-      });
+      },
+      [&](int c0) { load_params<V>(mean, c0, mu); load_params<V>(invstd, c0, is); });
 }
 
 // partials [n_blocks][W] -> out[W] (+=): 32 columns x 8 row lanes per block
