@@ -506,7 +506,7 @@ class BNGroupOp(Op):
             f_app.append(Launch('bn_apply', 'bn_apply<%s>' % dt, lib.dv_bn_apply,
                                 (p.dtype, x.ptr, x.ld, m.scale.data_ptr(), m.shift.data_ptr(),
                                  res.ptr if res is not None else 0, res.ld if res is not None else 0, y.ptr, y.ld, M, Cn,
-                                 DV_RELU if m.relu else 0), _abytes(x) * (3 if res is not None else 2)))
+                                 DV_RELU if m.relu else 0), _abytes(x) * (3 if res is not None else 2), 0, 'M%d C%d' % (M, Cn)))
             if p.with_grad:
                 dy = y.grad
                 mflag = 0 if m.relu else DV_NO_RELU_MASK
@@ -514,7 +514,7 @@ class BNGroupOp(Op):
                 sums = p.zero_ptr(m.sums_off)
                 b_red.append(Launch('bn_bwd_reduce', 'bn_bwd_reduce<%s>' % dt, lib.dv_bn_bwd_reduce,
                                     (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, m.mean.data_ptr(), m.invstd.data_ptr(),
-                                     M, Cn, mflag, sums, BN_REPLICAS), _abytes(x) * nact))
+                                     M, Cn, mflag, sums, BN_REPLICAS), _abytes(x) * nact, 0, 'M%d C%d' % (M, Cn)))
                 dres = res.grad if (res is not None and res.grad is not None) else None
                 bflags = mflag | (DV_ACCUM if (dres is not None and self.acc.get('res%d' % i)) else 0)
                 nres = 0 if dres is None else (2 if bflags & DV_ACCUM else 1)
@@ -522,7 +522,8 @@ class BNGroupOp(Op):
                                     (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, m.mean.data_ptr(), m.invstd.data_ptr(),
                                      st.w_master(gs), sums, BN_REPLICAS, 1.0 / (M * R), 1.0 / R, st.w_grad(gs), st.w_grad(bs),
                                      x.grad.ptr, x.grad.ld, dres.ptr if dres is not None else 0,
-                                     dres.ld if dres is not None else 0, M, Cn, bflags), _abytes(x) * (nact + 1 + nres)))
+                                     dres.ld if dres is not None else 0, M, Cn, bflags), _abytes(x) * (nact + 1 + nres), 0,
+                                    'M%d C%d' % (M, Cn)))
         f = list(f_red)
         b = list(b_red)
         if R > 1:
