@@ -89,6 +89,8 @@ class SepInception(nn.Module):
         return (self.gating_b0, self.gating_b1, self.gating_b2, self.gating_b3) if self.gating else (None,) * 4
 
     def register(self, store):
+        # the three 1x1x1 branch-entry convs read the same tensor: one [o0+o1a+o2a][Cin] GEMM
+        self._entry = store.add_merged([self.branch0[0].conv.weight, self.branch1[0].conv.weight, self.branch2[0].conv.weight])
         self.branch0[0].register(store)
         self.branch1[0].register(store); self.branch1[1].register(store)
         self.branch2[0].register(store); self.branch2[1].register(store)
@@ -118,7 +120,13 @@ class SepInception(nn.Module):
         st1, st2 = self.branch1[1], self.branch2[1]
         mp = self.branch3[0]
         px = plan.maxpool(x, (mp.kernel_size,) * 3, (mp.stride,) * 3, (mp.padding,) * 3)
-        r0, r1, r2, r3 = conv(b0.conv, x), conv(b1a.conv, x), conv(b2a.conv, x), conv(b3.conv, px)
+        ent = plan.store.add_merged([b0.conv.weight, b1a.conv.weight, b2a.conv.weight])
+        raw = plan.conv(ent, x, (1, 1, 1), (1, 1, 1), (0, 0, 0))                    # [M, o0 | o1a | o2a]
+        c0, c1, c2 = b0.conv.out_channels, b1a.conv.out_channels, b2a.conv.out_channels
+        r0, r1, r2 = plan.slice(raw, 0, c0), plan.slice(raw, c0, c1), plan.slice(raw, c0 + c1, c2)
+        for r in (r0, r1, r2):
+            r.producer = raw.producer
+        r3 = conv(b3.conv, px)
         _, y1, y2, _ = plan.bn_group([(b0.bn, r0, True, None, dst[0]), (b1a.bn, r1, True, None, None),
                                       (b2a.bn, r2, True, None, None), (b3.bn, r3, True, None, dst[3])])
         y1, y2 = plan.bn_group([(st1.bn1, conv(st1.conv1, y1), True, None, None),

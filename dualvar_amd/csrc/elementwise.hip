@@ -66,20 +66,20 @@ struct BnFinalize {
   const float* gamma; const float* beta; float eps, momentum;
   float* running_mean; float* running_var; float* mean; float* invstd; float* scale; float* shift;
 };
-__global__ void bn_reduce_stats_kernel(const float* __restrict__ part, int n_tiles, int tile_rows, int64_t M, int C,
+__global__ void bn_reduce_stats_kernel(const float* __restrict__ part, int n_tiles, int tile_rows, int P, int64_t M, int C,
                                        float* __restrict__ out, int fin, BnFinalize f) {
   __shared__ float sh[8];
   const int c = blockIdx.x;
   float s = 0.f;
-  for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s += part[((size_t)i * 2) * C + c];
+  for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s += part[((size_t)i * 2) * P + c];
   const float S = block_sum(s, sh);
   const float mean = S / (float)M;
   float m2 = 0.f;
   for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
     int64_t left = M - (int64_t)i * tile_rows;
     float n_i = (float)(left < tile_rows ? left : tile_rows);
-    float d = part[((size_t)i * 2) * C + c] / n_i - mean;
-    m2 += part[((size_t)i * 2 + 1) * C + c] + n_i * d * d;
+    float d = part[((size_t)i * 2) * P + c] / n_i - mean;
+    m2 += part[((size_t)i * 2 + 1) * P + c] + n_i * d * d;
   }
   const float M2 = block_sum(m2, sh + 4);
   if (threadIdx.x == 0) {
@@ -648,24 +648,24 @@ extern "C" int dv_ingest_ncdhw(int32_t dtype, const float* x, void* y, int32_t N
   return dv_launch_status();
 }
 
-extern "C" int dv_bn_reduce_stats(const float* partials, int32_t n_tiles, int32_t tile_rows, int64_t M, int32_t C,
-                                  float* local_stats, void* stream) {
-  if (!partials || !local_stats || n_tiles <= 0 || C <= 0 || M <= 0) return DV_EINVAL;
+extern "C" int dv_bn_reduce_stats(const float* partials, int32_t n_tiles, int32_t tile_rows, int32_t pitch, int64_t M,
+                                  int32_t C, float* local_stats, void* stream) {
+  if (!partials || !local_stats || n_tiles <= 0 || C <= 0 || M <= 0 || pitch < C) return DV_EINVAL;
   BnFinalize f = {};
-  hipLaunchKernelGGL(bn_reduce_stats_kernel, dim3(C), dim3(kThreads), 0, ST(stream), partials, n_tiles, tile_rows, M, C,
+  hipLaunchKernelGGL(bn_reduce_stats_kernel, dim3(C), dim3(kThreads), 0, ST(stream), partials, n_tiles, tile_rows, pitch, M, C,
                      local_stats, 0, f);
   return dv_launch_status();
 }
 
-extern "C" int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int32_t tile_rows, int64_t M, int32_t C,
-                                    float* local_stats, const float* gamma, const float* beta, float eps, float momentum,
+extern "C" int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int32_t tile_rows, int32_t pitch, int64_t M,
+                                    int32_t C, float* local_stats, const float* gamma, const float* beta, float eps, float momentum,
                                     float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
                                     float* shift, void* stream) {
-  if (!partials || !local_stats || n_tiles <= 0 || C <= 0 || M <= 0) return DV_EINVAL;
+  if (!partials || !local_stats || n_tiles <= 0 || C <= 0 || M <= 0 || pitch < C) return DV_EINVAL;
   if (!gamma || !beta || !mean || !invstd || !scale || !shift) return DV_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return DV_EINVAL;
   BnFinalize f = {gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
-  hipLaunchKernelGGL(bn_reduce_stats_kernel, dim3(C), dim3(kThreads), 0, ST(stream), partials, n_tiles, tile_rows, M, C,
+  hipLaunchKernelGGL(bn_reduce_stats_kernel, dim3(C), dim3(kThreads), 0, ST(stream), partials, n_tiles, tile_rows, pitch, M, C,
                      local_stats, 1, f);
   return dv_launch_status();
 }
@@ -701,7 +701,7 @@ extern "C" int dv_bn_apply(int32_t dtype, const void* x, int32_t ldx, const floa
 
 extern "C" int dv_bn_bwd_blocks(int64_t M, int32_t C) {
   (void)C;
-  int64_t b = (M + 127) / 128;
+  int64_t b = (M + 31) / 32;          // small tensors are latency bound: many short blocks
   if (b > 1024) b = 1024;
   if (b < 1) b = 1;
   return (int)b;

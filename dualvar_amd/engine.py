@@ -31,7 +31,7 @@ def _align8(n):
 
 class Slot:
     __slots__ = ('tensor', 'kind', 'off', 'size', 'Cout', 'Cin', 'taps', 'cin_pitch', 'cout_pitch', 'wd_off',
-                 'shape', 'strides')
+                 'shape', 'strides', 'parts')
 
 
 class ParamStore:
@@ -39,6 +39,7 @@ class ParamStore:
 
     def __init__(self):
         self.slots = []
+        self.merged = []           # virtual slots: several convs that share their input, stored back to back
         self._by_id = {}
         self.buffers = []          # (module, name) float buffers (BN running stats) -- left where they are
         self.nbt = []              # BN modules whose num_batches_tracked is bumped per forward
@@ -73,6 +74,26 @@ class ParamStore:
             taps *= d
         return self._add(weight, 'conv', Cout=O, Cin=I, taps=taps, cin_pitch=cin_pitch or cp8(I), cout_pitch=cp8(O),
                          wd_off=0 if (need_dgrad and not self.no_dgrad) else -1)
+
+    def add_merged(self, weights):
+        """Several 1x1x1 convs reading the same input become ONE GEMM: their [Cout_i][Cin] blocks are registered
+        back to back, so together they are a [sum Cout_i][Cin] matrix (forward / wgrad use it in place; the dgrad
+        layout gets its own packed copy).  Returns the virtual slot."""
+        parts = [self.add_conv(w, need_dgrad=False) for w in weights]
+        key = tuple(id(w) for w in weights)
+        for m in self.merged:
+            if tuple(id(p.tensor) for p in m.parts) == key:
+                return m
+        assert all(p.taps == 1 and p.Cin == parts[0].Cin and p.Cout % 8 == 0 for p in parts)
+        m = Slot()
+        m.tensor, m.kind, m.parts = None, 'merged', parts
+        m.Cin, m.taps, m.cin_pitch = parts[0].Cin, 1, parts[0].cin_pitch
+        m.Cout = sum(p.Cout for p in parts)
+        m.cout_pitch = cp8(m.Cout)
+        m.wd_off = -1 if self.no_dgrad else 0
+        m.off = m.size = 0
+        self.merged.append(m)
+        return m
 
     def add_vec(self, t):
         return self._add(t, 'vec')
@@ -121,6 +142,13 @@ class ParamStore:
                     s.wd_off = wd_off
                     wd_off += _align8(s.Cin * s.taps * s.cout_pitch)
             off += _align8(s.size)
+        for m in self.merged:
+            m.off, m.size = m.parts[0].off, sum(p.size for p in m.parts)
+            for a, b in zip(m.parts, m.parts[1:]):
+                assert b.off == a.off + a.size, 'merged convs must be registered back to back'
+            if m.wd_off >= 0:
+                m.wd_off = wd_off
+                wd_off += _align8(m.Cin * m.taps * m.cout_pitch)
         self.total = off
         master = torch.zeros(off, dtype=torch.float32, device=device)
         grad = torch.zeros(off, dtype=torch.float32, device=device)
@@ -135,7 +163,7 @@ class ParamStore:
         self.cc = master if dtype == DV_F32 else torch.zeros(off, dtype=torch.bfloat16, device=device)
         self.wd = torch.zeros(max(wd_off, 8), dtype=ops.TORCH_DTYPE[dtype], device=device)
         # pack descriptors (device copies)
-        packs = [s for s in self.slots if s.kind == 'conv' and s.wd_off >= 0]
+        packs = [s for s in self.slots + self.merged if s.kind in ('conv', 'merged') and s.wd_off >= 0]
         self._n_pack_blocks = 0
         if packs:
             arr = (L.PackDesc * len(packs))()
@@ -493,13 +521,17 @@ class BNGroupOp(Op):
             eps, mom = float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1)
             local = self.local.data_ptr() + 4 * m.loff
             outs = (m.mean.data_ptr(), m.invstd.data_ptr(), m.scale.data_ptr(), m.shift.data_ptr())
+            # x may be a channel slice of a merged conv's output: its partials are columns [coff, coff+C) of a wider table
+            coff = x.off - m.conv.y.off
+            spitch = m.conv.slot.Cout
+            sptr = m.conv.stats.data_ptr() + 4 * coff
             if R == 1:
                 f_red.append(Launch('bn_stats_finalize', 'bn_reduce_stats', lib.dv_bn_stats_finalize,
-                                    (m.conv.stats.data_ptr(), m.conv.tiles, 128, M, Cn, local, st.w_master(gs), st.w_master(bs),
+                                    (sptr, m.conv.tiles, 128, spitch, M, Cn, local, st.w_master(gs), st.w_master(bs),
                                      eps, mom, rm, rv) + outs, m.conv.tiles * 2 * Cn * 4))
             else:
                 f_red.append(Launch('bn_reduce_stats', 'bn_reduce_stats', lib.dv_bn_reduce_stats,
-                                    (m.conv.stats.data_ptr(), m.conv.tiles, 128, M, Cn, local), m.conv.tiles * 2 * Cn * 4))
+                                    (sptr, m.conv.tiles, 128, spitch, M, Cn, local), m.conv.tiles * 2 * Cn * 4))
                 f_fin.append(Launch('bn_finalize', 'bn_finalize', lib.dv_bn_finalize,
                                     (self.gathered.data_ptr() + 4 * m.loff, R, self.width, Cn, st.w_master(gs), st.w_master(bs),
                                      eps, mom, rm, rv) + outs))

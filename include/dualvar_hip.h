@@ -138,9 +138,11 @@ int dv_ingest_ncdhw(int32_t dtype, const float* x, void* y, int32_t N, int32_t C
 /* Per-channel fp32 arrays read by the apply / backward kernels (scale, shift, mean, invstd, gamma, sums) are
  * accessed with 16-byte loads: they must be 16-byte aligned and readable up to CP = round_up(C, 8) floats;
  * `sums` arrays are laid out [2][CP]. */
-int dv_bn_reduce_stats(const float* partials, int32_t n_tiles, int32_t tile_rows, int64_t M, int32_t C,
+/* partials: [tiles][2][pitch] with this layer's C channels starting at the pointer (pitch > C when several
+ * convolutions that share their input were run as one GEMM) */
+int dv_bn_reduce_stats(const float* partials, int32_t n_tiles, int32_t tile_rows, int32_t pitch, int64_t M, int32_t C,
                        float* local_stats /*[2*C+1]*/, void* stream);
-int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int32_t tile_rows, int64_t M, int32_t C,
+int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int32_t tile_rows, int32_t pitch, int64_t M, int32_t C,
                          float* local_stats /*[2*C+1]*/, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
                          float* scale, float* shift, void* stream);

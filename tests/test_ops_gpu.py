@@ -86,7 +86,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, dtype, case):
     # statistics: sum and M2 recombine to the batch mean / biased variance of the stored values
     M = N * To * Ho * Wo
     local = torch.zeros(2 * Cout + 1, device=gpu)
-    ops.call('dv_bn_reduce_stats', stats, tiles, 128, M, Cout, local)
+    ops.call('dv_bn_reduce_stats', stats, tiles, 128, Cout, M, Cout, local)
     ys = ops.act_to_ncdhw(ya)
     mean_ref = ys.mean(dim=(0, 2, 3, 4)).cpu()
     var_ref = ys.var(dim=(0, 2, 3, 4), unbiased=False).cpu()
@@ -202,7 +202,7 @@ def test_batchnorm_fwd_bwd(gpu, dtype, C_, residual, relu):
         part[i, 0] = blk.sum(0)
         part[i, 1] = ((blk - blk.mean(0)) ** 2).sum(0)
     local = torch.zeros(2 * C_ + 1, device=gpu)
-    ops.call('dv_bn_reduce_stats', part, tiles, 128, M, C_, local)
+    ops.call('dv_bn_reduce_stats', part, tiles, 128, C_, M, C_, local)
     # two "ranks" with half the data each must give the same result as one (SyncBN identity)
     rm, rv = torch.zeros(C_, device=gpu), torch.ones(C_, device=gpu)
     CP = ops.cp8(C_)
@@ -217,7 +217,7 @@ def test_batchnorm_fwd_bwd(gpu, dtype, C_, residual, relu):
     # the fused single-rank variant must agree with reduce + finalize
     rm2, rv2, local2 = torch.zeros(C_, device=gpu), torch.ones(C_, device=gpu), torch.zeros(2 * C_ + 1, device=gpu)
     o2 = [torch.zeros(CP, device=gpu) for _ in range(4)]
-    ops.call('dv_bn_stats_finalize', part, tiles, 128, M, C_, local2, gam, bet, 1e-5, 0.1, rm2, rv2, *o2)
+    ops.call('dv_bn_stats_finalize', part, tiles, 128, C_, M, C_, local2, gam, bet, 1e-5, 0.1, rm2, rv2, *o2)
     for a_, b_ in zip((mean, invstd, scale, shift, rm, rv, local), (*o2, rm2, rv2, local2)):
         assert torch.equal(a_, b_)
     close(rm, bn.running_mean, DV_F32, 'running_mean', factor=10)
