@@ -34,6 +34,17 @@ class PackDesc(C.Structure):
                 ('taps', C.c_int32), ('cin_pitch', C.c_int32), ('cout_pitch', C.c_int32), ('_pad', C.c_int32)]
 
 
+class BnItem(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ('partials', 'local_stats', 'gamma', 'beta', 'running_mean', 'running_var', 'mean',
+                                           'invstd', 'scale', 'shift', 'x', 'residual', 'y', 'dy', 'dx', 'dres', 'sums',
+                                           'dgamma', 'dbeta')] +
+                [('M', C.c_int64)] +
+                [(n, C.c_int32) for n in ('n_tiles', 'tile_rows', 'pitch', 'C', 'ldx', 'ldr', 'ldy', 'lddy', 'lddx', 'lddres',
+                                          'fwd_flags', 'bwd_flags', 'n_rep')] +
+                [(n, C.c_float) for n in ('eps', 'momentum', 'inv_count', 'dparam_scale')] +
+                [(n, C.c_int32) for n in ('blk_stats', 'blk_apply', 'blk_red', 'blk_bapply')])
+
+
 class GemmDesc(C.Structure):
     _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('bias', C.c_void_p),
                 ('sam', C.c_int64), ('sak', C.c_int64), ('sbk', C.c_int64), ('sbn', C.c_int64), ('ldc', C.c_int64),
@@ -59,6 +70,10 @@ SIGNATURES = {
     'dv_bn_finalize': [P, I32, I32, I32, P, P, F, F, P, P, P, P, P, P, P],
     'dv_bn_stats_finalize': [P, I32, I32, I32, I64, I32, P, P, P, F, F, P, P, P, P, P, P, P],
     'dv_bn_apply': [I32, P, I32, P, P, P, I32, P, I32, I64, I32, I32, P],
+    'dv_bn_stats_multi': [P, I32, I32, I32, P],
+    'dv_bn_apply_multi': [I32, P, I32, I32, P],
+    'dv_bn_bwd_reduce_multi': [I32, P, I32, I32, P],
+    'dv_bn_bwd_apply_multi': [I32, P, I32, I32, I32, P],
     'dv_bn_bwd_blocks': [I64, I32],
     'dv_bn_bwd_reduce': [I32, P, I32, P, I32, P, I32, P, P, I64, I32, I32, P, I32, P],
     'dv_bn_bwd_apply': [I32, P, I32, P, I32, P, I32, P, P, P, P, I32, F, F, P, P, P, I32, P, I32, I64, I32, I32, P],

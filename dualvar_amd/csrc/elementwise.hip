@@ -66,10 +66,10 @@ struct BnFinalize {
   const float* gamma; const float* beta; float eps, momentum;
   float* running_mean; float* running_var; float* mean; float* invstd; float* scale; float* shift;
 };
-__global__ void bn_reduce_stats_kernel(const float* __restrict__ part, int n_tiles, int tile_rows, int P, int64_t M, int C,
-                                       float* __restrict__ out, int fin, BnFinalize f) {
+__device__ __forceinline__ void bn_reduce_stats_body(const float* __restrict__ part, int n_tiles, int tile_rows, int P,
+                                                     int64_t M, int C, float* __restrict__ out, int fin,
+                                                     const BnFinalize& f, int c) {
   __shared__ float sh[8];
-  const int c = blockIdx.x;
   float s = 0.f;
   for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s += part[((size_t)i * 2) * P + c];
   const float S = block_sum(s, sh);
@@ -102,6 +102,30 @@ __global__ void bn_reduce_stats_kernel(const float* __restrict__ part, int n_til
       }
     }
   }
+}
+
+__global__ void bn_reduce_stats_kernel(const float* __restrict__ part, int n_tiles, int tile_rows, int P, int64_t M, int C,
+                                       float* __restrict__ out, int fin, BnFinalize f) {
+  bn_reduce_stats_body(part, n_tiles, tile_rows, P, M, C, out, fin, f, blockIdx.x);
+}
+
+// locate the item a block of a multi-tensor launch belongs to: `end` is the running block-count prefix
+template <typename GetEnd>
+__device__ __forceinline__ int find_item(int n, uint32_t& bid, uint32_t& nblk, GetEnd end) {
+  int i = 0;
+  uint32_t start = 0;
+  while (i < n - 1 && bid >= (uint32_t)end(i)) { start = (uint32_t)end(i); ++i; }
+  nblk = (uint32_t)end(i) - start;
+  bid -= start;
+  return i;
+}
+
+__global__ void bn_stats_multi_kernel(const dv_bn_item* __restrict__ items, int n, int fin) {
+  uint32_t bid = blockIdx.x, nblk;
+  const int i = find_item(n, bid, nblk, [&](int k) { return items[k].blk_stats; });
+  const dv_bn_item& it = items[i];
+  BnFinalize f = {it.gamma, it.beta, it.eps, it.momentum, it.running_mean, it.running_var, it.mean, it.invstd, it.scale, it.shift};
+  bn_reduce_stats_body(it.partials, it.n_tiles, it.tile_rows, it.pitch, it.M, it.C, it.local_stats, fin, f, (int)bid);
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, int R, int stride, int C, const float* gamma,
@@ -146,12 +170,13 @@ __device__ __forceinline__ void load_params(const float* __restrict__ p, int c0,
 }
 
 template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
-                                const float* __restrict__ shift, const T* __restrict__ res, int ldr,
-                                T* __restrict__ y, int ldy, uint32_t total, int C, FastDiv fcv, int flags) {
+__device__ __forceinline__ void bn_apply_body(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                              const float* __restrict__ shift, const T* __restrict__ res, int ldr,
+                                              T* __restrict__ y, int ldy, uint32_t total, int C, const FastDiv& fcv,
+                                              int flags, uint32_t bid, uint32_t nblk) {
   constexpr int V = DT<T>::VEC;
   const uint32_t CV = fcv.d;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (uint32_t i = bid * blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
     const uint32_t row = fd_div(i, fcv);
     const int c0 = (int)(i - row * CV) * V;
     float v[V], r[V], sc[V], sh[V];
@@ -168,6 +193,35 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, int ldx, const float* _
     }
     Pack16<T>::store(y + (size_t)row * ldy + c0, v);
   }
+}
+
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const T* __restrict__ res, int ldr,
+                                T* __restrict__ y, int ldy, uint32_t total, int C, FastDiv fcv, int flags) {
+  bn_apply_body<T>(x, ldx, scale, shift, res, ldr, y, ldy, total, C, fcv, flags, blockIdx.x, gridDim.x);
+}
+
+__device__ __forceinline__ FastDiv fastdiv_dev(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t sft = 0;
+  while ((1u << sft) < d) ++sft;
+  f.shr = sft;
+  f.mul = (uint32_t)((((1ull << sft) - d) << 32) / d + 1);
+  f._pad = 0;
+  return f;
+}
+
+template <typename T>
+__global__ void bn_apply_multi_kernel(const dv_bn_item* __restrict__ items, int n) {
+  uint32_t bid = blockIdx.x, nblk;
+  const int i = find_item(n, bid, nblk, [&](int k) { return items[k].blk_apply; });
+  const dv_bn_item& it = items[i];
+  constexpr int V = DT<T>::VEC;
+  const int CP = (it.C + 7) & ~7;
+  bn_apply_body<T>((const T*)it.x, it.ldx, it.scale, it.shift, (const T*)it.residual, it.ldr, (T*)it.y, it.ldy,
+                   (uint32_t)(it.M * (CP / V)), it.C, fastdiv_dev((uint32_t)(CP / V)), it.fwd_flags, bid, nblk);
 }
 
 // ------------------------------------------------------------------ column reductions over rows
@@ -235,14 +289,15 @@ __device__ __forceinline__ void column_reduce(int64_t r_begin, int64_t r_end, in
 }
 
 template <typename T>
-__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
-                                     const T* __restrict__ x, int ldx, const float* __restrict__ mean,
-                                     const float* __restrict__ invstd, int64_t M, int C, int CP, int flags,
-                                     int64_t rows_per_block, float* __restrict__ sums_all, int n_rep) {
+__device__ __forceinline__ void bn_bwd_reduce_body(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
+                                                   const T* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                   const float* __restrict__ invstd, int64_t M, int C, int CP, int flags,
+                                                   int64_t rows_per_block, float* __restrict__ sums_all, int n_rep,
+                                                   uint32_t bid) {
   constexpr int V = DT<T>::VEC;
   // atomics on one address serialise at the memory side (~12 ns each): spread the blocks over n_rep replicas
-  float* sums = sums_all + (size_t)(blockIdx.x % n_rep) * 2 * CP;
-  const int64_t r0 = blockIdx.x * rows_per_block;
+  float* sums = sums_all + (size_t)(bid % n_rep) * 2 * CP;
+  const int64_t r0 = (int64_t)bid * rows_per_block;
   const int64_t r1 = min(M, r0 + rows_per_block);
   const bool mask = !(flags & DV_NO_RELU_MASK);
   float mu[V], is[V];
@@ -266,6 +321,25 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T
           if (c0 + e < C) { atomicAdd(sums + c0 + e, acc[0][e]); atomicAdd(sums + CP + c0 + e, acc[1][e]); }
       },
       [&](int c0) { load_params<V>(mean, c0, mu); load_params<V>(invstd, c0, is); });
+}
+
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
+                                     const T* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                     const float* __restrict__ invstd, int64_t M, int C, int CP, int flags,
+                                     int64_t rows_per_block, float* __restrict__ sums_all, int n_rep) {
+  bn_bwd_reduce_body<T>(dy, lddy, y, ldy, x, ldx, mean, invstd, M, C, CP, flags, rows_per_block, sums_all, n_rep, blockIdx.x);
+}
+
+template <typename T>
+__global__ void bn_bwd_reduce_multi_kernel(const dv_bn_item* __restrict__ items, int n) {
+  uint32_t bid = blockIdx.x, nblk;
+  const int i = find_item(n, bid, nblk, [&](int k) { return items[k].blk_red; });
+  const dv_bn_item& it = items[i];
+  const int CP = (it.C + 7) & ~7;
+  const int64_t rpb = (it.M + nblk - 1) / nblk;
+  bn_bwd_reduce_body<T>((const T*)it.dy, it.lddy, (const T*)it.y, it.ldy, (const T*)it.x, it.ldx, it.mean, it.invstd, it.M,
+                        it.C, CP, it.bwd_flags, rpb, it.sums, it.n_rep, bid);
 }
 
 // partials [n_blocks][W] -> out[W] (+=): 32 columns x 8 row lanes per block
@@ -298,16 +372,16 @@ __global__ void reduce_rows_kernel(const float* __restrict__ part, int64_t ld, i
 // dx = k1[c]*g + k2[c]*x + k3[c] with  k1 = gamma*invstd, k2 = -k1*invstd*sgx/M, k3 = -k1*sg/M - k2*mean
 // (sg, sgx = global sums of g and g*xhat).  The table is built once per block in LDS.
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
-                                    const T* __restrict__ x, int ldx, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ sums_g, int rep_g, float inv_count, float dscale,
-                                    float* dgamma, float* dbeta, T* __restrict__ dx, int lddx,
-                                    T* __restrict__ dres, int lddres, uint32_t total, int C, int CP, FastDiv fcv,
-                                    int flags) {
+__device__ __forceinline__ void bn_bwd_apply_body(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
+                                                  const T* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                  const float* __restrict__ sums_g, int rep_g, float inv_count,
+                                                  float dscale, float* dgamma, float* dbeta, T* __restrict__ dx,
+                                                  int lddx, T* __restrict__ dres, int lddres, uint32_t total, int C,
+                                                  int CP, const FastDiv& fcv, int flags, uint32_t bid, uint32_t nblk) {
   constexpr int V = DT<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) float coef[];      // [3][CP]
-  if (blockIdx.x == 0 && dgamma) {
+  if (bid == 0 && dgamma) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float sb = 0.f, sg = 0.f;
       for (int r = 0; r < rep_g; ++r) { sb += sums_g[(size_t)r * 2 * CP + c]; sg += sums_g[(size_t)r * 2 * CP + CP + c]; }
@@ -329,7 +403,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T*
   __syncthreads();
   const uint32_t CV = fcv.d;
   const bool mask = !(flags & DV_NO_RELU_MASK);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (uint32_t i = bid * blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
     const uint32_t row = fd_div(i, fcv);
     const int c0 = (int)(i - row * CV) * V;
     float g[V], yy[V], xx[V], o[V], ro[V], k1[V], k2[V], k3[V];
@@ -349,6 +423,31 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T*
     Pack16<T>::store(dx + (size_t)row * lddx + c0, o);
     if (dres) Pack16<T>::store(dres + (size_t)row * lddres + c0, ro);
   }
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
+                                    const T* __restrict__ x, int ldx, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ sums_g, int rep_g, float inv_count, float dscale,
+                                    float* dgamma, float* dbeta, T* __restrict__ dx, int lddx,
+                                    T* __restrict__ dres, int lddres, uint32_t total, int C, int CP, FastDiv fcv,
+                                    int flags) {
+  bn_bwd_apply_body<T>(dy, lddy, y, ldy, x, ldx, mean, invstd, gamma, sums_g, rep_g, inv_count, dscale, dgamma, dbeta, dx,
+                       lddx, dres, lddres, total, C, CP, fcv, flags, blockIdx.x, gridDim.x);
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_multi_kernel(const dv_bn_item* __restrict__ items, int n) {
+  uint32_t bid = blockIdx.x, nblk;
+  const int i = find_item(n, bid, nblk, [&](int k) { return items[k].blk_bapply; });
+  const dv_bn_item& it = items[i];
+  constexpr int V = DT<T>::VEC;
+  const int CP = (it.C + 7) & ~7;
+  bn_bwd_apply_body<T>((const T*)it.dy, it.lddy, (const T*)it.y, it.ldy, (const T*)it.x, it.ldx, it.mean, it.invstd,
+                       it.gamma, it.sums, it.n_rep, it.inv_count, it.dparam_scale, it.dgamma, it.dbeta, (T*)it.dx, it.lddx,
+                       (T*)it.dres, it.lddres, (uint32_t)(it.M * (CP / V)), it.C, CP, fastdiv_dev((uint32_t)(CP / V)),
+                       it.bwd_flags, bid, nblk);
 }
 
 // ------------------------------------------------------------------ MaxPool3d
@@ -677,6 +776,31 @@ extern "C" int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int3
   BnFinalize f = {gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
   hipLaunchKernelGGL(bn_reduce_stats_kernel, dim3(C), dim3(kThreads), 0, ST(stream), partials, n_tiles, tile_rows, pitch, M, C,
                      local_stats, 1, f);
+  return dv_launch_status();
+}
+
+extern "C" int dv_bn_stats_multi(const dv_bn_item* items, int32_t n, int32_t finalize, int32_t total_blocks, void* stream) {
+  if (!items || n <= 0 || total_blocks <= 0) return DV_EINVAL;
+  hipLaunchKernelGGL(bn_stats_multi_kernel, dim3(total_blocks), dim3(kThreads), 0, ST(stream), items, n, finalize);
+  return dv_launch_status();
+}
+extern "C" int dv_bn_apply_multi(int32_t dtype, const dv_bn_item* items, int32_t n, int32_t total_blocks, void* stream) {
+  if (!items || n <= 0 || total_blocks <= 0) return DV_EINVAL;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_multi_kernel<T>), dim3(total_blocks), dim3(kThreads), 0, ST(stream), items, n));
+  return dv_launch_status();
+}
+extern "C" int dv_bn_bwd_reduce_multi(int32_t dtype, const dv_bn_item* items, int32_t n, int32_t total_blocks, void* stream) {
+  if (!items || n <= 0 || total_blocks <= 0) return DV_EINVAL;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_reduce_multi_kernel<T>), dim3(total_blocks), dim3(kThreads), 0, ST(stream), items, n));
+  return dv_launch_status();
+}
+extern "C" int dv_bn_bwd_apply_multi(int32_t dtype, const dv_bn_item* items, int32_t n, int32_t total_blocks, int32_t max_c,
+                                     void* stream) {
+  if (!items || n <= 0 || total_blocks <= 0 || max_c <= 0) return DV_EINVAL;
+  const int CP = cp8(max_c);
+  if (3 * CP * 4 > 60 * 1024) return DV_EUNSUPPORTED;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_multi_kernel<T>), dim3(total_blocks), dim3(kThreads), 3 * CP * sizeof(float),
+                                       ST(stream), items, n));
   return dv_launch_status();
 }
 

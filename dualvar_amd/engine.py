@@ -509,6 +509,58 @@ class BNGroupOp(Op):
             return []
         return [('res%d' % i, m.res) for i, m in enumerate(self.members) if m.res is not None and m.res.grad is not None]
 
+    def _multi(self, R, f_red, f_app, b_red, b_app):
+        p, st, lib = self.plan, self.plan.store, self.plan.lib
+        V = 4 if p.dtype == DV_F32 else 8
+        arr = (L.BnItem * len(self.members))()
+        ends = [0, 0, 0, 0]
+        for i, m in enumerate(self.members):
+            it, bn, x, y, res = arr[i], m.bn, m.x, m.y, m.res
+            gs, bs = st.slot(bn.weight), st.slot(bn.bias)
+            it.partials = m.conv.stats.data_ptr() + 4 * (x.off - m.conv.y.off)
+            it.local_stats = self.local.data_ptr() + 4 * m.loff
+            it.gamma, it.beta = st.w_master(gs), st.w_master(bs)
+            it.running_mean = bn.running_mean.data_ptr() if bn.running_mean is not None else 0
+            it.running_var = bn.running_var.data_ptr() if bn.running_var is not None else 0
+            it.mean, it.invstd, it.scale, it.shift = (t.data_ptr() for t in (m.mean, m.invstd, m.scale, m.shift))
+            it.x, it.ldx, it.y, it.ldy = x.ptr, x.ld, y.ptr, y.ld
+            it.residual, it.ldr = (res.ptr, res.ld) if res is not None else (0, 0)
+            it.M, it.C, it.n_tiles, it.tile_rows, it.pitch = m.M, m.C, m.conv.tiles, 128, m.conv.slot.Cout
+            it.eps, it.momentum = float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1)
+            it.fwd_flags = DV_RELU if m.relu else 0
+            total = m.M * (m.CP // V)
+            ends[0] += m.C
+            ends[1] += max(1, min(4096, (total + 255) // 256))
+            it.blk_stats, it.blk_apply = ends[0], ends[1]
+            if p.with_grad:
+                dres = res.grad if (res is not None and res.grad is not None) else None
+                mflag = 0 if m.relu else DV_NO_RELU_MASK
+                it.dy, it.lddy, it.dx, it.lddx = y.grad.ptr, y.grad.ld, x.grad.ptr, x.grad.ld
+                it.dres, it.lddres = (dres.ptr, dres.ld) if dres is not None else (0, 0)
+                it.sums, it.n_rep = p.zero_ptr(m.sums_off), BN_REPLICAS
+                it.dgamma, it.dbeta = st.w_grad(gs), st.w_grad(bs)
+                it.inv_count, it.dparam_scale = 1.0 / (m.M * R), 1.0 / R
+                it.bwd_flags = mflag | (DV_ACCUM if (dres is not None and self.acc.get('res%d' % i)) else 0)
+                ends[2] += lib.dv_bn_bwd_blocks(m.M, m.C)
+                ends[3] += max(1, min(2048, (total + 255) // 256))
+                it.blk_red, it.blk_bapply = ends[2], ends[3]
+        self._items = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(p.device)
+        p.bytes += self._items.numel()
+        tab, n, dt = self._items.data_ptr(), len(self.members), _dt(p.dtype)
+
+        def tot(lst, attr):
+            return sum(getattr(l, attr) for l in lst)
+        f_red = [Launch('bn_stats_multi', 'bn_stats_multi', lib.dv_bn_stats_multi, (tab, n, 1 if R == 1 else 0, ends[0]),
+                        tot(f_red, 'bytes'))]
+        f_app = [Launch('bn_apply_multi', 'bn_apply_multi<%s>' % dt, lib.dv_bn_apply_multi, (p.dtype, tab, n, ends[1]),
+                        tot(f_app, 'bytes'))]
+        if p.with_grad:
+            b_red = [Launch('bn_bwd_reduce_multi', 'bn_bwd_reduce_multi<%s>' % dt, lib.dv_bn_bwd_reduce_multi,
+                            (p.dtype, tab, n, ends[2]), tot(b_red, 'bytes'))]
+            b_app = [Launch('bn_bwd_apply_multi', 'bn_bwd_apply_multi<%s>' % dt, lib.dv_bn_bwd_apply_multi,
+                            (p.dtype, tab, n, ends[3], max(m.C for m in self.members)), tot(b_app, 'bytes'))]
+        return f_red, f_app, b_red, b_app
+
     def launches(self):
         p, st, lib = self.plan, self.plan.store, self.plan.lib
         R, dt = p.comm.world, _dt(p.dtype)
@@ -556,6 +608,9 @@ class BNGroupOp(Op):
                                      x.grad.ptr, x.grad.ld, dres.ptr if dres is not None else 0,
                                      dres.ld if dres is not None else 0, M, Cn, bflags), _abytes(x) * (nact + 1 + nres), 0,
                                     'M%d C%d' % (M, Cn)))
+        if len(self.members) > 1:
+            # multi-tensor launches: one per phase for the whole group (the layers are small and latency bound)
+            f_red, f_app, b_red, b_app = self._multi(R, f_red, f_app, b_red, b_app)
         f = list(f_red)
         b = list(b_red)
         if R > 1:

@@ -153,6 +153,25 @@ int dv_bn_finalize(const float* stats /*[R] rows of (sum[C], M2[C], count), row 
 int dv_bn_apply(int32_t dtype, const void* x, int32_t ldx, const float* scale, const float* shift,
                 const void* residual, int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t C,
                 int32_t flags, void* stream);
+/* Multi-tensor forms: the independent BatchNorm layers of one group (e.g. the four branch-entry BNs of an Inception
+ * block) in ONE launch per phase.  `items` is a DEVICE array; blk_* are running block-count prefixes per phase
+ * (stats: C blocks per item; apply / bwd_apply: ceil(M*CP/V/256) capped; bwd_reduce: dv_bn_bwd_blocks). */
+typedef struct dv_bn_item {
+  const float* partials; float* local_stats; const float* gamma; const float* beta;
+  float* running_mean; float* running_var; float* mean; float* invstd; float* scale; float* shift;
+  const void* x; const void* residual; void* y; const void* dy; void* dx; void* dres;
+  float* sums; float* dgamma; float* dbeta;
+  int64_t M;
+  int32_t n_tiles, tile_rows, pitch, C, ldx, ldr, ldy, lddy, lddx, lddres;
+  int32_t fwd_flags, bwd_flags, n_rep;
+  float eps, momentum, inv_count, dparam_scale;
+  int32_t blk_stats, blk_apply, blk_red, blk_bapply;
+} dv_bn_item;
+int dv_bn_stats_multi(const dv_bn_item* items, int32_t n, int32_t finalize, int32_t total_blocks, void* stream);
+int dv_bn_apply_multi(int32_t dtype, const dv_bn_item* items, int32_t n, int32_t total_blocks, void* stream);
+int dv_bn_bwd_reduce_multi(int32_t dtype, const dv_bn_item* items, int32_t n, int32_t total_blocks, void* stream);
+int dv_bn_bwd_apply_multi(int32_t dtype, const dv_bn_item* items, int32_t n, int32_t total_blocks, int32_t max_c,
+                          void* stream);
 int dv_bn_bwd_blocks(int64_t M, int32_t C);
 int dv_bn_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                      int32_t ldx, const float* mean, const float* invstd, int64_t M, int32_t C,
