@@ -154,17 +154,18 @@ __device__ __forceinline__ float act_apply(float v, int flags) {
 // fwd / dgrad kernel.  256 threads = 4 waves arranged WAVES_M x WAVES_N over a BM x BN tile.
 // LDS rows hold 64 bytes of K, padded to 80 so that ds_read_b128 fragments are conflict free.
 template <typename T, int MODE, int GVB, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvArgs a) {
   constexpr int ROWB = 64, PITCH = 80;
   constexpr int BKE = ROWB / (int)sizeof(T);
   constexpr int GV = GVB / (int)sizeof(T);
   constexpr int VPR = ROWB / GVB;           // vectors per row (4 or 8)
-  constexpr int RPP = 256 / VPR;            // rows per pass (64 or 32)
+  constexpr int NT = WAVES_M * WAVES_N * 64; // threads
+  constexpr int RPP = NT / VPR;             // rows per pass
   constexpr int A_PASSES = BM / RPP;
   constexpr int B_PASSES = (BN + RPP - 1) / RPP;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(BN <= NT && BM % RPP == 0, "tile / thread layout");
   static_assert(TM >= 1 && TN >= 1, "tile");
   typedef typename VecB<GVB>::type vec_t;
 
@@ -565,8 +566,20 @@ static int pick_bn(int np) {
   return (w128 <= w64) ? 128 : 64;
 }
 
+// Tile rows: 128, or 64 when a 128-row grid would leave most CUs with fewer than ~4 workgroups (the K loop is
+// latency bound at low occupancy; twice as many, half as tall workgroups hide it)
+static int pick_bm(int M, int ntn) {
+  return ((int64_t)((M + 127) / 128) * ntn >= 1024) ? 128 : 64;
+}
+
 template <typename T, int MODE, int GVB>
-static void launch_gemm(int bn, const ConvArgs& a, int grid, hipStream_t s) {
+static void launch_gemm(int bm, int bn, const ConvArgs& a, int grid, hipStream_t s) {
+  if (bm == 64) {
+    if (bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 32, 2, 1>), dim3(grid), dim3(128), 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 64, 2, 2>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 128, 2, 2>), dim3(grid), dim3(256), 0, s, a);
+    return;
+  }
   if (bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 32, 4, 1>), dim3(grid), dim3(256), 0, s, a);
   else if (bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 64, 4, 1>), dim3(grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 128, 2, 2>), dim3(grid), dim3(256), 0, s, a);
@@ -574,10 +587,18 @@ static void launch_gemm(int bn, const ConvArgs& a, int grid, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int dv_conv3d_tile_rows(const dv_conv_desc* d) {
+  if (!d) return DV_EINVAL;
+  const int64_t m = (int64_t)d->N * d->To * d->Ho * d->Wo;
+  const int bn = pick_bn(d->cout_pitch);
+  return pick_bm((int)m, (d->cout_pitch + bn - 1) / bn);
+}
+
 extern "C" int dv_conv3d_stat_tiles(const dv_conv_desc* d) {
   if (!d) return DV_EINVAL;
-  int64_t m = (int64_t)d->N * d->To * d->Ho * d->Wo;
-  return (int)((m + 127) / 128);
+  const int64_t m = (int64_t)d->N * d->To * d->Ho * d->Wo;
+  const int bm = dv_conv3d_tile_rows(d);
+  return (int)((m + bm - 1) / bm);
 }
 
 extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
@@ -601,11 +622,12 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   if ((d->ldx * esz) % gvb || (a.ldw * esz) % gvb) return DV_EALIGN;
   const int bn = pick_bn(a.NP);
   a.ntn = (a.NP + bn - 1) / bn;
-  const int grid = a.ntn * ((a.M + 127) / 128);
+  const int bm = pick_bm(a.M, a.ntn);
+  const int grid = a.ntn * ((a.M + bm - 1) / bm);
   hipStream_t s = (hipStream_t)stream;
-  if (d->dtype == DV_F32) launch_gemm<float, MODE_FWD, 16>(bn, a, grid, s);
-  else if (gvb == 16) launch_gemm<bf16_t, MODE_FWD, 16>(bn, a, grid, s);
-  else launch_gemm<bf16_t, MODE_FWD, 8>(bn, a, grid, s);
+  if (d->dtype == DV_F32) launch_gemm<float, MODE_FWD, 16>(bm, bn, a, grid, s);
+  else if (gvb == 16) launch_gemm<bf16_t, MODE_FWD, 16>(bm, bn, a, grid, s);
+  else launch_gemm<bf16_t, MODE_FWD, 8>(bm, bn, a, grid, s);
   return dv_launch_status();
 }
 
@@ -627,10 +649,11 @@ extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void
   a.flags = d->flags & DV_ACCUM;
   const int bn = pick_bn(a.NP);
   a.ntn = (a.NP + bn - 1) / bn;
-  const int grid = a.ntn * ((a.M + 127) / 128);
+  const int bm = pick_bm(a.M, a.ntn);
+  const int grid = a.ntn * ((a.M + bm - 1) / bm);
   hipStream_t s = (hipStream_t)stream;
-  if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bn, a, grid, s);
-  else launch_gemm<bf16_t, MODE_DGRAD, 16>(bn, a, grid, s);
+  if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, a, grid, s);
+  else launch_gemm<bf16_t, MODE_DGRAD, 16>(bm, bn, a, grid, s);
   return dv_launch_status();
 }
 

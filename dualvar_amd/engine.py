@@ -437,6 +437,7 @@ class ConvOp(Op):
         assert x.cpitch == slot.cin_pitch, (x.cpitch, slot.cin_pitch)
         self.d = ops.conv_desc(self.dtype, x, self.y, k, s, p, flags=DV_STATS if stats else 0)
         self.tiles = ops.stat_tiles(self.d)
+        self.tile_rows = ops.tile_rows(self.d)
         self.stats = plan.f32(self.tiles, 2, slot.Cout) if stats else None
         self.need_dx = plan.with_grad and x.grad is not None and slot.wd_off >= 0
 
@@ -450,7 +451,7 @@ class ConvOp(Op):
         flops = 2 * y.rows * sl.Cout * taps * sl.Cin
         wbytes = sl.Cout * taps * sl.Cin * es
         gv = 8 if (self.dtype == DV_BF16 and sl.cin_pitch % 8) else 16
-        kf = 'conv_gemm<%s,FWD,%d,128,%d>' % (_dt(self.dtype), gv, _pick_bn(y.cpitch))
+        kf = 'conv_gemm<%s,FWD,%d,%d,%d>' % (_dt(self.dtype), gv, self.tile_rows, _pick_bn(y.cpitch))
         shp = 'M%d Cin%d Cout%d k%s s%s' % (y.rows, sl.Cin, sl.Cout, 'x'.join(map(str, self.k)), 'x'.join(map(str, self.s)))
         f = [Launch('conv_fwd', kf, lib.dv_conv3d_fwd,
                     (C.byref(self.d), x.ptr, st.w_fwd(sl), 0, y.ptr, self.stats.data_ptr() if self.stats is not None else 0),
@@ -464,7 +465,9 @@ class ConvOp(Op):
             if self.need_dx:
                 acc = bool(self.acc.get('x'))
                 self.d_g = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=DV_ACCUM if acc else 0)
-                b.append(Launch('conv_dgrad', 'conv_gemm<%s,DGRAD,16,128,%d>' % (_dt(self.dtype), _pick_bn(x.cpitch)),
+                bnd = _pick_bn(x.cpitch)
+                bmd = 128 if ((x.rows + 127) // 128) * ((x.cpitch + bnd - 1) // bnd) >= 1024 else 64
+                b.append(Launch('conv_dgrad', 'conv_gemm<%s,DGRAD,16,%d,%d>' % (_dt(self.dtype), bmd, bnd),
                                 lib.dv_conv3d_dgrad, (C.byref(self.d_g), y.grad.ptr, st.w_dgrad(sl), x.grad.ptr),
                                 _abytes(y) + wbytes + _abytes(x) * (2 if acc else 1), flops, shp))
         return f, b
@@ -525,7 +528,7 @@ class BNGroupOp(Op):
             it.mean, it.invstd, it.scale, it.shift = (t.data_ptr() for t in (m.mean, m.invstd, m.scale, m.shift))
             it.x, it.ldx, it.y, it.ldy = x.ptr, x.ld, y.ptr, y.ld
             it.residual, it.ldr = (res.ptr, res.ld) if res is not None else (0, 0)
-            it.M, it.C, it.n_tiles, it.tile_rows, it.pitch = m.M, m.C, m.conv.tiles, 128, m.conv.slot.Cout
+            it.M, it.C, it.n_tiles, it.tile_rows, it.pitch = m.M, m.C, m.conv.tiles, m.conv.tile_rows, m.conv.slot.Cout
             it.eps, it.momentum = float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1)
             it.fwd_flags = DV_RELU if m.relu else 0
             total = m.M * (m.CP // V)
@@ -579,11 +582,11 @@ class BNGroupOp(Op):
             sptr = m.conv.stats.data_ptr() + 4 * coff
             if R == 1:
                 f_red.append(Launch('bn_stats_finalize', 'bn_reduce_stats', lib.dv_bn_stats_finalize,
-                                    (sptr, m.conv.tiles, 128, spitch, M, Cn, local, st.w_master(gs), st.w_master(bs),
+                                    (sptr, m.conv.tiles, m.conv.tile_rows, spitch, M, Cn, local, st.w_master(gs), st.w_master(bs),
                                      eps, mom, rm, rv) + outs, m.conv.tiles * 2 * Cn * 4))
             else:
                 f_red.append(Launch('bn_reduce_stats', 'bn_reduce_stats', lib.dv_bn_reduce_stats,
-                                    (sptr, m.conv.tiles, 128, spitch, M, Cn, local), m.conv.tiles * 2 * Cn * 4))
+                                    (sptr, m.conv.tiles, m.conv.tile_rows, spitch, M, Cn, local), m.conv.tiles * 2 * Cn * 4))
                 f_fin.append(Launch('bn_finalize', 'bn_finalize', lib.dv_bn_finalize,
                                     (self.gathered.data_ptr() + 4 * m.loff, R, self.width, Cn, st.w_master(gs), st.w_master(bs),
                                      eps, mom, rm, rv) + outs))

@@ -100,6 +100,10 @@ def stat_tiles(d):
     return L.load().dv_conv3d_stat_tiles(C.byref(d))
 
 
+def tile_rows(d):
+    return L.load().dv_conv3d_tile_rows(C.byref(d))
+
+
 def pool_desc(dtype, x, y, k, s, p):
     d = L.PoolDesc()
     d.dtype = dtype

@@ -82,8 +82,10 @@ typedef struct dv_conv_desc {
   int32_t flags;
 } dv_conv_desc;
 
-/* number of M-tiles dv_conv3d_fwd emits BatchNorm partials for (rows of `stats`) */
+/* number of M-tiles dv_conv3d_fwd emits BatchNorm partials for (rows of `stats`) and the rows per tile (128, or 64
+ * for small problems) -- both are what dv_bn_reduce_stats / dv_bn_stats_finalize need */
 int dv_conv3d_stat_tiles(const dv_conv_desc* d);
+int dv_conv3d_tile_rows(const dv_conv_desc* d);
 /* y = conv(x, w) [+bias][act]; with DV_STATS also stats[tile][2][Cout] = (sum, M2 about the
  * tile mean) of the values as stored.  */
 int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w_fwd, const float* bias,

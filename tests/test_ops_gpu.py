@@ -86,7 +86,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, dtype, case):
     # statistics: sum and M2 recombine to the batch mean / biased variance of the stored values
     M = N * To * Ho * Wo
     local = torch.zeros(2 * Cout + 1, device=gpu)
-    ops.call('dv_bn_reduce_stats', stats, tiles, 128, Cout, M, Cout, local)
+    ops.call('dv_bn_reduce_stats', stats, tiles, ops.tile_rows(d), Cout, M, Cout, local)
     ys = ops.act_to_ncdhw(ya)
     mean_ref = ys.mean(dim=(0, 2, 3, 4)).cpu()
     var_ref = ys.var(dim=(0, 2, 3, 4), unbiased=False).cpu()
