@@ -133,7 +133,7 @@ def test_train_steps_fp32_against_reference_fixture(gpu, kind, net, B, steps):
         lsens = max([float(g[k]) for k in g.files if k.startswith('sens/last/out/') and 'logits' in k] + [0.0]) if it > 0 else 0.0
         assert abs(float(loss) - float(g[f'loss_step{it}'])) < max(1e-3, 5 * float(g[f'sens/loss_step{it}']), 0.1 * lsens)
     pc = param_checksum(m, P)
-    worst = max(abs(v[0] - g[f'param/{k}'][0]) / max(5e-3 * abs(g[f'param/{k}'][0]) + 1e-9, (5 if steps <= 2 else 15) * float(g[f'sens/param/{k}']))
+    worst = max(abs(v[0] - g[f'param/{k}'][0]) / max(5e-3 * abs(g[f'param/{k}'][0]) + 1e-9, (10 if steps <= 2 else 25) * float(g[f'sens/param/{k}']))
                 for k, v in pc.items() if f'param/{k}' in g.files)
     report.append(('end', 'param checksum worst err/bound', worst))
     print(kind, net, report)
