@@ -117,6 +117,15 @@ __device__ __forceinline__ int src_pos(const RowPos& r, const KCursor& k, const 
   return ok ? r.base + (t * g.sH + h) * g.sW + w : -1;
 }
 
+// Blocks are dealt round-robin over the 8 XCDs (private L2 each): blocks b and b+8 share an XCD.  Remap so that each
+// XCD gets a CONTIGUOUS range of logical tiles -- the tiles that re-read the same rows (all N tiles of one M tile,
+// all (i,j) tiles of one wgrad row split) then hit the same L2.  Bijective for any grid size.  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   // one K-tile = 64 bytes = 32 bf16 per row: two 32x32x16 steps
@@ -176,7 +185,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int tile_n = blockIdx.x % a.ntn, tile_m = blockIdx.x / a.ntn;
+  const int lbid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_n = lbid % a.ntn, tile_m = lbid / a.ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
 
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  int bid = blockIdx.x;
+  int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int tile_j = bid % a.ntj; bid /= a.ntj;
   const int tile_i = bid % a.nti;
   const int split = bid / a.nti;
