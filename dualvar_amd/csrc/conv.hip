@@ -50,9 +50,9 @@ template <> struct VecB<8> { typedef uint2 type; static __device__ __forceinline
 
 // Per-thread cursor over the k axis of the im2col matrix for one fixed vector slot.
 struct KCursor {
-  int c, dt, dh, dw;
+  int c, dt, dh, dw, tap;
   __device__ __forceinline__ void init(int k0, const ConvGeom& g) {
-    int tap = k0 / g.CP;
+    tap = k0 / g.CP;
     c = k0 - tap * g.CP;
     dw = tap % g.kw;
     int t2 = tap / g.kw;
@@ -63,6 +63,7 @@ struct KCursor {
     c += step;
     while (c >= g.CP) {
       c -= g.CP;
+      ++tap;
       if (++dw == g.kw) {
         dw = 0;
         if (++dh == g.kh) { dh = 0; ++dt; }
@@ -203,11 +204,43 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   const int nk = (g.Ktot + BKE - 1) / BKE;
   vec_t ra[A_PASSES], rb[B_PASSES];
 
-  auto gload = [&](int kt_idx) {
+  // Per-row validity of every tap, computed once: the K loop then needs one shift + one add per row instead of the
+  // full coordinate arithmetic (the gather was VALU bound: ~20 VALU instructions per MFMA).  Usable when the source
+  // position is linear in the tap (always for FWD; for DGRAD when all strides are 1) and there are <= 64 taps.
+  const int ntaps = g.kt * g.kh * g.kw;
+  const bool lin = ntaps <= 64 && (MODE == MODE_FWD || (g.st == 1 && g.sh == 1 && g.sw == 1));
+  unsigned long long rmask[A_PASSES];
+  int rlin[A_PASSES];
+  if (lin) {
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
-      int pos = src_pos<MODE>(rows[p], kc, g);
-      ra[p] = pos >= 0 ? *reinterpret_cast<const vec_t*>(src + (size_t)pos * a.lds_ + kc.c) : VecB<GVB>::zero();
+      unsigned long long mk = 0;
+      KCursor t;
+      t.c = 0; t.dt = t.dh = t.dw = 0; t.tap = 0;
+      for (int tp = 0; tp < ntaps; ++tp) {
+        if (src_pos<MODE>(rows[p], t, g) >= 0) mk |= 1ull << tp;
+        if (++t.dw == g.kw) { t.dw = 0; if (++t.dh == g.kh) { t.dh = 0; ++t.dt; } }
+      }
+      rmask[p] = mk;
+      rlin[p] = rows[p].base + (rows[p].t0 * g.sH + rows[p].h0) * g.sW + rows[p].w0;
+    }
+  }
+  auto gload = [&](int kt_idx) {
+    if (lin) {
+      const int toff = (kc.dt * g.sH + kc.dh) * g.sW + kc.dw;
+      const bool tin = kc.tap < ntaps;
+#pragma unroll
+      for (int p = 0; p < A_PASSES; ++p) {
+        const bool ok = tin && ((rmask[p] >> kc.tap) & 1ull);
+        const int pos = MODE == MODE_FWD ? rlin[p] + toff : rlin[p] - toff;
+        ra[p] = ok ? *reinterpret_cast<const vec_t*>(src + (size_t)pos * a.lds_ + kc.c) : VecB<GVB>::zero();
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < A_PASSES; ++p) {
+        int pos = src_pos<MODE>(rows[p], kc, g);
+        ra[p] = pos >= 0 ? *reinterpret_cast<const vec_t*>(src + (size_t)pos * a.lds_ + kc.c) : VecB<GVB>::zero();
+      }
     }
     const int kk = kt_idx * BKE + vslot * GV;
 #pragma unroll
