@@ -202,7 +202,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   kc.init(vslot * GV, g);
 
   const int nk = (g.Ktot + BKE - 1) / BKE;
-  vec_t raA[A_PASSES], rbA[B_PASSES], raB[A_PASSES], rbB[B_PASSES];   // two tiles in flight
+  vec_t ra[A_PASSES], rb[B_PASSES];
 
   // Per-row validity of every tap, computed once: the K loop then needs one shift + one add per row instead of the
   // full coordinate arithmetic (the gather was VALU bound: ~20 VALU instructions per MFMA).  Usable when the source
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
       rlin[p] = rows[p].base + (rows[p].t0 * g.sH + rows[p].h0) * g.sW + rows[p].w0;
     }
   }
-  auto gload = [&](int kt_idx, vec_t (&ra)[A_PASSES], vec_t (&rb)[B_PASSES]) {
+  auto gload = [&](int kt_idx) {
     if (lin) {
       const int toff = (kc.dt * g.sH + kc.dh) * g.sW + kc.dw;
       const bool tin = kc.tap < ntaps;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
       rb[p] = ok ? *reinterpret_cast<const vec_t*>(wgt + (size_t)n * a.ldw + kk) : VecB<GVB>::zero();
     }
   };
-  auto lstore = [&](int buf, const vec_t (&ra)[A_PASSES], const vec_t (&rb)[B_PASSES]) {
+  auto lstore = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p)
       *reinterpret_cast<vec_t*>(smem + buf * BUFB + (vrow + p * RPP) * PITCH + vslot * GVB) = ra[p];
@@ -270,31 +270,23 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto compute = [&](int cur) {
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt_idx = 0; kt_idx < nk; ++kt_idx) {
+    const int cur = kt_idx & 1;
+    if (kt_idx + 1 < nk) {
+      kc.advance(BKE, g);
+      gload(kt_idx + 1);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         Mma<T>::tile(smem + cur * BUFB + (wm0 + i * 32 + l31) * PITCH,
                      smem + cur * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, acc[i][j]);
-  };
-  // K loop, two K-tiles ahead in registers (sets A and B) + double-buffered LDS: the loads of tile t+2 are issued
-  // before tile t is consumed, so a workgroup tolerates ~2 iterations of memory latency
-  gload(0, raA, rbA);
-  if (nk > 1) { kc.advance(BKE, g); gload(1, raB, rbB); }
-  lstore(0, raA, rbA);
-  __syncthreads();
-  for (int kt_idx = 0; kt_idx < nk; kt_idx += 2) {
-    if (kt_idx + 2 < nk) { kc.advance(BKE, g); gload(kt_idx + 2, raA, rbA); }
-    compute(0);
-    if (kt_idx + 1 < nk) lstore(1, raB, rbB);
+    if (kt_idx + 1 < nk) lstore(cur ^ 1);
     __syncthreads();
-    if (kt_idx + 1 < nk) {
-      if (kt_idx + 3 < nk) { kc.advance(BKE, g); gload(kt_idx + 3, raB, rbB); }
-      compute(1);
-      if (kt_idx + 2 < nk) lstore(0, raA, rbA);
-      __syncthreads();
-    }
   }
 
   // ---------------- epilogue
