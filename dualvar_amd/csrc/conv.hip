@@ -41,6 +41,8 @@ struct ConvArgs {
   int lds_, ldo, ldw;    // pitches in elements (src, out, weights)
   int ntn;               // number of N tiles
   int flags;
+  int src_bytes, w_bytes; // extents for the buffer descriptors (< 2 GiB)
+  FastDiv fCP;           // k -> (tap, c)
   ConvGeom g;
 };
 
@@ -192,63 +194,96 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
 
   const int vslot = tid % VPR, vrow = tid / VPR;
-  const T* src = reinterpret_cast<const T*>(a.src);
-  const T* wgt = reinterpret_cast<const T*>(a.w);
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  constexpr int ES = (int)sizeof(T);
+  constexpr unsigned kOOB = 0x80000000u;      // beyond every buffer (tensors are < 2 GiB): the load returns zeros
 
-  RowPos rows[A_PASSES];
+  // ---- gather set-up -------------------------------------------------------------------------------------------
+  // The K loop used to spend ~50 scalar/vector instructions and 19 branches per MFMA on coordinate arithmetic and
+  // zero-fill selects.  Now: (1) loads go through buffer descriptors, so an invalid tap is just an out-of-range
+  // offset and the hardware returns zeros (no branch, no select); (2) tap validity is separable, valid(dt,dh,dw) =
+  // vt(dt)&vh(dh)&vw(dw), kept as three small bit masks per row; (3) the source offset of a tap is linear in the tap
+  // (for dgrad with stride 2 in the halved coordinates), looked up from a per-kernel LDS table.
+  __shared__ int2 taptab[256];
+  const int ntaps = g.kt * g.kh * g.kw;
+  {
+    const int st_s = g.st - 1, sh_s = g.sh - 1, sw_s = g.sw - 1;     // strides are 1 or 2 on the dgrad path
+    for (int tp = tid; tp < ntaps; tp += NT) {
+      const int dw = tp % g.kw, t2 = tp / g.kw, dh = t2 % g.kh, dt = t2 / g.kh;
+      const int toff = MODE == MODE_FWD ? (dt * g.sH + dh) * g.sW + dw
+                                        : -(((dt >> st_s) * g.sH + (dh >> sh_s)) * g.sW + (dw >> sw_s));
+      taptab[tp] = make_int2(toff, dt | (dh << 8) | (dw << 16));
+    }
+  }
+  const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src), 0, a.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
+  const unsigned ldb = (unsigned)a.lds_ * ES;
+
+  unsigned rowoff[A_PASSES], mt[A_PASSES], mh[A_PASSES], mw[A_PASSES];
 #pragma unroll
-  for (int p = 0; p < A_PASSES; ++p) rows[p] = decode_row<MODE>((uint32_t)(m0 + vrow + p * RPP), a.M, g);
-  KCursor kc;
-  kc.init(vslot * GV, g);
+  for (int p = 0; p < A_PASSES; ++p) {
+    const RowPos r = decode_row<MODE>((uint32_t)(m0 + vrow + p * RPP), a.M, g);
+    unsigned bt = 0, bh = 0, bw = 0;
+    int pos;
+    if (MODE == MODE_FWD) {
+      for (int d = 0; d < g.kt; ++d) bt |= ((unsigned)(r.t0 + d) < (unsigned)g.sT ? 1u : 0u) << d;
+      for (int d = 0; d < g.kh; ++d) bh |= ((unsigned)(r.h0 + d) < (unsigned)g.sH ? 1u : 0u) << d;
+      for (int d = 0; d < g.kw; ++d) bw |= ((unsigned)(r.w0 + d) < (unsigned)g.sW ? 1u : 0u) << d;
+      pos = r.base + (r.t0 * g.sH + r.h0) * g.sW + r.w0;
+    } else {
+      const int st_s = g.st - 1, sh_s = g.sh - 1, sw_s = g.sw - 1;
+      for (int d = 0; d < g.kt; ++d) { int v = r.t0 - d; bt |= ((v >= 0 && !(v & st_s) && (v >> st_s) < g.sT) ? 1u : 0u) << d; }
+      for (int d = 0; d < g.kh; ++d) { int v = r.h0 - d; bh |= ((v >= 0 && !(v & sh_s) && (v >> sh_s) < g.sH) ? 1u : 0u) << d; }
+      for (int d = 0; d < g.kw; ++d) { int v = r.w0 - d; bw |= ((v >= 0 && !(v & sw_s) && (v >> sw_s) < g.sW) ? 1u : 0u) << d; }
+      pos = r.base + ((r.t0 >> st_s) * g.sH + (r.h0 >> sh_s)) * g.sW + (r.w0 >> sw_s);
+    }
+    if (!r.valid) bt = 0;
+    mt[p] = bt; mh[p] = bh; mw[p] = bw;
+    rowoff[p] = (unsigned)pos * ldb;           // modulo 2^32; exact for every valid (row, tap)
+  }
+  unsigned woff[B_PASSES];
+#pragma unroll
+  for (int p = 0; p < B_PASSES; ++p) {
+    const int r = vrow + p * RPP, n = n0 + r;
+    woff[p] = (r < BN && n < a.N) ? (unsigned)n * (unsigned)a.ldw * ES : kOOB;
+  }
+  __syncthreads();                             // taptab
 
   const int nk = (g.Ktot + BKE - 1) / BKE;
   vec_t ra[A_PASSES], rb[B_PASSES];
 
-  // Per-row validity of every tap, computed once: the K loop then needs one shift + one add per row instead of the
-  // full coordinate arithmetic (the gather was VALU bound: ~20 VALU instructions per MFMA).  Usable when the source
-  // position is linear in the tap (always for FWD; for DGRAD when all strides are 1) and there are <= 64 taps.
-  const int ntaps = g.kt * g.kh * g.kw;
-  const bool lin = ntaps <= 64 && g.CP >= BKE && (MODE == MODE_FWD || (g.st == 1 && g.sh == 1 && g.sw == 1));
-  unsigned long long rmask[A_PASSES];
-  int rlin[A_PASSES];
-  if (lin) {
+  auto gload = [&](int kt_idx) {
+    const unsigned k = (unsigned)(kt_idx * BKE + vslot * GV);
+    const unsigned tap = fd_div(k, a.fCP);
+    const unsigned c = k - tap * (unsigned)g.CP;
+    const bool tin = (int)tap < ntaps;
+    const int2 ti = taptab[tin ? tap : 0];
+    const unsigned dt = ti.y & 255, dh = (ti.y >> 8) & 255, dw = (unsigned)ti.y >> 16;
+    const unsigned tb = (unsigned)ti.x * ldb + c * ES;
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
-      unsigned long long mk = 0;
-      KCursor t;
-      t.c = 0; t.dt = t.dh = t.dw = 0; t.tap = 0;
-      for (int tp = 0; tp < ntaps; ++tp) {
-        if (src_pos<MODE>(rows[p], t, g) >= 0) mk |= 1ull << tp;
-        if (++t.dw == g.kw) { t.dw = 0; if (++t.dh == g.kh) { t.dh = 0; ++t.dt; } }
-      }
-      rmask[p] = mk;
-      rlin[p] = rows[p].base + (rows[p].t0 * g.sH + rows[p].h0) * g.sW + rows[p].w0;
-    }
-  }
-  auto gload = [&](int kt_idx) {
-    if (lin) {
-      const int toff = (kc.dt * g.sH + kc.dh) * g.sW + kc.dw;
-      const bool tin = kc.tap < ntaps;
-#pragma unroll
-      for (int p = 0; p < A_PASSES; ++p) {
-        const bool ok = tin && ((rmask[p] >> kc.tap) & 1ull);
-        const int pos = MODE == MODE_FWD ? rlin[p] + toff : rlin[p] - toff;
-        ra[p] = ok ? *reinterpret_cast<const vec_t*>(src + (size_t)pos * a.lds_ + kc.c) : VecB<GVB>::zero();
-      }
-    } else {
-#pragma unroll
-      for (int p = 0; p < A_PASSES; ++p) {
-        int pos = src_pos<MODE>(rows[p], kc, g);
-        ra[p] = pos >= 0 ? *reinterpret_cast<const vec_t*>(src + (size_t)pos * a.lds_ + kc.c) : VecB<GVB>::zero();
+      const unsigned ok = (mt[p] >> dt) & (mh[p] >> dh) & (mw[p] >> dw) & (tin ? 1u : 0u);
+      const unsigned off = ok ? rowoff[p] + tb : kOOB;
+      if constexpr (GVB == 16) {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, off, 0, 0);
+        ra[p] = make_uint4(v.x, v.y, v.z, v.w);
+      } else {
+        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(src_rsrc, off, 0, 0);
+        ra[p] = make_uint2(v.x, v.y);
       }
     }
-    const int kk = kt_idx * BKE + vslot * GV;
+    const unsigned kb = (k < (unsigned)g.Ktot) ? k * ES : kOOB;
 #pragma unroll
     for (int p = 0; p < B_PASSES; ++p) {
-      int r = vrow + p * RPP;
-      int n = n0 + r;
-      bool ok = (r < BN) && (n < a.N) && (kk < g.Ktot);
-      rb[p] = ok ? *reinterpret_cast<const vec_t*>(wgt + (size_t)n * a.ldw + kk) : VecB<GVB>::zero();
+      const unsigned off = (woff[p] | kb) >= kOOB ? kOOB : woff[p] + kb;
+      if constexpr (GVB == 16) {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off, 0, 0);
+        rb[p] = make_uint4(v.x, v.y, v.z, v.w);
+      } else {
+        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, off, 0, 0);
+        rb[p] = make_uint2(v.x, v.y);
+      }
     }
   };
   auto lstore = [&](int buf) {
@@ -275,10 +310,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   __syncthreads();
   for (int kt_idx = 0; kt_idx < nk; ++kt_idx) {
     const int cur = kt_idx & 1;
-    if (kt_idx + 1 < nk) {
-      kc.advance(BKE, g);
-      gload(kt_idx + 1);
-    }
+    if (kt_idx + 1 < nk) gload(kt_idx + 1);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -659,6 +691,15 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   a.N = d->Cout; a.NP = d->cout_pitch;
   a.lds_ = d->ldx; a.ldo = d->ldy; a.ldw = a.g.Ktot;
   a.flags = d->flags & (DV_BIAS | DV_RELU | DV_SIGMOID | DV_STATS);
+  {
+    const int64_t es = d->dtype == DV_F32 ? 4 : 2;
+    const int64_t sb = ((int64_t)d->N * d->Ti * d->Hi * d->Wi - 1) * d->ldx * es + (int64_t)d->cin_pitch * es;
+    const int64_t wb = (int64_t)d->Cout * a.g.Ktot * es;
+    if (sb >= (1ll << 31) || wb >= (1ll << 31) || d->kt > 32 || d->kh > 32 || d->kw > 32 || d->kt * d->kh * d->kw > 256)
+      return DV_EUNSUPPORTED;
+    a.src_bytes = (int)sb; a.w_bytes = (int)wb;
+    a.fCP = make_fastdiv((uint32_t)a.g.CP);
+  }
   const int gvb = gather_bytes(d->dtype, d->cin_pitch);
   if (gvb == 16 && !aligned16(x)) return DV_EALIGN;
   const int esz = d->dtype == DV_F32 ? 4 : 2;
@@ -690,6 +731,15 @@ extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void
   a.N = d->Cin; a.NP = d->cin_pitch;
   a.lds_ = d->ldy; a.ldo = d->ldx; a.ldw = a.g.Ktot;
   a.flags = d->flags & DV_ACCUM;
+  {
+    const int64_t es = d->dtype == DV_F32 ? 4 : 2;
+    const int64_t sb = ((int64_t)d->N * d->To * d->Ho * d->Wo - 1) * d->ldy * es + (int64_t)d->cout_pitch * es;
+    const int64_t wb = (int64_t)d->Cin * a.g.Ktot * es;
+    if (sb >= (1ll << 31) || wb >= (1ll << 31) || d->kt > 32 || d->kh > 32 || d->kw > 32 || d->kt * d->kh * d->kw > 256)
+      return DV_EUNSUPPORTED;
+    a.src_bytes = (int)sb; a.w_bytes = (int)wb;
+    a.fCP = make_fastdiv((uint32_t)a.g.CP);
+  }
   const int bn = pick_bn(a.NP);
   a.ntn = (a.NP + bn - 1) / bn;
   const int bm = pick_bm(a.M, a.ntn);
