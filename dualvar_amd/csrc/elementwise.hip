@@ -48,7 +48,7 @@ __global__ void ingest_kernel(const float* __restrict__ x, T* __restrict__ y, in
 }
 
 // ------------------------------------------------------------------ block reduce helper
-__device__ __forceinline__ float block_sum(float v, float* sh /*>= 4 floats*/) {
+__device__ __forceinline__ float block_sum(float v, float* sh /*>= blockDim/64 floats*/) {
   v = wave_sum(v);
   const int w = threadIdx.x >> 6;
   __syncthreads();
@@ -69,7 +69,7 @@ struct BnFinalize {
 __device__ __forceinline__ void bn_reduce_stats_body(const float* __restrict__ part, int n_tiles, int tile_rows, int P,
                                                      int64_t M, int C, float* __restrict__ out, int fin,
                                                      const BnFinalize& f, int c) {
-  __shared__ float sh[8];
+  __shared__ float sh[32];
   float s = 0.f;
   for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s += part[((size_t)i * 2) * P + c];
   const float S = block_sum(s, sh);
@@ -81,7 +81,7 @@ __device__ __forceinline__ void bn_reduce_stats_body(const float* __restrict__ p
     float d = part[((size_t)i * 2) * P + c] / n_i - mean;
     m2 += part[((size_t)i * 2 + 1) * P + c] + n_i * d * d;
   }
-  const float M2 = block_sum(m2, sh + 4);
+  const float M2 = block_sum(m2, sh + 16);
   if (threadIdx.x == 0) {
     out[c] = S;
     out[C + c] = M2;
@@ -761,8 +761,8 @@ extern "C" int dv_bn_reduce_stats(const float* partials, int32_t n_tiles, int32_
                                   int32_t C, float* local_stats, void* stream) {
   if (!partials || !local_stats || n_tiles <= 0 || C <= 0 || M <= 0 || pitch < C) return DV_EINVAL;
   BnFinalize f = {};
-  hipLaunchKernelGGL(bn_reduce_stats_kernel, dim3(C), dim3(kThreads), 0, ST(stream), partials, n_tiles, tile_rows, pitch, M, C,
-                     local_stats, 0, f);
+  hipLaunchKernelGGL(bn_reduce_stats_kernel, dim3(C), dim3(n_tiles >= 2048 ? 1024 : kThreads), 0, ST(stream), partials, n_tiles,
+                     tile_rows, pitch, M, C, local_stats, 0, f);
   return dv_launch_status();
 }
 
@@ -774,8 +774,8 @@ extern "C" int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int3
   if (!gamma || !beta || !mean || !invstd || !scale || !shift) return DV_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return DV_EINVAL;
   BnFinalize f = {gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
-  hipLaunchKernelGGL(bn_reduce_stats_kernel, dim3(C), dim3(kThreads), 0, ST(stream), partials, n_tiles, tile_rows, pitch, M, C,
-                     local_stats, 1, f);
+  hipLaunchKernelGGL(bn_reduce_stats_kernel, dim3(C), dim3(n_tiles >= 2048 ? 1024 : kThreads), 0, ST(stream), partials, n_tiles,
+                     tile_rows, pitch, M, C, local_stats, 1, f);
   return dv_launch_status();
 }
 

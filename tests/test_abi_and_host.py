@@ -146,3 +146,34 @@ def test_bench_cli_and_bucket_ranges():
     assert r[0] == (68, 100) and r[-1] == (0, 4) and sum(b - a for a, b in r) == 100
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True)
     assert out.returncode == 0 and '--gpus' in out.stdout and '--warmup' in out.stdout
+
+
+def test_checkpoint_interchange_with_reference_format(tmp_path):
+    """a reference-format checkpoint ({'epoch','state_dict',...}, reference key names) loads into
+    the HIP model and back, also after the parameters have been moved into the arena."""
+    import torch
+    from dualvar_amd import model as M
+    from dualvar_amd.ops import DV_F32
+    from dualvar_amd.utils.utils import neq_load_customized, save_checkpoint
+    from oracle import procedural as P, torch_ref as O
+    ref = O.SimCLR_TimeSeriesV4('s3dg', 128, 0.07, False)
+    P.procedural_init(ref)
+    ck = {'epoch': 3, 'state_dict': ref.state_dict(), 'best_acc': 0.0, 'iteration': 7}
+    mine = M.SimCLR_TimeSeriesV4('s3dg', 128, 0.07, False)
+    mine.store.materialize(torch.device('cpu'), DV_F32)
+    mine.load_state_dict(ck['state_dict'])                       # strict: identical key set
+    assert mine.store.ready(torch.device('cpu'), DV_F32)         # still views of the arena
+    for k, v in ref.state_dict().items():
+        assert torch.equal(mine.state_dict()[k], v), k
+    path = str(tmp_path / 'model' / 'epoch3.pth.tar')
+    os.makedirs(os.path.dirname(path))
+    save_checkpoint({'epoch': 4, 'state_dict': mine.state_dict(), 'best_acc': 0.0, 'iteration': 8}, filename=path)
+    back = torch.load(path, map_location='cpu', weights_only=True)
+    assert back['state_dict']['encoder_q.0.Conv_1a.conv1.weight'].is_contiguous()
+    ref2 = O.SimCLR_TimeSeriesV4('s3dg', 128, 0.07, False)
+    ref2.load_state_dict(back['state_dict'])
+    # the downstream rename of classifier.py:362-366 (encoder_q.0. -> backbone.) finds its keys
+    assert any(k.startswith('encoder_q.0.') for k in back['state_dict'])
+    # partial load helper
+    sub = {k: v for k, v in back['state_dict'].items() if 'series_proj_head' not in k}
+    neq_load_customized(M.SimCLR_TimeSeriesV4('s3dg', 128, 0.07, False), sub, verbose=False)
