@@ -132,24 +132,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   // one K-tile = 64 bytes = 32 bf16 per row: two 32x32x16 steps
-  static __device__ __forceinline__ void tile(const unsigned char* a_row, const unsigned char* b_row, int h,
+  // sa / sb: XOR masks on the 16-byte slot index (0 for the padded layout, (row>>2)&3 for the swizzled DMA layout)
+  static __device__ __forceinline__ void tile(const unsigned char* a_row, const unsigned char* b_row, int h, int sa, int sb,
                                                f32x16& acc) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a = *reinterpret_cast<const bf16x8*>(a_row + (2 * ks + h) * 16);
-      bf16x8 b = *reinterpret_cast<const bf16x8*>(b_row + (2 * ks + h) * 16);
+      bf16x8 a = *reinterpret_cast<const bf16x8*>(a_row + ((2 * ks + h) ^ sa) * 16);
+      bf16x8 b = *reinterpret_cast<const bf16x8*>(b_row + ((2 * ks + h) ^ sb) * 16);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
   }
 };
 template <> struct Mma<float> {
   // one K-tile = 64 bytes = 16 f32 per row: eight 32x32x2 steps
-  static __device__ __forceinline__ void tile(const unsigned char* a_row, const unsigned char* b_row, int h,
+  static __device__ __forceinline__ void tile(const unsigned char* a_row, const unsigned char* b_row, int h, int sa, int sb,
                                                f32x16& acc) {
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-      f32x4 a = *reinterpret_cast<const f32x4*>(a_row + gq * 16);
-      f32x4 b = *reinterpret_cast<const f32x4*>(b_row + gq * 16);
+      f32x4 a = *reinterpret_cast<const f32x4*>(a_row + (gq ^ sa) * 16);
+      f32x4 b = *reinterpret_cast<const f32x4*>(b_row + (gq ^ sb) * 16);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a.y : a.x, h ? b.y : b.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a.w : a.z, h ? b.w : b.z, acc, 0, 0, 0);
     }
@@ -167,7 +168,12 @@ __device__ __forceinline__ float act_apply(float v, int flags) {
 // LDS rows hold 64 bytes of K, padded to 80 so that ds_read_b128 fragments are conflict free.
 template <typename T, int MODE, int GVB, int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvArgs a) {
-  constexpr int ROWB = 64, PITCH = 80;
+  // DMA: 16-byte gathers go global -> LDS directly (buffer_load ... lds), no VGPR staging and no ds_write.  One wave
+  // instruction fills 16 rows x 64 B = 1 KiB of a row-linear, UNPADDED tile; bank conflicts of the ds_read_b128 fragment
+  // reads are avoided by XOR-swizzling the 16-byte slot with (row>>2)&3, applied on the source side (which k-slot a
+  // lane fetches) and on the read side.  The 8-byte-gather instantiation (RGB stem) keeps register staging + padding.
+  constexpr bool DMA = (GVB == 16);
+  constexpr int ROWB = 64, PITCH = DMA ? 64 : 80;
   constexpr int BKE = ROWB / (int)sizeof(T);
   constexpr int GV = GVB / (int)sizeof(T);
   constexpr int VPR = ROWB / GVB;           // vectors per row (4 or 8)
@@ -178,6 +184,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   static_assert(BN <= NT && BM % RPP == 0, "tile / thread layout");
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int A_G = DMA ? (BM / 16) / NW : A_PASSES;          // 16-row groups of the A tile per wave
+  constexpr int B_G = DMA ? ((BN / 16) + NW - 1) / NW : B_PASSES;
+  static_assert(!DMA || (BM / 16) % NW == 0, "A groups per wave");
   static_assert(TM >= 1 && TN >= 1, "tile");
   typedef typename VecB<GVB>::type vec_t;
 
@@ -193,7 +203,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
 
-  const int vslot = tid % VPR, vrow = tid / VPR;
+  // register-staged path: thread -> (vector slot, row); DMA path: lane -> (row within a 16-row group, swizzled slot)
+  const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int vslot = DMA ? ((lane & 3) ^ ((lane >> 4) & 3)) : tid % VPR;
+  const int vrow = DMA ? (lane >> 2) : tid / VPR;
+  auto a_row_of = [&](int p) { return DMA ? 16 * (uwave + p * NW) + vrow : vrow + p * RPP; };
+  auto b_row_of = [&](int p) { return DMA ? 16 * (uwave + p * NW) + vrow : vrow + p * RPP; };
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
   constexpr int ES = (int)sizeof(T);
@@ -220,10 +235,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
   const unsigned ldb = (unsigned)a.lds_ * ES;
 
-  unsigned rowoff[A_PASSES], mt[A_PASSES], mh[A_PASSES], mw[A_PASSES];
+  unsigned rowoff[A_G], mt[A_G], mh[A_G], mw[A_G];
 #pragma unroll
-  for (int p = 0; p < A_PASSES; ++p) {
-    const RowPos r = decode_row<MODE>((uint32_t)(m0 + vrow + p * RPP), a.M, g);
+  for (int p = 0; p < A_G; ++p) {
+    const RowPos r = decode_row<MODE>((uint32_t)(m0 + a_row_of(p)), a.M, g);
     unsigned bt = 0, bh = 0, bw = 0;
     int pos;
     if (MODE == MODE_FWD) {
@@ -242,18 +257,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
     mt[p] = bt; mh[p] = bh; mw[p] = bw;
     rowoff[p] = (unsigned)pos * ldb;           // modulo 2^32; exact for every valid (row, tap)
   }
-  unsigned woff[B_PASSES];
+  unsigned woff[B_G];
 #pragma unroll
-  for (int p = 0; p < B_PASSES; ++p) {
-    const int r = vrow + p * RPP, n = n0 + r;
+  for (int p = 0; p < B_G; ++p) {
+    const int r = b_row_of(p), n = n0 + r;
     woff[p] = (r < BN && n < a.N) ? (unsigned)n * (unsigned)a.ldw * ES : kOOB;
   }
   __syncthreads();                             // taptab
 
   const int nk = (g.Ktot + BKE - 1) / BKE;
-  vec_t ra[A_PASSES], rb[B_PASSES];
+  vec_t ra[A_G], rb[B_G];
 
-  auto gload = [&](int kt_idx) {
+  // gload(tile, buf): register-staged -> ra/rb (buf ignored); DMA -> straight into LDS buffer `buf`
+  auto gload = [&](int kt_idx, int buf) {
     const unsigned k = (unsigned)(kt_idx * BKE + vslot * GV);
     const unsigned tap = fd_div(k, a.fCP);
     const unsigned c = k - tap * (unsigned)g.CP;
@@ -262,10 +278,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
     const unsigned dt = ti.y & 255, dh = (ti.y >> 8) & 255, dw = (unsigned)ti.y >> 16;
     const unsigned tb = (unsigned)ti.x * ldb + c * ES;
 #pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) {
+    for (int p = 0; p < A_G; ++p) {
       const unsigned ok = (mt[p] >> dt) & (mh[p] >> dh) & (mw[p] >> dw) & (tin ? 1u : 0u);
       const unsigned off = ok ? rowoff[p] + tb : kOOB;
-      if constexpr (GVB == 16) {
+      if constexpr (DMA) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            src_rsrc, (__attribute__((address_space(3))) void*)(smem + buf * BUFB + (uwave + p * NW) * 1024), 16, off, 0, 0, 0);
+      } else if constexpr (GVB == 16) {
         u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, off, 0, 0);
         ra[p] = make_uint4(v.x, v.y, v.z, v.w);
       } else {
@@ -275,9 +294,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
     }
     const unsigned kb = (k < (unsigned)g.Ktot) ? k * ES : kOOB;
 #pragma unroll
-    for (int p = 0; p < B_PASSES; ++p) {
+    for (int p = 0; p < B_G; ++p) {
       const unsigned off = (woff[p] | kb) >= kOOB ? kOOB : woff[p] + kb;
-      if constexpr (GVB == 16) {
+      if constexpr (DMA) {
+        if (uwave + p * NW < BN / 16)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              w_rsrc, (__attribute__((address_space(3))) void*)(smem + buf * BUFB + BM * PITCH + (uwave + p * NW) * 1024), 16,
+              off, 0, 0, 0);
+      } else if constexpr (GVB == 16) {
         u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off, 0, 0);
         rb[p] = make_uint4(v.x, v.y, v.z, v.w);
       } else {
@@ -287,13 +311,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
     }
   };
   auto lstore = [&](int buf) {
+    if constexpr (!DMA) {
 #pragma unroll
-    for (int p = 0; p < A_PASSES; ++p)
-      *reinterpret_cast<vec_t*>(smem + buf * BUFB + (vrow + p * RPP) * PITCH + vslot * GVB) = ra[p];
+      for (int p = 0; p < A_G; ++p)
+        *reinterpret_cast<vec_t*>(smem + buf * BUFB + (vrow + p * RPP) * PITCH + vslot * GVB) = ra[p];
 #pragma unroll
-    for (int p = 0; p < B_PASSES; ++p) {
-      int r = vrow + p * RPP;
-      if (r < BN) *reinterpret_cast<vec_t*>(smem + buf * BUFB + (BM + r) * PITCH + vslot * GVB) = rb[p];
+      for (int p = 0; p < B_G; ++p) {
+        int r = vrow + p * RPP;
+        if (r < BN) *reinterpret_cast<vec_t*>(smem + buf * BUFB + (BM + r) * PITCH + vslot * GVB) = rb[p];
+      }
     }
   };
 
@@ -305,18 +331,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  gload(0);
+  // 32-row fragment blocks start at multiples of 32, so (row>>2)&3 of a fragment row is (l31>>2)&3 for A and B alike
+  const int swz = DMA ? ((l31 >> 2) & 3) : 0;
+  gload(0, 0);
   lstore(0);
-  __syncthreads();
+  __syncthreads();          // (with a DMA in flight hipcc drains vmcnt(0) before the barrier: exactly what is needed)
   for (int kt_idx = 0; kt_idx < nk; ++kt_idx) {
     const int cur = kt_idx & 1;
-    if (kt_idx + 1 < nk) gload(kt_idx + 1);
+    if (kt_idx + 1 < nk) gload(kt_idx + 1, cur ^ 1);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         Mma<T>::tile(smem + cur * BUFB + (wm0 + i * 32 + l31) * PITCH,
-                     smem + cur * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, acc[i][j]);
+                     smem + cur * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, swz, swz, acc[i][j]);
     if (kt_idx + 1 < nk) lstore(cur ^ 1);
     __syncthreads();
   }
@@ -762,7 +790,8 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
   a.Cout = d->Cout; a.CoutP = d->cout_pitch; a.J = a.g.Ktot;
   a.ldx = d->ldx; a.ldy = d->ldy; a.ldw = a.g.Ktot;
   // 128 output channels x 64 im2col columns per workgroup, or 64 x 128 when the layer has <= 64 output channels
-  const bool narrow = a.Cout <= 64;
+  // tile heights 64 or 128: whichever pads Cout less (144 -> 3 x 64 rather than 2 x 128)
+  const bool narrow = (a.Cout + 63) / 64 * 64 < (a.Cout + 127) / 128 * 128;
   const int BI = narrow ? 64 : 128, BJ = narrow ? 128 : 64;
   a.nti = (a.Cout + BI - 1) / BI;
   a.ntj = (a.J + BJ - 1) / BJ;

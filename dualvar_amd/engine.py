@@ -459,7 +459,7 @@ class ConvOp(Op):
         b = []
         if p.with_grad:
             self.d_w = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=0)
-            b.append(Launch('conv_wgrad', 'conv_wgrad<%s,%d,%s>' % (_dt(self.dtype), gv, '64,128' if sl.Cout <= 64 else '128,64'), lib.dv_conv3d_wgrad,
+            b.append(Launch('conv_wgrad', 'conv_wgrad<%s,%d,%s>' % (_dt(self.dtype), gv, '64,128' if ((sl.Cout + 63) // 64 * 64 < (sl.Cout + 127) // 128 * 128) else '128,64'), lib.dv_conv3d_wgrad,
                             (C.byref(self.d_w), x.ptr, y.grad.ptr, st.w_grad(sl)),
                             _abytes(x) + _abytes(y) + sl.Cout * taps * sl.Cin * 4, flops, shp))
             if self.need_dx:
