@@ -191,8 +191,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   static_assert(TM >= 1 && TN >= 1, "tile");
   typedef typename VecB<GVB>::type vec_t;
 
-  constexpr int NBUF = DMA ? 3 : 2;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * (BM + BN) * PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * PITCH];
   constexpr int BUFB = (BM + BN) * PITCH;   // A tile then B tile, twice
 
   const ConvGeom& g = a.g;
@@ -334,43 +333,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
 
   // 32-row fragment blocks start at multiples of 32, so (row>>2)&3 of a fragment row is (l31>>2)&3 for A and B alike
   const int swz = DMA ? ((l31 >> 2) & 3) : 0;
-  if constexpr (DMA) {
-    // Three LDS buffers, the DMA of tile t+2 is issued while tile t is consumed; ONE raw barrier per K-tile.
-    //   wait (own DMAs of tile t landed: all but the youngest tile's loads) -> s_barrier (everybody's tile t is in LDS
-    //   and everybody has finished reading tile t-1) -> issue tile t+2 into the buffer tile t-1 occupied -> MFMAs.
-    // __syncthreads() would drain vmcnt(0) and serialise the pipeline, hence the counted s_waitcnt + raw s_barrier.
-    int my_b = 0;                                    // DMA instructions this wave issues per tile for the B operand
-#pragma unroll
-    for (int p = 0; p < B_G; ++p) my_b += (uwave + p * NW < BN / 16) ? 1 : 0;
-    const int per_tile = A_G + my_b;                 // wave-uniform
-    gload(0, 0);
-    if (nk > 1) gload(1, 1);
-    int cur = 0;
-    for (int kt_idx = 0; kt_idx < nk; ++kt_idx) {
-      if (kt_idx + 1 < nk) {                         // tile kt+1 may stay in flight
-        if (per_tile == A_G) __builtin_amdgcn_s_waitcnt(0x0F70 | (A_G & 15));
-        else if (per_tile == A_G + 1) __builtin_amdgcn_s_waitcnt(0x0F70 | ((A_G + 1) & 15));
-        else __builtin_amdgcn_s_waitcnt(0x0F70 | ((A_G + 2) & 15));
-      } else {
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
-      }
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      int nxt2 = cur + 2; if (nxt2 >= 3) nxt2 -= 3;
-      if (kt_idx + 2 < nk) gload(kt_idx + 2, nxt2);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          Mma<T>::tile(smem + cur * BUFB + (wm0 + i * 32 + l31) * PITCH,
-                       smem + cur * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, swz, swz, acc[i][j]);
-      cur = cur + 1 == 3 ? 0 : cur + 1;
-    }
-    __syncthreads();                                 // LDS is reused by the statistics epilogue
-  } else {
   gload(0, 0);
   lstore(0);
-  __syncthreads();
+  __syncthreads();          // (with a DMA in flight hipcc drains vmcnt(0) before the barrier: exactly what is needed)
   for (int kt_idx = 0; kt_idx < nk; ++kt_idx) {
     const int cur = kt_idx & 1;
     if (kt_idx + 1 < nk) gload(kt_idx + 1, cur ^ 1);
@@ -382,7 +347,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
                      smem + cur * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, swz, swz, acc[i][j]);
     if (kt_idx + 1 < nk) lstore(cur ^ 1);
     __syncthreads();
-  }
   }
 
   // ---------------- epilogue
