@@ -232,9 +232,21 @@ def main():
         else:
             roof = {'bound': 'hbm', 'achieved': round(bw, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(f_hbm, 4)}
         tot_ms = sum(v[1] for k, v in csum.items() if not k.startswith('host:'))
-        roof.update({'traffic': None, 'kernel': dominant, 'launches_per_step': n // args.steps,
+        traffic = None
+        try:        # HBM bytes per launch of this kernel family from the committed PMC passes (tools/pmc_traffic.py)
+            pj = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_traffic.json'))[-1]
+            fam = json.load(open(os.path.join(ROOT, 'profiles', pj)))['families']
+            key = dominant.split('<')[0]
+            if key in fam:
+                traffic = round(fam[key]['hbm_bytes_per_launch'])
+                roof_src = pj
+        except Exception:
+            traffic = None
+        roof.update({'traffic': traffic, 'kernel': dominant, 'launches_per_step': n // args.steps,
                      'avg_launch_us': round(avg_ms * 1e3, 2), 'share_of_kernel_time': round(csum[dominant][1] / tot_ms, 3),
-                     'other_bound_frac': round(min(f_hbm, f_mfma), 4)})
+                     'other_bound_frac': round(min(f_hbm, f_mfma), 4),
+                     'algorithmic_bytes_per_launch': round(nbytes / n),
+                     'traffic_source': (roof_src + ' (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)') if traffic else None})
         out = {
             'metric': 'clips/sec (whole node), S3D-G 8x112^2 SimCLR pretrain step', 'value': round(clips / dt, 2),
             'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

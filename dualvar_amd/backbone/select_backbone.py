@@ -1,21 +1,25 @@
-"""select_backbone(network, first_channel=3) -> (module, {'feature_size': int})
-Same contract as the reference factory (backbone/select_backbone.py:7-31); the modules are the HIP-engine
-backbones.  'r50' builds the 2D3D ResNet-50 the reference intended (its own call raises TypeError)."""
+"""`select_backbone(network, first_channel=3) -> (module, {'feature_size': int})`.
+
+Contract of the reference factory (backbone/select_backbone.py:7-31): the returned module maps clips
+[N,3,T,H,W] to a post-ReLU feature map [N,feature_size,T',H',W'].  Here the modules are the HIP-engine
+backbones, and 'r50' builds the 2D3D ResNet-50 the reference meant to build (its own call raises TypeError:
+SURVEY.md D7).  'c3d' and 'r2d3d18' are not on the pretrain hot path and are not provided."""
 from .resnets import Bottleneck2d, Bottleneck3d, R2Plus1DNet, R3DNet, ResNet2d3d
 from .s3dg import S3D
 
+_FACTORIES = {
+    's3d': lambda ch: S3D(input_channel=ch, gating=False),
+    's3dg': lambda ch: S3D(input_channel=ch, gating=True),
+    'r21d': lambda ch: R2Plus1DNet(),
+    'r3d': lambda ch: R3DNet(),
+    'r50': lambda ch: ResNet2d3d([Bottleneck2d, Bottleneck2d, Bottleneck3d, Bottleneck3d], [3, 4, 6, 3], ch),
+}
+
 
 def select_backbone(network, first_channel=3):
-    if network == 's3d':
-        model = S3D(input_channel=first_channel)
-    elif network == 's3dg':
-        model = S3D(input_channel=first_channel, gating=True)
-    elif network == 'r50':
-        model = ResNet2d3d([Bottleneck2d, Bottleneck2d, Bottleneck3d, Bottleneck3d], [3, 4, 6, 3], first_channel)
-    elif network == 'r21d':
-        model = R2Plus1DNet()
-    elif network == 'r3d':
-        model = R3DNet()
-    else:
-        raise NotImplementedError(network)
-    return model, {'feature_size': model.feature_size}
+    try:
+        module = _FACTORIES[network](first_channel)
+    except KeyError:
+        raise NotImplementedError('backbone %r is not part of the MI355X pretrain path (have: %s)'
+                                  % (network, ', '.join(sorted(_FACTORIES)))) from None
+    return module, {'feature_size': module.feature_size}

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/<round>_pmc_traffic.json.
+
+Usage (on the GPU box, three separate passes as MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE do not
+fit one pass, and PMC must not be combined with the API trace domains):
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline
+    python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/r01_pmc_traffic.json
+Units / corrections (guide, section HBM): the counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide
+(16 B/lane) coalesced reads, so it is doubled; WRITE_SIZE is taken as is.  Output: bytes per launch per kernel."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def short(name):
+    """map a mangled / demangled kernel name to the bench's kernel label family"""
+    n = name
+    for key, pat in (('conv_wgrad', r'conv_wgrad_kernel'), ('conv_gemm', r'conv_gemm_kernel'),
+                     ('bn_bwd_reduce_multi', r'bn_bwd_reduce_multi'), ('bn_bwd_apply_multi', r'bn_bwd_apply_multi'),
+                     ('bn_apply_multi', r'bn_apply_multi'), ('bn_stats_multi', r'bn_stats_multi'),
+                     ('bn_bwd_reduce', r'bn_bwd_reduce_kernel'), ('bn_bwd_apply', r'bn_bwd_apply_kernel'),
+                     ('bn_apply', r'bn_apply_kernel'), ('maxpool_fwd', r'maxpool_fwd'), ('maxpool_bwd', r'maxpool_bwd')):
+        if re.search(pat, n):
+            return key
+    return None
+
+
+def load(d, counter):
+    agg, cnt = collections.defaultdict(float), collections.Counter()
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] == counter:
+                agg[r['Kernel_Name']] += float(r['Counter_Value'])
+                cnt[r['Kernel_Name']] += 1
+    return agg, cnt
+
+
+def main():
+    fdir, wdir, out = sys.argv[1:4]
+    f, nf = load(fdir, 'FETCH_SIZE')
+    w, nw = load(wdir, 'WRITE_SIZE')
+    fam = collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
+    per_kernel = {}
+    for k in set(f) | set(w):
+        fb = 2.0 * f.get(k, 0.0) * 1024.0 / max(nf.get(k, 1), 1)
+        wb = w.get(k, 0.0) * 1024.0 / max(nw.get(k, 1), 1)
+        per_kernel[k] = {'launches': nf.get(k, nw.get(k, 0)), 'fetch_bytes_per_launch': fb, 'write_bytes_per_launch': wb}
+        s = short(k)
+        if s:
+            e = fam[s]
+            e[0] += nf.get(k, 0); e[1] += 2.0 * f.get(k, 0.0) * 1024.0
+            e[2] += nw.get(k, 0); e[3] += w.get(k, 0.0) * 1024.0
+    families = {s: {'launches': e[0], 'hbm_bytes_per_launch': (e[1] / max(e[0], 1)) + (e[3] / max(e[2], 1))} for s, e in fam.items()}
+    json.dump({'note': 'FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, per launch',
+               'families': families, 'kernels': per_kernel}, open(out, 'w'), indent=1, sort_keys=True)
+    print('wrote', out, {k: int(v['hbm_bytes_per_launch']) for k, v in families.items()})
+
+
+if __name__ == '__main__':
+    main()
