@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdualvar_hip.so')
 SOURCES = ['conv.hip', 'elementwise.hip', 'loss.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-comment', '-ffp-contract=off']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-comment', '-Wno-inline-asm', '-ffp-contract=off']
 
 
 def _stale(target, deps):

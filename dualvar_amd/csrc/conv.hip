@@ -129,6 +129,29 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// ---- global -> LDS DMA (buffer_load_dwordx4 ... lds) as inline assembly -------------------------------------------
+// The __builtin_amdgcn_raw_ptr_buffer_load_lds form is tracked by the compiler's wait-count pass, which cannot prove
+// that the following ds_reads touch the OTHER buffer and therefore drains vmcnt(0) in front of them: the prefetch of
+// tile k+1 is then waited for before tile k is even read, i.e. no overlap inside a workgroup.  Issued as opaque
+// assembly the load is invisible to that pass; the kernels wait for it themselves (dma_wait_all) right before the
+// barrier that publishes the tile.  One wave instruction moves 64 lanes x 16 B to LDS [m0, m0 + 1 KiB).
+typedef __attribute__((ext_vector_type(4))) unsigned int dma_rsrc_t;
+__device__ __forceinline__ dma_rsrc_t dma_make_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  dma_rsrc_t r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+  return r;
+}
+__device__ __forceinline__ void dma_load16(dma_rsrc_t rsrc, unsigned lds_base, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :
+               : "s"(lds_base), "v"(voff), "s"(rsrc)
+               : "memory", "m0");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   // one K-tile = 64 bytes = 32 bf16 per row: two 32x32x16 steps
@@ -233,6 +256,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   }
   const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src), 0, a.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
+  const dma_rsrc_t src_dma = dma_make_rsrc(a.src, (unsigned)a.src_bytes), w_dma = dma_make_rsrc(a.w, (unsigned)a.w_bytes);
+  const unsigned smem_base = lds_addr(smem);
   const unsigned ldb = (unsigned)a.lds_ * ES;
 
   unsigned rowoff[A_G], mt[A_G], mh[A_G], mw[A_G];
@@ -282,8 +307,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
       const unsigned ok = (mt[p] >> dt) & (mh[p] >> dh) & (mw[p] >> dw) & (tin ? 1u : 0u);
       const unsigned off = ok ? rowoff[p] + tb : kOOB;
       if constexpr (DMA) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            src_rsrc, (__attribute__((address_space(3))) void*)(smem + buf * BUFB + (uwave + p * NW) * 1024), 16, off, 0, 0, 0);
+        dma_load16(src_dma, smem_base + buf * BUFB + (uwave + p * NW) * 1024, off);
       } else if constexpr (GVB == 16) {
         u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, off, 0, 0);
         ra[p] = make_uint4(v.x, v.y, v.z, v.w);
@@ -298,9 +322,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
       const unsigned off = (woff[p] | kb) >= kOOB ? kOOB : woff[p] + kb;
       if constexpr (DMA) {
         if (uwave + p * NW < BN / 16)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(
-              w_rsrc, (__attribute__((address_space(3))) void*)(smem + buf * BUFB + BM * PITCH + (uwave + p * NW) * 1024), 16,
-              off, 0, 0, 0);
+          dma_load16(w_dma, smem_base + buf * BUFB + BM * PITCH + (uwave + p * NW) * 1024, off);
       } else if constexpr (GVB == 16) {
         u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off, 0, 0);
         rb[p] = make_uint4(v.x, v.y, v.z, v.w);
@@ -335,7 +357,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   const int swz = DMA ? ((l31 >> 2) & 3) : 0;
   gload(0, 0);
   lstore(0);
-  __syncthreads();          // (with a DMA in flight hipcc drains vmcnt(0) before the barrier: exactly what is needed)
+  if constexpr (DMA) dma_wait_all();
+  __syncthreads();
   for (int kt_idx = 0; kt_idx < nk; ++kt_idx) {
     const int cur = kt_idx & 1;
     if (kt_idx + 1 < nk) gload(kt_idx + 1, cur ^ 1);
@@ -346,6 +369,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
         Mma<T>::tile(smem + cur * BUFB + (wm0 + i * 32 + l31) * PITCH,
                      smem + cur * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, swz, swz, acc[i][j]);
     if (kt_idx + 1 < nk) lstore(cur ^ 1);
+    if constexpr (DMA) dma_wait_all();     // tile k+1 has landed (it had the whole MFMA phase to do so)
     __syncthreads();
   }
 
@@ -614,6 +638,188 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
 
 // ------------------------------------------------------------------------------------------
+// bf16 wgrad with global -> LDS DMA gathers (16-byte vectors; the RGB stem and the f32 parity mode keep the
+// register-staged kernel above).  Differences from it:
+//  * both tiles are UNPADDED row-linear LDS images filled by buffer_load ... lds (one wave instruction = 1 KiB), so no
+//    VGPR staging and no ds_write; the bank conflicts of the transposed fragment reads (4 rows x 64 B per half wave)
+//    are removed by XOR-swizzling the 64-byte chunk index with the row (row&3 for 256-byte rows, (row>>1)&1 for
+//    128-byte rows), applied on the source side (which column slot a lane fetches) and on the read side;
+//  * a row's im2col coordinates are decoded ONCE per workgroup (not once per 16-byte vector): each wave decodes 64 of
+//    the next 256 rows into an LDS table {byte offset of the row's first tap, separable tap-validity masks}; a lane's
+//    column slot -- hence its tap and channel -- is fixed for the whole kernel, so the per-step address is
+//    table.offset + constant, or an out-of-range offset (hardware zero fill) when the tap falls into the padding.
+struct WgradDmaArgs {
+  WgradArgs w;
+  int x_bytes, dy_bytes;
+};
+
+template <int RB> __device__ __forceinline__ int wg_swz(int row) { return RB == 256 ? (row & 3) : ((row >> 1) & 1); }
+
+template <int RB>
+__device__ __forceinline__ bf16x8 wg_frag(const unsigned char* tile, int col0, int lane, int ks) {
+  const int g16 = lane >> 4, li = lane & 15;
+  const int q = li >> 2, p = li & 3;
+  const int row = ks * 16 + 8 * (g16 >> 1) + q;              // wg_swz(row) == wg_swz(q) == wg_swz(row + 4)
+  const int colb = ((col0 + 16 * (g16 & 1) + 4 * p) * 2) ^ (wg_swz<RB>(q) << 6);
+  const unsigned char* ad = tile + row * RB + colb;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad + 4 * RB));
+  s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradDmaArgs aa) {
+  const WgradArgs& a = aa.w;
+  constexpr int ROWS = 32;
+  constexpr int RBP = BI * 2, RBQ = BJ * 2;          // row bytes of the dY (P) and im2col (Q) tiles
+  static_assert((RBP == 128 || RBP == 256) && (RBQ == 128 || RBQ == 256), "swizzle covers 128/256-byte rows");
+  constexpr int DP = RBP / 16, DQ = RBQ / 16;        // 16-byte slots per row
+  constexpr int QOFF = ROWS * RBP, BUFB = ROWS * (RBP + RBQ);
+  constexpr int NPW = (QOFF / 1024) / 4, NQW = ((BUFB - QOFF) / 1024) / 4;    // DMA instructions per wave and step
+  static_assert(NPW >= 1 && NQW >= 1, "tile");
+  constexpr int RT = 256;                            // rows per decode round (8 steps)
+  constexpr int WI = BI / 2, WJ = BJ / 2, TI = WI / 32, TJ = WJ / 32;
+  constexpr unsigned kOOB = 0x80000000u;
+
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUFB];
+  __shared__ uint2 rowtab[2][RT];
+
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_j = bid % a.ntj; bid /= a.ntj;
+  const int tile_i = bid % a.nti;
+  const int split = bid / a.nti;
+  const int i0 = tile_i * BI, j0 = tile_j * BJ;
+  const int wi0 = (wave >> 1) * WI, wj0 = (wave & 1) * WJ;
+  const int m_begin = split * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+  if (m_begin >= m_end) return;
+
+  const dma_rsrc_t x_rsrc = dma_make_rsrc(a.x, (unsigned)aa.x_bytes), dy_rsrc = dma_make_rsrc(a.dy, (unsigned)aa.dy_bytes);
+  const unsigned smem_base = lds_addr(smem);
+  const unsigned ldxb = (unsigned)a.ldx * 2, ldyb = (unsigned)a.ldy * 2;
+
+  // fixed per-lane roles: LDS slot -> (row, swizzled source column)
+  int prow[NPW]; unsigned pcolb[NPW];
+#pragma unroll
+  for (int u = 0; u < NPW; ++u) {
+    const int sl = (wave + 4 * u) * 64 + lane;
+    prow[u] = sl / DP;
+    const int jj = (sl % DP) ^ (wg_swz<RBP>(prow[u]) << 2);
+    const int n = i0 + jj * 8;
+    pcolb[u] = n < a.CoutP ? (unsigned)n * 2 : kOOB;
+  }
+  int qrow[NQW]; unsigned qtb[NQW], qbit[NQW];
+#pragma unroll
+  for (int u = 0; u < NQW; ++u) {
+    const int sl = (wave + 4 * u) * 64 + lane;
+    qrow[u] = sl / DQ;
+    const int jj = (sl % DQ) ^ (wg_swz<RBQ>(qrow[u]) << 2);
+    const int col = j0 + jj * 8;
+    if (col < a.J) {
+      const int tap = col / g.CP, c = col - tap * g.CP;
+      const int dw = tap % g.kw, t2 = tap / g.kw, dh = t2 % g.kh, dt = t2 / g.kh;
+      qbit[u] = (1u << dt) | (1u << (8 + dh)) | (1u << (16 + dw));
+      qtb[u] = (unsigned)((dt * g.sH + dh) * g.sW + dw) * ldxb + (unsigned)c * 2;
+    } else {
+      qbit[u] = 0xffffffffu;                         // never matches a 24-bit mask: zero fill
+      qtb[u] = 0;
+    }
+  }
+
+  // decode 64 rows of round `rnd` (this wave's share) into rowtab[rnd & 1]
+  auto decode = [&](int rnd) {
+    const int idx = wave * 64 + lane;
+    const int m = m_begin + rnd * RT + idx;
+    uint2 e = make_uint2(0u, 0u);
+    if (m < m_end) {
+      const RowPos r = decode_row<MODE_FWD>((uint32_t)m, a.M, g);
+      auto range = [](int x0, int k, int lim) -> unsigned {      // bits d in [0,k) with 0 <= x0 + d < lim
+        const int lo = max(0, -x0), hi = min(k, lim - x0);
+        return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+      };
+      const unsigned bt = range(r.t0, g.kt, g.sT), bh = range(r.h0, g.kh, g.sH), bw = range(r.w0, g.kw, g.sW);
+      e.x = (unsigned)(r.base + (r.t0 * g.sH + r.h0) * g.sW + r.w0) * ldxb;   // modulo 2^32; exact for valid taps
+      e.y = (bt && bh && bw) ? (bt | (bh << 8) | (bw << 16)) : 0u;
+    }
+    rowtab[rnd & 1][idx] = e;
+  };
+
+  auto issue = [&](int s, int buf) {
+    const int mb = m_begin + s * ROWS;
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) {
+      const int m = mb + prow[u];
+      const unsigned off = (m < m_end && pcolb[u] != kOOB) ? (unsigned)m * ldyb + pcolb[u] : kOOB;
+      dma_load16(dy_rsrc, smem_base + buf * BUFB + (wave + 4 * u) * 1024, off);
+    }
+    const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(rowtab[(s >> 3) & 1] + (s & 7) * ROWS);
+    unsigned long long e[NQW];
+#pragma unroll
+    for (int u = 0; u < NQW; ++u) e[u] = tab[qrow[u]];          // one ds_read_b64 each, issued back to back
+#pragma unroll
+    for (int u = 0; u < NQW; ++u) {
+      const unsigned ex = (unsigned)e[u], ey = (unsigned)(e[u] >> 32);
+      const unsigned off = ((ey & qbit[u]) == qbit[u]) ? ex + qtb[u] : kOOB;
+      dma_load16(x_rsrc, smem_base + buf * BUFB + QOFF + (wave + 4 * u) * 1024, off);
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsteps = (m_end - m_begin + ROWS - 1) / ROWS;
+  decode(0);
+  __syncthreads();
+  issue(0, 0);
+  dma_wait_all();
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    // table of round R+1 is written during the first step of round R; its previous contents (round R-1) were last
+    // read two barriers ago, and its first reader (step 8R+7) is seven barriers ahead
+    if ((s & 7) == 0 && (s + 8) < nsteps) decode((s >> 3) + 1);
+    if (s + 1 < nsteps) issue(s + 1, cur ^ 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[TI], bf[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) af[i] = wg_frag<RBP>(smem + cur * BUFB, wi0 + i * 32, lane, ks);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) bf[j] = wg_frag<RBQ>(smem + cur * BUFB + QOFF, wj0 + j * 32, lane, ks);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    dma_wait_all();                                  // tile s+1 has landed
+    __syncthreads();
+  }
+
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int col = j0 + wj0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wi0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < a.Cout && col < a.J) atomicAdd(a.dw + (size_t)row * a.ldw + col, acc[i][j][r]);
+      }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
 // host side
 static bool fill_geom(const dv_conv_desc* d, int mode, ConvGeom& g) {
   g.kt = d->kt; g.kh = d->kh; g.kw = d->kw;
@@ -806,6 +1012,17 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
   const int gvb = gather_bytes(d->dtype, d->cin_pitch);
   if (gvb == 16 && !aligned16(x)) return DV_EALIGN;
   hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == DV_BF16 && gvb == 16 && d->kt <= 8 && d->kh <= 8 && d->kw <= 8) {
+    const int64_t xb = ((int64_t)d->N * d->Ti * d->Hi * d->Wi - 1) * d->ldx * 2 + (int64_t)d->cin_pitch * 2;
+    const int64_t yb = ((int64_t)a.M - 1) * d->ldy * 2 + (int64_t)d->cout_pitch * 2;
+    if (xb < (1ll << 31) && yb < (1ll << 31)) {
+      WgradDmaArgs aa;
+      aa.w = a; aa.x_bytes = (int)xb; aa.dy_bytes = (int)yb;
+      if (narrow) hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 128>), dim3(grid), dim3(256), 0, s, aa);
+      else hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 64>), dim3(grid), dim3(256), 0, s, aa);
+      return dv_launch_status();
+    }
+  }
 #define WG_LAUNCH(T_, G_)                                                                                   \
   do {                                                                                                      \
     if (narrow) hipLaunchKernelGGL((conv_wgrad_kernel<T_, G_, 64, 128>), dim3(grid), dim3(256), 0, s, a);   \
