@@ -148,6 +148,16 @@ __device__ __forceinline__ void dma_load16(dma_rsrc_t rsrc, unsigned lds_base, u
                : "memory", "m0");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most n (wave-uniform, <= 24) of this wave's DMA pieces are still in flight
+__device__ __forceinline__ void dma_wait_upto(int n) {
+#define DV_W(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
+  switch (n) {
+    DV_W(1) DV_W(2) DV_W(3) DV_W(4) DV_W(5) DV_W(6) DV_W(7) DV_W(8) DV_W(9) DV_W(10) DV_W(11) DV_W(12)
+    DV_W(13) DV_W(14) DV_W(15) DV_W(16) DV_W(17) DV_W(18) DV_W(19) DV_W(20) DV_W(21) DV_W(22) DV_W(23) DV_W(24)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef DV_W
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
 }
@@ -189,13 +199,20 @@ __device__ __forceinline__ float act_apply(float v, int flags) {
 // ------------------------------------------------------------------------------------------
 // fwd / dgrad kernel.  256 threads = 4 waves arranged WAVES_M x WAVES_N over a BM x BN tile.
 // LDS rows hold 64 bytes of K, padded to 80 so that ds_read_b128 fragments are conflict free.
-template <typename T, int MODE, int GVB, int BM, int BN, int WAVES_M, int WAVES_N>
+// GM (gather mode): 0 = generic (a K-step may straddle taps; per-lane tap decode through the LDS tap table);
+// 1 = uniform tap (channel pitch a multiple of the K-step, <= 32 taps, DMA path): the tap, its source offset and the
+// K offset are wave-uniform and live in SGPRs, the separable validity masks are folded into ONE inverted bit mask per
+// row in the prologue, and a gather address costs three VALU instructions (add, bfe, lshl_or) instead of ~12 -- the K
+// loop was issue bound on exactly that address arithmetic (VALU ~ half of all issued cycles in the PMC profile).
+// NS: LDS stages of the DMA pipeline (tiles k+1 .. k+NS-1 are in flight while tile k is multiplied; counted vmcnt).
+template <typename T, int MODE, int GVB, int BM, int BN, int WAVES_M, int WAVES_N, int GM, int NS = 2>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvArgs a) {
   // DMA: 16-byte gathers go global -> LDS directly (buffer_load ... lds), no VGPR staging and no ds_write.  One wave
   // instruction fills 16 rows x 64 B = 1 KiB of a row-linear, UNPADDED tile; bank conflicts of the ds_read_b128 fragment
   // reads are avoided by XOR-swizzling the 16-byte slot with (row>>2)&3, applied on the source side (which k-slot a
   // lane fetches) and on the read side.  The 8-byte-gather instantiation (RGB stem) keeps register staging + padding.
   constexpr bool DMA = (GVB == 16);
+  static_assert(GM == 0 || DMA, "uniform-tap gathers are DMA only");
   constexpr int ROWB = 64, PITCH = DMA ? 64 : 80;
   constexpr int BKE = ROWB / (int)sizeof(T);
   constexpr int GV = GVB / (int)sizeof(T);
@@ -214,8 +231,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   static_assert(TM >= 1 && TN >= 1, "tile");
   typedef typename VecB<GVB>::type vec_t;
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * PITCH];
-  constexpr int BUFB = (BM + BN) * PITCH;   // A tile then B tile, twice
+  static_assert(NS == 2 || GVB == 16, "deeper pipelines are DMA only");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (BM + BN) * PITCH];
+  constexpr int BUFB = (BM + BN) * PITCH;   // A tile then B tile, NS times
 
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x;
@@ -288,6 +306,26 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
     const int r = b_row_of(p), n = n0 + r;
     woff[p] = (r < BN && n < a.N) ? (unsigned)n * (unsigned)a.ldw * ES : kOOB;
   }
+  // uniform-tap mode: wave-uniform K cursor (next tile to load) and per-row inverted tap masks
+  int u_c0 = 0, u_tap = 0, u_dt = 0, u_dh = 0, u_dw = 0;
+  unsigned u_toffb = 0;                        // source byte offset of the current tap relative to tap 0
+  unsigned imask[A_G];
+  if constexpr (GM == 1) {
+#pragma unroll
+    for (int p = 0; p < A_G; ++p) {
+      unsigned inv = 0;
+      int tp = 0;
+      for (int dt = 0; dt < g.kt; ++dt)
+        for (int dh = 0; dh < g.kh; ++dh)
+          for (int dw = 0; dw < g.kw; ++dw, ++tp)
+            inv |= ((((mt[p] >> dt) & (mh[p] >> dh) & (mw[p] >> dw)) & 1u) ^ 1u) << tp;
+      imask[p] = inv;
+      rowoff[p] += (unsigned)vslot * GVB;
+    }
+#pragma unroll
+    for (int p = 0; p < B_G; ++p)
+      if (woff[p] != kOOB) woff[p] += (unsigned)vslot * GVB;
+  }
   __syncthreads();                             // taptab
 
   const int nk = (g.Ktot + BKE - 1) / BKE;
@@ -295,6 +333,32 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
 
   // gload(tile, buf): register-staged -> ra/rb (buf ignored); DMA -> straight into LDS buffer `buf`
   auto gload = [&](int kt_idx, int buf) {
+    if constexpr (GM == 1) {
+      const unsigned s_a = u_toffb + (unsigned)u_c0 * ES;
+#pragma unroll
+      for (int p = 0; p < A_G; ++p) {
+        const unsigned off = ((__builtin_amdgcn_ubfe(imask[p], (unsigned)u_tap, 1u)) << 31) | (rowoff[p] + s_a);
+        dma_load16(src_dma, smem_base + buf * BUFB + (uwave + p * NW) * 1024, off);
+      }
+      const unsigned s_b = (unsigned)(u_tap * g.CP + u_c0) * ES;
+#pragma unroll
+      for (int p = 0; p < B_G; ++p)
+        if (uwave + p * NW < BN / 16)
+          dma_load16(w_dma, smem_base + buf * BUFB + BM * PITCH + (uwave + p * NW) * 1024, woff[p] + s_b);
+      u_c0 += BKE;
+      if (u_c0 >= g.CP) {
+        u_c0 = 0;
+        ++u_tap;
+        if (++u_dw == g.kw) {
+          u_dw = 0;
+          if (++u_dh == g.kh) { u_dh = 0; ++u_dt; }
+        }
+        const int toff = MODE == MODE_FWD ? (u_dt * g.sH + u_dh) * g.sW + u_dw
+                                          : -(((u_dt >> (g.st - 1)) * g.sH + (u_dh >> (g.sh - 1))) * g.sW + (u_dw >> (g.sw - 1)));
+        u_toffb = (unsigned)toff * ldb;
+      }
+      return;
+    }
     const unsigned k = (unsigned)(kt_idx * BKE + vslot * GV);
     const unsigned tap = fd_div(k, a.fCP);
     const unsigned c = k - tap * (unsigned)g.CP;
@@ -355,22 +419,41 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
 
   // 32-row fragment blocks start at multiples of 32, so (row>>2)&3 of a fragment row is (l31>>2)&3 for A and B alike
   const int swz = DMA ? ((l31 >> 2) & 3) : 0;
-  gload(0, 0);
-  lstore(0);
-  if constexpr (DMA) dma_wait_all();
-  __syncthreads();
-  for (int kt_idx = 0; kt_idx < nk; ++kt_idx) {
-    const int cur = kt_idx & 1;
-    if (kt_idx + 1 < nk) gload(kt_idx + 1, cur ^ 1);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        Mma<T>::tile(smem + cur * BUFB + (wm0 + i * 32 + l31) * PITCH,
-                     smem + cur * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, swz, swz, acc[i][j]);
-    if (kt_idx + 1 < nk) lstore(cur ^ 1);
-    if constexpr (DMA) dma_wait_all();     // tile k+1 has landed (it had the whole MFMA phase to do so)
+        Mma<T>::tile(smem + buf * BUFB + (wm0 + i * 32 + l31) * PITCH,
+                     smem + buf * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, swz, swz, acc[i][j]);
+  };
+  if constexpr (DMA) {
+    // pieces this wave issues per tile (the B groups may not divide evenly over the waves)
+    int pieces = A_G;
+#pragma unroll
+    for (int p = 0; p < B_G; ++p) pieces += (uwave + p * NW < BN / 16) ? 1 : 0;
+    constexpr int D = NS - 1;                  // prefetch distance
+    for (int t = 0; t < D && t < nk; ++t) gload(t, t);
+    int cur = 0, nxt = D % NS;                 // stage of tile k / of tile k + D
+    for (int kt_idx = 0; kt_idx < nk; ++kt_idx) {
+      dma_wait_upto(min(D - 1, nk - 1 - kt_idx) * pieces);   // tile k has landed (this wave's pieces)
+      __syncthreads();                         // ... everybody's; and stage `nxt` (tile k-1) is no longer read
+      if (kt_idx + D < nk) gload(kt_idx + D, nxt);
+      compute(cur);
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    }
+  } else {
+    gload(0, 0);
+    lstore(0);
     __syncthreads();
+    for (int kt_idx = 0; kt_idx < nk; ++kt_idx) {
+      const int cur = kt_idx & 1;
+      if (kt_idx + 1 < nk) gload(kt_idx + 1, cur ^ 1);
+      compute(cur);
+      if (kt_idx + 1 < nk) lstore(cur ^ 1);
+      __syncthreads();
+    }
   }
 
   // ---------------- epilogue
@@ -881,17 +964,36 @@ static int pick_bm(int M, int ntn) {
   return ((int64_t)((M + 127) / 128) * ntn >= 1024) ? 128 : 64;
 }
 
-template <typename T, int MODE, int GVB>
-static void launch_gemm(int bm, int bn, const ConvArgs& a, int grid, hipStream_t s) {
+template <typename T, int MODE, int GVB, int GM, int NS>
+static void launch_gemm_ns(int bm, int bn, const ConvArgs& a, int grid, hipStream_t s) {
   if (bm == 64) {
-    if (bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 32, 2, 1>), dim3(grid), dim3(128), 0, s, a);
-    else if (bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 64, 2, 2>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 128, 2, 2>), dim3(grid), dim3(256), 0, s, a);
+    if (bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 32, 2, 1, GM, NS>), dim3(grid), dim3(128), 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 64, 2, 2, GM, NS>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 128, 2, 2, GM, NS>), dim3(grid), dim3(256), 0, s, a);
     return;
   }
-  if (bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 32, 4, 1>), dim3(grid), dim3(256), 0, s, a);
-  else if (bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 64, 4, 1>), dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 128, 2, 2>), dim3(grid), dim3(256), 0, s, a);
+  if (bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 32, 4, 1, GM, NS>), dim3(grid), dim3(256), 0, s, a);
+  else if (bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 64, 4, 1, GM, NS>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 128, 2, 2, GM, NS>), dim3(grid), dim3(256), 0, s, a);
+}
+
+// Two LDS stages everywhere: with the DMA overlapping the MFMA phase, three to six stages measured equal or slower on
+// every S3D-G layer (they cost resident workgroups, and the K loop is issue bound, not latency bound).
+template <typename T, int MODE, int GVB, int GM>
+static void launch_gemm_gm(int bm, int bn, const ConvArgs& a, int grid, hipStream_t s) {
+  launch_gemm_ns<T, MODE, GVB, GM, 2>(bm, bn, a, grid, s);
+}
+
+template <typename T, int MODE, int GVB>
+static void launch_gemm(int bm, int bn, const ConvArgs& a, int grid, hipStream_t s) {
+  if constexpr (GVB == 16 && sizeof(T) == 2) {
+    // uniform-tap gathers: every 32-element K-step inside one tap, tap bit mask in one register
+    if (a.g.CP % 32 == 0 && a.g.kt * a.g.kh * a.g.kw <= 32) {
+      launch_gemm_gm<T, MODE, GVB, 1>(bm, bn, a, grid, s);
+      return;
+    }
+  }
+  launch_gemm_gm<T, MODE, GVB, 0>(bm, bn, a, grid, s);
 }
 
 }  // namespace
