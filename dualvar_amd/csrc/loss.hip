@@ -58,9 +58,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
 
 // Several independent small GEMMs in one launch (the four self-gating FCs of an Inception block and their
 // backward products).  Descriptors live in device memory and are static per plan.
+// One workgroup per 32x32 output tile; its four waves split K in interleaved 16-deep chunks (these GEMMs are a few
+// dozen tiles with K up to 832: one wave per tile left the chip idle and serialised ~50 dependent load rounds) and
+// reduce through LDS.  A K-contiguous operand is read as two float4 per lane and chunk instead of eight strided
+// dwords.  Within a chunk lane half h multiplies k = chunk + 8h + u (u = 0..7): any pairing works as long as A and B
+// agree, this one makes each lane's eight values contiguous.
 __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const dv_gemm_desc* __restrict__ descs, int n_groups) {
+  __shared__ float red[3][16][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int tile = blockIdx.x * 4 + wave;
+  int tile = blockIdx.x;
   int gi = 0;
   while (gi < n_groups && tile >= descs[gi].tile_end) ++gi;
   if (gi >= n_groups) return;
@@ -70,37 +76,57 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const dv_gemm_des
   const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
   const int l31 = lane & 31, h = lane >> 5;
   const int m = m0 + l31, n = n0 + l31;
-  const float* ap = d.A + (int64_t)m * d.sam;
-  const float* bp = d.B + (int64_t)n * d.sbn;
+  const bool mok = m < d.M, nok = n < d.N;
+  const float* ap = d.A + (int64_t)(mok ? m : 0) * d.sam;
+  const float* bp = d.B + (int64_t)(nok ? n : 0) * d.sbn;
+  const bool avec = d.sak == 1 && (d.sam & 3) == 0 && ((uintptr_t)d.A & 15) == 0;
+  const bool bvec = d.sbk == 1 && (d.sbn & 3) == 0 && ((uintptr_t)d.B & 15) == 0;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  int k = 0;
-  for (; k + 16 <= d.K; k += 16) {
+  for (int kc = wave * 16; kc < d.K; kc += 64) {
+    const int kb = kc + 8 * h;
     float a[8], b[8];
+    if (kc + 16 <= d.K) {
+      if (avec) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ap + kb), v1 = *reinterpret_cast<const f32x4*>(ap + kb + 4);
+        a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+      } else {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int kk = k + 2 * u + h;
-      a[u] = (m < d.M) ? ap[(int64_t)kk * d.sak] : 0.f;
-      b[u] = (n < d.N) ? bp[(int64_t)kk * d.sbk] : 0.f;
+        for (int u = 0; u < 8; ++u) a[u] = ap[(int64_t)(kb + u) * d.sak];
+      }
+      if (bvec) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(bp + kb), v1 = *reinterpret_cast<const f32x4*>(bp + kb + 4);
+        b[0] = v0.x; b[1] = v0.y; b[2] = v0.z; b[3] = v0.w; b[4] = v1.x; b[5] = v1.y; b[6] = v1.z; b[7] = v1.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = bp[(int64_t)(kb + u) * d.sbk];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool kok = kb + u < d.K;
+        a[u] = kok ? ap[(int64_t)(kb + u) * d.sak] : 0.f;
+        b[u] = kok ? bp[(int64_t)(kb + u) * d.sbk] : 0.f;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    for (int u = 0; u < 8; ++u)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mok ? a[u] : 0.f, nok ? b[u] : 0.f, acc, 0, 0, 0);
   }
-  for (; k < d.K; k += 2) {
-    const int kk = k + h;
-    float a = (m < d.M && kk < d.K) ? ap[(int64_t)kk * d.sak] : 0.f;
-    float b = (n < d.N && kk < d.K) ? bp[(int64_t)kk * d.sbk] : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
   }
-  if (n < d.N) {
+  __syncthreads();
+  if (wave == 0 && nok) {
     const float bv = d.bias ? d.bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (row < d.M) {
         float* p = d.C + (int64_t)row * d.ldc + n;
-        float v = d.alpha * acc[r] + bv;
+        float v = d.alpha * (((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane]) + bv;
         if (d.flags & DV_ACCUM) v += *p;
         if (d.flags & DV_SIGMOID) v = 1.f / (1.f + __expf(-v));
         if (d.flags & DV_RELU) v = fmaxf(v, 0.f);
@@ -317,7 +343,7 @@ extern "C" int dv_gemm_f32(int32_t M, int32_t N, int32_t K, const float* A, int6
 
 extern "C" int dv_gemm_f32_grouped(const dv_gemm_desc* descs_dev, int32_t n_groups, int32_t total_tiles, void* stream) {
   if (!descs_dev || n_groups <= 0 || total_tiles <= 0) return DV_EINVAL;
-  hipLaunchKernelGGL(gemm_f32_grouped_kernel, dim3((total_tiles + 3) / 4), dim3(256), 0, ST(stream), descs_dev, n_groups);
+  hipLaunchKernelGGL(gemm_f32_grouped_kernel, dim3(total_tiles), dim3(256), 0, ST(stream), descs_dev, n_groups);
   return dv_launch_status();
 }
 
