@@ -459,29 +459,78 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   // ---------------- epilogue
   T* out = reinterpret_cast<T*>(a.out);
   const int flags = a.flags;
+  if constexpr (sizeof(T) == 2) {
+    // bf16: each wave stages a 32-row strip of its tile in LDS ([row][col], 2-byte writes at immediate offsets) and
+    // writes it out as 16-byte vectors, eight lanes per 128-byte row segment -- instead of one 2-byte global store and
+    // a 64-bit address computation per element (the old epilogue was ~1/3 of all instructions a workgroup issued).
+    constexpr int SP = WN * 2 + 16;                  // staging row pitch (bytes)
+    constexpr int STG = 32 * SP;
+    constexpr int CPR = WN / 8;                      // 16-byte chunks per strip row
+    static_assert(NW * STG <= (int)sizeof(smem), "staging fits the tile buffers");
+    __syncthreads();                                 // every wave is done reading the last K tile
+    unsigned char* stg = smem + wave * STG;
+    const bool plain = !(flags & (DV_BIAS | DV_RELU | DV_SIGMOID));
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn0 + j * 32 + l31;
-      const float bv = ((flags & DV_BIAS) && col < a.N) ? a.bias[col] : 0.f;
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + j * 32 + l31;
+        const float bv = ((flags & DV_BIAS) && col < a.N) ? a.bias[col] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        float v = act_apply(acc[i][j][r] + bv, flags);
-        if (col >= a.N) v = 0.f;
-        if (row < a.M && col < a.NP) {
-          T* p = out + (size_t)row * a.ldo + col;
-          if (flags & DV_ACCUM) v += DT<T>::to_f(*p);
-          T tv = DT<T>::from_f(v);
-          *p = tv;
-          v = DT<T>::to_f(tv);
-        } else {
-          v = 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+          float v = acc[i][j][r];
+          if (!plain) {                              // (plain: rows >= M and columns >= N are exact zeros already)
+            v = act_apply(v + bv, flags);
+            if (col >= a.N || m0 + wm0 + i * 32 + rl >= a.M) v = 0.f;
+          }
+          const T tv = DT<T>::from_f(v);
+          *reinterpret_cast<T*>(stg + rl * SP + (j * 32 + l31) * 2) = tv;
+          acc[i][j][r] = DT<T>::to_f(tv);            // as stored: feeds the statistics
         }
-        acc[i][j][r] = v;   // as stored (0 outside the valid region): feeds the statistics
+      }
+#pragma unroll
+      for (int it = 0; it < (32 * CPR) / 64; ++it) {
+        const int idx = it * 64 + lane;
+        const int rl = idx / CPR, ch = idx % CPR;
+        const int row = m0 + wm0 + i * 32 + rl, col0 = n0 + wn0 + ch * 8;
+        if (row < a.M && col0 < a.NP) {
+          bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + rl * SP + ch * 16);
+          T* p = out + (size_t)row * a.ldo + col0;
+          if (flags & DV_ACCUM) {
+            const bf16x8 o = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)o[e]);
+          }
+          *reinterpret_cast<bf16x8*>(p) = v;
+        }
       }
     }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + j * 32 + l31;
+        const float bv = ((flags & DV_BIAS) && col < a.N) ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float v = act_apply(acc[i][j][r] + bv, flags);
+          if (col >= a.N) v = 0.f;
+          if (row < a.M && col < a.NP) {
+            T* p = out + (size_t)row * a.ldo + col;
+            if (flags & DV_ACCUM) v += DT<T>::to_f(*p);
+            T tv = DT<T>::from_f(v);
+            *p = tv;
+            v = DT<T>::to_f(tv);
+          } else {
+            v = 0.f;
+          }
+          acc[i][j][r] = v;   // as stored (0 outside the valid region): feeds the statistics
+        }
+      }
+  }
 
   if (MODE == MODE_FWD && (flags & DV_STATS)) {
     // per-tile BatchNorm partials: column sums and M2 about the tile mean, over valid rows
