@@ -61,6 +61,7 @@ SIGNATURES = {
     'dv_check_device': [],
     'dv_conv3d_stat_tiles': [CD],
     'dv_conv3d_tile_rows': [CD],
+    'dv_conv3d_tile_shape': [CD, I32, P, P],
     'dv_conv3d_fwd': [CD, P, P, P, P, P, P],
     'dv_conv3d_dgrad': [CD, P, P, P, P],
     'dv_conv3d_wgrad': [CD, P, P, P, P],

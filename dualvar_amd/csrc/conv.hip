@@ -459,6 +459,26 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   // ---------------- epilogue
   T* out = reinterpret_cast<T*>(a.out);
   const int flags = a.flags;
+  // BatchNorm partials of this tile (fwd + DV_STATS): per column the sum and M2 (about the tile mean) of the values AS
+  // STORED, over valid rows.  One pass, fused into the conversion loop: each wave accumulates sum(v - c) and
+  // sum((v - c)^2) about a provisional centre c = its first row's value (a sample of the column, so no cancellation
+  // problem), which needs no second sweep over the accumulators -- keeping them alive for a two-pass M2 used to cost
+  // the forward kernel 16..50 more VGPRs (one resident workgroup per CU less) than the otherwise identical dgrad.
+  constexpr bool STATS_MODE = (MODE == MODE_FWD);
+  const bool do_stats = STATS_MODE && (flags & DV_STATS);
+  const bool full_tile = m0 + BM <= a.M;
+  float st_c[TN], st_s1[TN], st_s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) st_c[j] = st_s1[j] = st_s2[j] = 0.f;
+  auto stat_acc = [&](int i, int j, int r, float vs, int rl /* row inside the wave strip i */) {
+    if constexpr (STATS_MODE) {
+      if (i == 0 && r == 0) st_c[j] = __shfl(vs, l31);          // row 0 of the wave's rows (held by the h == 0 half)
+      float d = vs - st_c[j];
+      if (!full_tile && m0 + wm0 + i * 32 + rl >= a.M) d = 0.f;
+      st_s1[j] += d;
+      st_s2[j] = fmaf(d, d, st_s2[j]);
+    }
+  };
   if constexpr (sizeof(T) == 2) {
     // bf16: each wave stages a 32-row strip of its tile in LDS ([row][col], 2-byte writes at immediate offsets) and
     // writes it out as 16-byte vectors, eight lanes per 128-byte row segment -- instead of one 2-byte global store and
@@ -486,7 +506,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
           }
           const T tv = DT<T>::from_f(v);
           *reinterpret_cast<T*>(stg + rl * SP + (j * 32 + l31) * 2) = tv;
-          acc[i][j][r] = DT<T>::to_f(tv);            // as stored: feeds the statistics
+          if (do_stats) stat_acc(i, j, r, DT<T>::to_f(tv), rl);
         }
       }
 #pragma unroll
@@ -515,7 +535,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
         const float bv = ((flags & DV_BIAS) && col < a.N) ? a.bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int row = m0 + wm0 + i * 32 + rl;
           float v = act_apply(acc[i][j][r] + bv, flags);
           if (col >= a.N) v = 0.f;
           if (row < a.M && col < a.NP) {
@@ -527,58 +548,101 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
           } else {
             v = 0.f;
           }
-          acc[i][j][r] = v;   // as stored (0 outside the valid region): feeds the statistics
+          acc[i][j][r] = v;   // as stored (0 outside the valid region): feeds the two-pass statistics below
         }
       }
   }
 
-  if (MODE == MODE_FWD && (flags & DV_STATS)) {
-    // per-tile BatchNorm partials: column sums and M2 about the tile mean, over valid rows
-    float* red = reinterpret_cast<float*>(smem);            // [WAVES_M][BN]
-    float* meanb = red + WAVES_M * BN;                      // [BN]
-    const int rows_here = min(BM, a.M - m0);
-    const int wmi = wave / WAVES_N;
-    __syncthreads();
+  if constexpr (STATS_MODE && sizeof(T) == 4) {
+    // f32 parity mode: exact two-pass M2 about the tile mean (register pressure is no concern here)
+    if (do_stats) {
+      float* red = reinterpret_cast<float*>(smem);            // [WAVES_M][BN]
+      float* meanb = red + WAVES_M * BN;                      // [BN]
+      const int rows_here = min(BM, a.M - m0);
+      const int wmi = wave / WAVES_N;
+      __syncthreads();
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float s = 0.f;
+      for (int j = 0; j < TN; ++j) {
+        float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
-      s += __shfl_xor(s, 32);
-      if (h == 0) red[wmi * BN + wn0 + j * 32 + l31] = s;
+          for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        s += __shfl_xor(s, 32);
+        if (h == 0) red[wmi * BN + wn0 + j * 32 + l31] = s;
+      }
+      __syncthreads();
+      if (tid < BN) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + tid];
+        meanb[tid] = s / (float)rows_here;
+        if (n0 + tid < a.N) a.stats[((size_t)tile_m * 2 + 0) * a.N + n0 + tid] = s;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float mu = meanb[wn0 + j * 32 + l31];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float dlt = acc[i][j][r] - mu;
+            s += (row < a.M) ? dlt * dlt : 0.f;
+          }
+        s += __shfl_xor(s, 32);
+        if (h == 0) red[wmi * BN + wn0 + j * 32 + l31] = s;
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < a.N) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + tid];
+        a.stats[((size_t)tile_m * 2 + 1) * a.N + n0 + tid] = s;
+      }
     }
-    __syncthreads();
-    if (tid < BN) {
-      float s = 0.f;
+  }
+  if constexpr (STATS_MODE && sizeof(T) == 2) {
+    if (do_stats) {
+      // merge: halves of a wave share the centre; the WAVES_M row strips of a column are combined pairwise (Chan)
+      float* red = reinterpret_cast<float*>(smem);            // [WAVES_M][2][BN]
+      static_assert(WAVES_M * 2 * BN * 4 <= (int)sizeof(smem), "stats scratch");
+      const int wmi = wave / WAVES_N;
+      const float nw = (float)max(0, min(WM, a.M - (m0 + wm0)));
+      __syncthreads();                                         // staging reads are done
 #pragma unroll
-      for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + tid];
-      meanb[tid] = s / (float)rows_here;
-      if (n0 + tid < a.N) a.stats[((size_t)tile_m * 2 + 0) * a.N + n0 + tid] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const float mu = meanb[wn0 + j * 32 + l31];
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          float dlt = acc[i][j][r] - mu;
-          s += (row < a.M) ? dlt * dlt : 0.f;
+      for (int j = 0; j < TN; ++j) {
+        float s1 = st_s1[j], s2 = st_s2[j];
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (h == 0) {
+          red[(wmi * 2 + 0) * BN + wn0 + j * 32 + l31] = s1 + nw * st_c[j];                    // sum
+          red[(wmi * 2 + 1) * BN + wn0 + j * 32 + l31] = nw > 0.f ? s2 - s1 * s1 / nw : 0.f;   // M2 about the strip mean
         }
-      s += __shfl_xor(s, 32);
-      if (h == 0) red[wmi * BN + wn0 + j * 32 + l31] = s;
-    }
-    __syncthreads();
-    if (tid < BN && n0 + tid < a.N) {
-      float s = 0.f;
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < a.N) {
+        float n = 0.f, S = 0.f, M2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + tid];
-      a.stats[((size_t)tile_m * 2 + 1) * a.N + n0 + tid] = s;
+        for (int w = 0; w < WAVES_M; ++w) {
+          const float nq = (float)max(0, min(WM, a.M - (m0 + w * WM)));
+          const float sw = red[(w * 2 + 0) * BN + tid], qw = red[(w * 2 + 1) * BN + tid];
+          if (nq > 0.f) {
+            if (n > 0.f) {
+              const float d = sw / nq - S / n;
+              M2 += qw + d * d * (n * nq / (n + nq));
+            } else {
+              M2 = qw;
+            }
+            S += sw;
+            n += nq;
+          }
+        }
+        a.stats[((size_t)tile_m * 2 + 0) * a.N + n0 + tid] = S;
+        a.stats[((size_t)tile_m * 2 + 1) * a.N + n0 + tid] = fmaxf(M2, 0.f);
+      }
     }
   }
 }
@@ -1013,6 +1077,15 @@ static int pick_bm(int M, int ntn) {
   return ((int64_t)((M + 127) / 128) * ntn >= 1024) ? 128 : 64;
 }
 
+// Tile (rows x columns) of the fwd / dgrad GEMM over M rows and NP (padded) columns: columns 32 / 64 / 128 by least
+// padding, rows 128 when that still gives >= 1024 workgroups, else 64.  (96- and 192-column tiles -- wave tiles 32x96
+// and 64x96 -- were measured too: 15-20 % faster on random data in isolation, but equal within noise inside the real
+// training step, where post-ReLU activations are half zeros and the clocks are higher; not kept.)
+static void pick_tile(int M, int NP, int& bm, int& bn) {
+  bn = pick_bn(NP);
+  bm = pick_bm(M, (NP + bn - 1) / bn);
+}
+
 template <typename T, int MODE, int GVB, int GM, int NS>
 static void launch_gemm_ns(int bm, int bn, const ConvArgs& a, int grid, hipStream_t s) {
   if (bm == 64) {
@@ -1054,6 +1127,20 @@ extern "C" int dv_conv3d_tile_rows(const dv_conv_desc* d) {
   return pick_bm((int)m, (d->cout_pitch + bn - 1) / bn);
 }
 
+extern "C" int dv_conv3d_tile_shape(const dv_conv_desc* d, int32_t dgrad, int32_t* rows, int32_t* cols) {
+  if (!d || !rows || !cols) return DV_EINVAL;
+  int bm, bn;
+  if (dgrad) {
+    const int64_t m = (int64_t)d->N * d->Ti * d->Hi * d->Wi;
+    pick_tile((int)m, d->cin_pitch, bm, bn);
+  } else {
+    const int64_t m = (int64_t)d->N * d->To * d->Ho * d->Wo;
+    pick_tile((int)m, d->cout_pitch, bm, bn);
+  }
+  *rows = bm; *cols = bn;
+  return DV_OK;
+}
+
 extern "C" int dv_conv3d_stat_tiles(const dv_conv_desc* d) {
   if (!d) return DV_EINVAL;
   const int64_t m = (int64_t)d->N * d->To * d->Ho * d->Wo;
@@ -1089,9 +1176,9 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   if (gvb == 16 && !aligned16(x)) return DV_EALIGN;
   const int esz = d->dtype == DV_F32 ? 4 : 2;
   if ((d->ldx * esz) % gvb || (a.ldw * esz) % gvb) return DV_EALIGN;
-  const int bn = pick_bn(a.NP);
+  int bm, bn;
+  pick_tile(a.M, a.NP, bm, bn);
   a.ntn = (a.NP + bn - 1) / bn;
-  const int bm = pick_bm(a.M, a.ntn);
   const int grid = a.ntn * ((a.M + bm - 1) / bm);
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == DV_F32) launch_gemm<float, MODE_FWD, 16>(bm, bn, a, grid, s);
@@ -1125,9 +1212,9 @@ extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void
     a.src_bytes = (int)sb; a.w_bytes = (int)wb;
     a.fCP = make_fastdiv((uint32_t)a.g.CP);
   }
-  const int bn = pick_bn(a.NP);
+  int bm, bn;
+  pick_tile(a.M, a.NP, bm, bn);
   a.ntn = (a.NP + bn - 1) / bn;
-  const int bm = pick_bm(a.M, a.ntn);
   const int grid = a.ntn * ((a.M + bm - 1) / bm);
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, a, grid, s);

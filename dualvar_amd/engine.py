@@ -280,12 +280,11 @@ class HostStep:
         self.call()
 
 
-def _pick_bn(np_):
-    if np_ <= 32:
-        return 32
-    if np_ <= 64:
-        return 64
-    return 128 if (np_ + 127) // 128 * 128 <= (np_ + 63) // 64 * 64 else 64
+def _tile_shape(lib, d, dgrad):
+    """(rows, cols) of the GEMM tile the library will pick: only for the per-launch profiling labels."""
+    r, c = C.c_int32(0), C.c_int32(0)
+    L.check(lib.dv_conv3d_tile_shape(C.byref(d), int(dgrad), C.byref(r), C.byref(c)), 'dv_conv3d_tile_shape')
+    return r.value, c.value
 
 
 def _dt(dtype):
@@ -451,7 +450,7 @@ class ConvOp(Op):
         flops = 2 * y.rows * sl.Cout * taps * sl.Cin
         wbytes = sl.Cout * taps * sl.Cin * es
         gv = 8 if (self.dtype == DV_BF16 and sl.cin_pitch % 8) else 16
-        kf = 'conv_gemm<%s,FWD,%d,%d,%d>' % (_dt(self.dtype), gv, self.tile_rows, _pick_bn(y.cpitch))
+        kf = 'conv_gemm<%s,FWD,%d,%d,%d>' % ((_dt(self.dtype), gv) + _tile_shape(lib, self.d, 0))
         shp = 'M%d Cin%d Cout%d k%s s%s' % (y.rows, sl.Cin, sl.Cout, 'x'.join(map(str, self.k)), 'x'.join(map(str, self.s)))
         f = [Launch('conv_fwd', kf, lib.dv_conv3d_fwd,
                     (C.byref(self.d), x.ptr, st.w_fwd(sl), 0, y.ptr, self.stats.data_ptr() if self.stats is not None else 0),
@@ -465,9 +464,7 @@ class ConvOp(Op):
             if self.need_dx:
                 acc = bool(self.acc.get('x'))
                 self.d_g = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=DV_ACCUM if acc else 0)
-                bnd = _pick_bn(x.cpitch)
-                bmd = 128 if ((x.rows + 127) // 128) * ((x.cpitch + bnd - 1) // bnd) >= 1024 else 64
-                b.append(Launch('conv_dgrad', 'conv_gemm<%s,DGRAD,16,%d,%d>' % (_dt(self.dtype), bmd, bnd),
+                b.append(Launch('conv_dgrad', 'conv_gemm<%s,DGRAD,16,%d,%d>' % ((_dt(self.dtype),) + _tile_shape(lib, self.d_g, 1)),
                                 lib.dv_conv3d_dgrad, (C.byref(self.d_g), y.grad.ptr, st.w_dgrad(sl), x.grad.ptr),
                                 _abytes(y) + wbytes + _abytes(x) * (2 if acc else 1), flops, shp))
         return f, b

@@ -86,6 +86,9 @@ typedef struct dv_conv_desc {
  * for small problems) -- both are what dv_bn_reduce_stats / dv_bn_stats_finalize need */
 int dv_conv3d_stat_tiles(const dv_conv_desc* d);
 int dv_conv3d_tile_rows(const dv_conv_desc* d);
+/* the GEMM tile (rows x columns) dv_conv3d_fwd (dgrad = 0) or dv_conv3d_dgrad (dgrad = 1) will use for this
+ * problem: informational (profiling labels, grid size = ceil(M/rows) * ceil(Npitch/cols)) */
+int dv_conv3d_tile_shape(const dv_conv_desc* d, int32_t dgrad, int32_t* rows, int32_t* cols);
 /* y = conv(x, w) [+bias][act]; with DV_STATS also stats[tile][2][Cout] = (sum, M2 about the
  * tile mean) of the values as stored.  */
 int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w_fwd, const float* bias,

@@ -60,7 +60,7 @@ def main():
     for name in names:
         N, T, H, W, Ci, Co, k, s, p = LAYERS[name]
         x = ops.new_act(N, T, H, W, Ci, L.DV_BF16, dev)
-        x.buf.normal_()
+        x.buf.normal_().relu_()                 # post-ReLU activations: half zeros, as inside the real step (clocks depend on it)
         To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
         y = ops.new_act(N, To, Ho, Wo, Co, L.DV_BF16, dev)
         dy = y.like()
