@@ -254,6 +254,8 @@ class Comm:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # RCCL gathers straight into one flat tensor; gloo (the CPU / single-GPU tests) only has the list form
+        self.flat_gather = self.world > 1 and dist.get_backend(group) == 'nccl'
 
 
 class Launch:
@@ -383,6 +385,7 @@ class Plan:
             op._b = b
         for op in reversed(self.ops):
             self.b_list += op._b
+        self.b_list = overlap_bn_exchange(self.b_list)
 
     # ------------------------------------------------------------------ execution
     def _run(self, lst):
@@ -405,6 +408,27 @@ class Plan:
         """(algorithmic bytes, flops) of one forward+backward replay."""
         ls = self.f_list + self.b_list
         return sum(l.bytes for l in ls), sum(l.flops for l in ls)
+
+
+def overlap_bn_exchange(b_list):
+    """Reorder a backward launch list so that every SyncBN sum exchange overlaps the weight-gradient kernels issued
+    since the previous exchange: [.. wgrad_a .. wgrad_b .. reduce, START, WAIT, apply ..] becomes
+    [.. reduce, START, wgrad_a, wgrad_b, WAIT, apply ..].  Safe because a weight gradient only reads a forward
+    activation and the (already final) gradient of its own conv output, and nothing in a backward list writes either
+    again; its own output (the fp32 gradient arena) is not read before the optimizer."""
+    out, since = [], 0                       # `since`: index in `out` just after the previous WAIT
+    for l in b_list:
+        if l.name == 'syncbn_allreduce_start':
+            moved = [x for x in out[since:] if x.name == 'conv_wgrad']
+            if moved:
+                out[since:] = [x for x in out[since:] if x.name != 'conv_wgrad']
+            out.append(l)
+            out += moved
+        else:
+            out.append(l)
+            if l.name == 'syncbn_allreduce_wait':
+                since = len(out)
+    return out
 
 
 class Op:
@@ -615,15 +639,26 @@ class BNGroupOp(Op):
         b = list(b_red)
         if R > 1:
             local, gathered, group = self.local, self.gathered, p.comm.group
-            f.append(HostStep('syncbn_allgather', lambda: dist.all_gather(list(gathered.unbind(0)), local, group=group)))
+            if p.comm.flat_gather:
+                f.append(HostStep('syncbn_allgather', lambda: dist.all_gather_into_tensor(gathered, local, group=group)))
+            else:
+                f.append(HostStep('syncbn_allgather', lambda: dist.all_gather(list(gathered.unbind(0)), local, group=group)))
             f += f_fin
             if p.with_grad:
                 first, last = self.members[0], self.members[-1]
                 lo, n = first.sums_off, last.sums_off + last.sums_len - first.sums_off
+                pending = []
 
-                def _allreduce():           # in place on the (contiguous) replica accumulators of the group
-                    dist.all_reduce(p.zero_arena.narrow(0, lo, n), group=group)
-                b.append(HostStep('syncbn_allreduce', _allreduce))
+                # In place on the (contiguous) replica accumulators of the group, asynchronously: Plan.finalize moves
+                # the weight-gradient kernels of the layers above between `start` and `wait`, so the exchange latency
+                # (the dominant multi-GPU cost of this path) hides behind work that does not need it.
+                def _start():
+                    pending.append(dist.all_reduce(p.zero_arena.narrow(0, lo, n), group=group, async_op=True))
+
+                def _wait():
+                    pending.pop().wait()
+                b.append(HostStep('syncbn_allreduce_start', _start))
+                b.append(HostStep('syncbn_allreduce_wait', _wait))
         f += f_app
         b += b_app
         return f, b

@@ -177,3 +177,23 @@ def test_checkpoint_interchange_with_reference_format(tmp_path):
     # partial load helper
     sub = {k: v for k, v in back['state_dict'].items() if 'series_proj_head' not in k}
     neq_load_customized(M.SimCLR_TimeSeriesV4('s3dg', 128, 0.07, False), sub, verbose=False)
+
+
+def test_backward_list_reorder_hides_syncbn_exchange_behind_weight_gradients():
+    """engine.overlap_bn_exchange: wgrads issued since the previous exchange move between START and WAIT; everything
+    else keeps its relative order (dgrad -> bn reduce -> START -> [wgrads] -> WAIT -> bn apply)."""
+    from dualvar_amd.engine import overlap_bn_exchange
+
+    class L_:
+        def __init__(self, name, tag):
+            self.name, self.tag = name, tag
+
+    names = [('bn_bwd_reduce', 'r3'), ('syncbn_allreduce_start', 's3'), ('syncbn_allreduce_wait', 'w3'), ('bn_bwd_apply', 'a3'),
+             ('conv_wgrad', 'wg3a'), ('conv_dgrad', 'dg3a'), ('conv_wgrad', 'wg3b'), ('conv_dgrad', 'dg3b'), ('maxpool_bwd', 'p'),
+             ('bn_bwd_reduce', 'r2'), ('syncbn_allreduce_start', 's2'), ('syncbn_allreduce_wait', 'w2'), ('bn_bwd_apply', 'a2'),
+             ('conv_wgrad', 'wg2'), ('conv_dgrad', 'dg2')]
+    out = [x.tag for x in overlap_bn_exchange([L_(n, t) for n, t in names])]
+    assert out == ['r3', 's3', 'w3', 'a3', 'dg3a', 'dg3b', 'p', 'r2', 's2', 'wg3a', 'wg3b', 'w2', 'a2', 'wg2', 'dg2']
+    # single-GPU lists (no exchange steps) are untouched
+    plain = [L_(n, t) for n, t in names if not n.startswith('syncbn')]
+    assert [x.tag for x in overlap_bn_exchange(plain)] == [x.tag for x in plain]
