@@ -27,9 +27,12 @@ class IngestOp(Op):
     """NCDHW fp32 clips (the reference's input layout) -> NDHWC compute dtype; optional Normalize and
     temporal segment shuffle fused in (pretrain.py:386-389, simclr.py:378-383)."""
 
-    def __init__(self, plan, N, T, H, W, n_seg):
+    def __init__(self, plan, N, T, H, W, n_seg, pad=0):
         super().__init__(plan)
-        self.y = plan.act(N, T, H, W, 3, cpitch=4, grad=False)
+        # pad > 0: frames carry a zero border of `pad` pixels (written once, here) -- the stem conv's padding
+        self.pad = pad
+        self.y = plan.act(N, T, H + 2 * pad, W + 2 * pad, 3, cpitch=4, grad=False, zero=True)
+        self.y.hw_pad = pad
         self.N, self.T, self.H, self.W, self.n_seg = N, T, H, W, n_seg
         self.src = self.perm = self.mean = self.istd = None
         self.stride_n = 3 * T * H * W
@@ -40,12 +43,12 @@ class IngestOp(Op):
 
     def _launch(self, stream):
         p = self.plan
-        L.check(p.lib.dv_ingest_ncdhw(p.dtype, self.src.data_ptr(), self.y.ptr, self.N, 3, self.T, self.H, self.W,
-                                      self.stride_n, self.y.ld,
-                                      self.mean.data_ptr() if self.mean is not None else 0,
-                                      self.istd.data_ptr() if self.istd is not None else 0,
-                                      self.perm.data_ptr() if self.perm is not None else 0,
-                                      self.n_seg if self.perm is not None else 0, stream), 'dv_ingest_ncdhw')
+        L.check(p.lib.dv_ingest_ncdhw_pad(p.dtype, self.src.data_ptr(), self.y.ptr, self.N, 3, self.T, self.H, self.W,
+                                          self.stride_n, self.y.ld,
+                                          self.mean.data_ptr() if self.mean is not None else 0,
+                                          self.istd.data_ptr() if self.istd is not None else 0,
+                                          self.perm.data_ptr() if self.perm is not None else 0,
+                                          self.n_seg if self.perm is not None else 0, self.pad, stream), 'dv_ingest_ncdhw_pad')
 
     def launches(self):
         return [_IngestStep(self)], []
@@ -102,6 +105,7 @@ class _BackboneFn(torch.autograd.Function):
 class HipBackbone(nn.Module):
     """Base class: owns (or is bound to) a ParamStore and a cache of launch plans."""
     feature_size = 0
+    stem_pad = 3            # all four backbones start with a 7x7 / stride 2 / padding 3 conv on RGB (see Plan.conv)
 
     def __init__(self):
         super().__init__()
@@ -174,7 +178,7 @@ class HipBackbone(nn.Module):
                 return pl
         comm = self.comm if self.comm is not None else Comm()
         pl = Plan(self.store, self.dtype, x.device, with_grad=with_grad, comm=comm)
-        pl.ingest = pl._push(IngestOp(pl, N, T, H, W, n_seg))
+        pl.ingest = pl._push(IngestOp(pl, N, T, H, W, n_seg, pad=self.stem_pad))
         out = self.emit(pl, pl.ingest.y)
         pl.out_act = out
         pl.mean_op = None
@@ -203,6 +207,8 @@ class HipBackbone(nn.Module):
     def _call(self, x, perm, want_map):
         if x.dim() != 5 or x.shape[1] != 3:
             raise ValueError('expected clips [N, 3, T, H, W], got %s' % (tuple(x.shape),))
+        if self.stem_pad and x.shape[4] % 2:
+            raise ValueError('frame width must be even (pixel-pair stem layout), got %d' % x.shape[4])
         if not x.is_cuda:
             raise L.DualVarHipError('dualvar_amd backbones run on the MI355X only (input is on %s)' % x.device)
         if not self.training:
@@ -240,6 +246,9 @@ def emit_conv_bn(plan, conv, bn, x, relu=True, residual=None, out=None):
 
 
 def register_conv_bn(store, conv, bn, first=False):
-    store.add_conv(conv.weight, cin_pitch=4 if conv.in_channels == 3 else None, need_dgrad=not first)
+    rgb = conv.in_channels == 3
+    # the RGB stems (7x7, stride 2, padding 3) store their kernel rows 8 taps wide: see Plan.conv
+    wide = 8 if (rgb and first and tuple(conv.kernel_size[1:]) == (7, 7)) else 0
+    store.add_conv(conv.weight, cin_pitch=4 if rgb else None, need_dgrad=not first, kw_store=wide)
     if bn is not None:
         store.add_bn(bn)

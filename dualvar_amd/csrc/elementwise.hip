@@ -17,7 +17,7 @@ static inline int grid_for(int64_t work_items, int max_blocks = 4096) {
 template <typename T>
 __global__ void ingest_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int T_, int H, int W,
                               int64_t sxn, int ldy, const float* mean3, const float* istd3,
-                              const int* perm, int n_seg) {
+                              const int* perm, int n_seg, int pad, int Hp, int Wp) {
   const int64_t total = (int64_t)N * T_ * H * W;
   const int64_t plane = (int64_t)H * W;
   const int seg = n_seg > 0 ? T_ / n_seg : T_;
@@ -35,7 +35,9 @@ __global__ void ingest_kernel(const float* __restrict__ x, T* __restrict__ y, in
       if (mean3) a = (a - mean3[c]) * istd3[c];
       v[c] = a;
     }
-    T* dst = y + i * ldy;
+    // destination pixel inside the (optionally zero-bordered) [N*T][Hp][Wp] frame
+    const int hh = (int)(hw / W), ww = (int)(hw - (int64_t)hh * W);
+    T* dst = y + ((nt * Hp + hh + pad) * (int64_t)Wp + ww + pad) * ldy;
     if (sizeof(T) == 4) {
       f32x4 o = {v[0], v[1], v[2], v[3]};
       *reinterpret_cast<f32x4*>(dst) = o;
@@ -753,7 +755,35 @@ extern "C" int dv_ingest_ncdhw(int32_t dtype, const float* x, void* y, int32_t N
   if ((mean3 == nullptr) != (istd3 == nullptr)) return DV_EINVAL;
   const int64_t total = (int64_t)N * T_ * H * W;
   DISPATCH_T(dtype, hipLaunchKernelGGL((ingest_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0, ST(stream), x,
-                                       (T*)y, N, C, T_, H, W, sxn, ldy, mean3, istd3, perm, n_seg));
+                                       (T*)y, N, C, T_, H, W, sxn, ldy, mean3, istd3, perm, n_seg, 0, H, W));
+  return dv_launch_status();
+}
+
+extern "C" int dv_ingest_ncdhw_pad(int32_t dtype, const float* x, void* y, int32_t N, int32_t C, int32_t T_, int32_t H,
+                                   int32_t W, int64_t sxn, int32_t ldy, const float* mean3, const float* istd3,
+                                   const int32_t* perm, int32_t n_seg, int32_t pad, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || C > 4 || ldy < 4 || ldy % 4 || pad < 0) return DV_EINVAL;
+  if (perm && (n_seg <= 0 || T_ % n_seg)) return DV_EINVAL;
+  if ((mean3 == nullptr) != (istd3 == nullptr)) return DV_EINVAL;
+  const int64_t total = (int64_t)N * T_ * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((ingest_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0, ST(stream), x,
+                                       (T*)y, N, C, T_, H, W, sxn, ldy, mean3, istd3, perm, n_seg, pad, H + 2 * pad,
+                                       W + 2 * pad));
+  return dv_launch_status();
+}
+
+__global__ void fill_cols_kernel(float* __restrict__ p, int64_t rows, int pitch, int col0, int ncols, float v) {
+  const int64_t total = rows * ncols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ncols;
+    p[r * pitch + col0 + (int)(i - r * ncols)] = v;
+  }
+}
+
+extern "C" int dv_fill_cols_f32(float* p, int64_t rows, int32_t pitch, int32_t col0, int32_t ncols, float value, void* stream) {
+  if (!p || rows <= 0 || ncols <= 0 || col0 < 0 || col0 + ncols > pitch) return DV_EINVAL;
+  hipLaunchKernelGGL(fill_cols_kernel, dim3(grid_for(rows * ncols)), dim3(kThreads), 0, ST(stream), p, rows, pitch, col0, ncols,
+                     value);
   return dv_launch_status();
 }
 

@@ -31,7 +31,7 @@ def _align8(n):
 
 class Slot:
     __slots__ = ('tensor', 'kind', 'off', 'size', 'Cout', 'Cin', 'taps', 'cin_pitch', 'cout_pitch', 'wd_off',
-                 'shape', 'strides', 'parts')
+                 'shape', 'strides', 'parts', 'kw_store')
 
 
 class ParamStore:
@@ -60,20 +60,25 @@ class ParamStore:
         s.tensor, s.kind = t, kind
         s.Cout = s.Cin = s.taps = s.cin_pitch = s.cout_pitch = 0
         s.wd_off = -1
+        s.kw_store = 0
         for k, v in kw.items():
             setattr(s, k, v)
         self.slots.append(s)
         self._by_id[id(t)] = s
         return s
 
-    def add_conv(self, weight, cin_pitch=None, need_dgrad=True):
-        """weight: [O, I, kt, kh, kw] or [O, I] parameter."""
+    def add_conv(self, weight, cin_pitch=None, need_dgrad=True, kw_store=0):
+        """weight: [O, I, kt, kh, kw] or [O, I] parameter.  kw_store > kw stores each kernel row kw_store taps wide
+        (the extra taps are structural zeros that the parameter view skips): the RGB stem, see Plan.conv."""
         O, I = weight.shape[:2]
         taps = 1
         for d in weight.shape[2:]:
             taps *= d
+        if kw_store:
+            assert weight.dim() == 5 and kw_store >= weight.shape[4] and not need_dgrad
+            taps = taps // weight.shape[4] * kw_store
         return self._add(weight, 'conv', Cout=O, Cin=I, taps=taps, cin_pitch=cin_pitch or cp8(I), cout_pitch=cp8(O),
-                         wd_off=0 if (need_dgrad and not self.no_dgrad) else -1)
+                         wd_off=0 if (need_dgrad and not self.no_dgrad) else -1, kw_store=kw_store)
 
     def add_merged(self, weights):
         """Several 1x1x1 convs reading the same input become ONE GEMM: their [Cout_i][Cin] blocks are registered
@@ -134,6 +139,7 @@ class ParamStore:
                 rowp = s.taps * s.cin_pitch
                 if len(shp) == 5:
                     kt, kh, kw = shp[2:]
+                    kw = s.kw_store or kw
                     s.strides = (rowp, 1, kh * kw * s.cin_pitch, kw * s.cin_pitch, s.cin_pitch)
                 else:
                     s.strides = (rowp, 1)
@@ -343,6 +349,21 @@ class Plan:
         return op
 
     def conv(self, slot, x, k, s, p, out=None, stats=True):
+        if getattr(x, 'hw_pad', 0):
+            # RGB stem on the zero-bordered ingest frames (include/dualvar_hip.h, dv_ingest_ncdhw_pad): the 7x7
+            # stride-2 padding-3 conv becomes a (kt,7,4)-tap stride-(st,2,1) conv over 8-channel pixel pairs
+            assert k[1:] == (7, 7) and s[1:] == (2, 2) and p[1:] == (3, 3) and x.hw_pad == 3 and slot.kw_store == 8, \
+                'the bordered ingest layout is for 7x7 / stride 2 / padding 3 RGB stems'
+            pairs = Act(x.buf.view(-1, 8), x.N, x.T, x.H, x.W // 2, 8, 8, 0, x.dtype, 8)
+            view = Slot()
+            for f in Slot.__slots__:
+                setattr(view, f, getattr(slot, f, None))
+            view.cin_pitch, view.Cin = 8, 8
+            op = self._push(ConvOp(self, view, pairs, (k[0], 7, 4), (s[0], 2, 1), (p[0], 0, 0), out, stats))
+            op.alg_k = k[0] * 49 * 3                     # algorithmic K for the flop count (not the padded 224)
+            op.zero_pad_taps = (slot.Cout * k[0] * 7, 32, 28, 4)    # rows, pitch, first pad column, count
+            op.y.producer = op
+            return op.y
         op = self._push(ConvOp(self, slot, x, k, s, p, out, stats))
         op.y.producer = op
         return op.y
@@ -463,6 +484,8 @@ class ConvOp(Op):
         self.tile_rows = ops.tile_rows(self.d)
         self.stats = plan.f32(self.tiles, 2, slot.Cout) if stats else None
         self.need_dx = plan.with_grad and x.grad is not None and slot.wd_off >= 0
+        self.alg_k = None
+        self.zero_pad_taps = None
 
     def grad_targets(self):
         return [('x', self.x)] if self.need_dx else []
@@ -471,8 +494,9 @@ class ConvOp(Op):
         p, st, lib, sl, x, y = self.plan, self.plan.store, self.plan.lib, self.slot, self.x, self.y
         es = ops.ESIZE[self.dtype]
         taps = self.k[0] * self.k[1] * self.k[2]
-        flops = 2 * y.rows * sl.Cout * taps * sl.Cin
-        wbytes = sl.Cout * taps * sl.Cin * es
+        kdim = self.alg_k if self.alg_k is not None else taps * sl.Cin
+        flops = 2 * y.rows * sl.Cout * kdim
+        wbytes = sl.Cout * kdim * es
         gv = 8 if (self.dtype == DV_BF16 and sl.cin_pitch % 8) else 16
         kf = 'conv_gemm<%s,FWD,%d,%d,%d>' % ((_dt(self.dtype), gv) + _tile_shape(lib, self.d, 0))
         shp = 'M%d Cin%d Cout%d k%s s%s' % (y.rows, sl.Cin, sl.Cout, 'x'.join(map(str, self.k)), 'x'.join(map(str, self.s)))
@@ -484,7 +508,10 @@ class ConvOp(Op):
             self.d_w = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=0)
             b.append(Launch('conv_wgrad', 'conv_wgrad<%s,%d,%s>' % (_dt(self.dtype), gv, '64,128' if ((sl.Cout + 63) // 64 * 64 < (sl.Cout + 127) // 128 * 128) else '128,64'), lib.dv_conv3d_wgrad,
                             (C.byref(self.d_w), x.ptr, y.grad.ptr, st.w_grad(sl)),
-                            _abytes(x) + _abytes(y) + sl.Cout * taps * sl.Cin * 4, flops, shp))
+                            _abytes(x) + _abytes(y) + sl.Cout * kdim * 4, flops, shp))
+            if self.zero_pad_taps is not None:
+                rows, pitch, c0, nc = self.zero_pad_taps
+                b.append(Launch('stem_pad_taps', 'fill_cols', lib.dv_fill_cols_f32, (st.w_grad(sl), rows, pitch, c0, nc, 0.0)))
             if self.need_dx:
                 acc = bool(self.acc.get('x'))
                 self.d_g = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=DV_ACCUM if acc else 0)

@@ -23,13 +23,14 @@ def stream_ptr():
 
 class Act:
     """[N,T,H,W,C] view with row pitch `ld` starting at channel `off` of `buf` ([rows, ld_total])."""
-    __slots__ = ('buf', 'N', 'T', 'H', 'W', 'C', 'ld', 'off', 'dtype', 'grad', 'cpitch', 'producer')
+    __slots__ = ('buf', 'N', 'T', 'H', 'W', 'C', 'ld', 'off', 'dtype', 'grad', 'cpitch', 'producer', 'hw_pad')
 
     def __init__(self, buf, N, T, H, W, C, ld, off, dtype, cpitch=None):
         self.buf, self.N, self.T, self.H, self.W, self.C, self.ld, self.off, self.dtype = buf, N, T, H, W, C, ld, off, dtype
         self.cpitch = cpitch if cpitch is not None else cp8(C)
         self.grad = None
         self.producer = None
+        self.hw_pad = 0              # zero border (pixels) materialised around H and W (the ingest frames)
 
     @property
     def rows(self):

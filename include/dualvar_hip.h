@@ -119,6 +119,17 @@ int dv_cast_arena(int32_t dtype, const float* src, void* dst, int64_t n, void* s
 int dv_ingest_ncdhw(int32_t dtype, const float* x, void* y, int32_t N, int32_t C, int32_t T, int32_t H,
                     int32_t W, int64_t x_stride_n, int32_t ldy, const float* mean3, const float* istd3,
                     const int32_t* perm, int32_t n_seg, void* stream);
+/* Same, into frames with a border of `pad` pixels on every side of H and W: y is [N*T][H+2*pad][W+2*pad][ldy] and
+ * only the interior is written (the caller zeroes the buffer once).  With the zero padding of the RGB stem conv
+ * (1x7x7 / 3x7x7, stride 2, padding 3: s3dg.py:137, r21d.py:201, r3d.py:116, resnet_2d3d.py:128) materialised like
+ * this, pixel pairs of the bordered frame are an 8-channel tensor [.., H+6, (W+6)/2, 8] on which that conv is a dense
+ * (kt x 7 x 4)-tap, stride (st, 2, 1), padding-free convolution over 16-byte vectors -- the fast gather path -- with
+ * the kernel's rows stored 8 wide (tap kw = 7 is a structural zero: dv_fill_cols_f32 keeps its gradient zero). */
+int dv_ingest_ncdhw_pad(int32_t dtype, const float* x, void* y, int32_t N, int32_t C, int32_t T, int32_t H,
+                        int32_t W, int64_t x_stride_n, int32_t ldy, const float* mean3, const float* istd3,
+                        const int32_t* perm, int32_t n_seg, int32_t pad, void* stream);
+/* p[r][col0 .. col0+ncols) = value for r < rows (row pitch `pitch` floats) */
+int dv_fill_cols_f32(float* p, int64_t rows, int32_t pitch, int32_t col0, int32_t ncols, float value, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * BatchNorm3d, training mode (nn.BatchNorm3d at s3dg.py:16,46-47, r21d.py:56,99,106,111,228, ...;

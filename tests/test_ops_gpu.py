@@ -173,6 +173,48 @@ def test_ingest(gpu, dtype):
 
 
 @pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
+@pytest.mark.parametrize('kt,st,pt', [(1, 1, 0), (3, 1, 1)])
+def test_rgb_stem_as_pixel_pair_conv(gpu, dtype, kt, st, pt):
+    """dv_ingest_ncdhw_pad + the (kt,7,4)-tap stride-(st,2,1) conv over 8-channel pixel pairs == the reference's
+    7x7 / stride 2 / padding 3 RGB stem (s3dg.py:137, r21d.py:201, r3d.py:116), forward and weight gradient; the
+    structural zero tap (kw = 7 of the 8-wide rows) gets a gradient from the gather and dv_fill_cols_f32 clears it."""
+    N, T, H, W, O = 2, 4, 18, 22, 24
+    x = q(rnd(N, 3, T, H, W, seed=61), dtype)
+    w = q(0.2 * rnd(O, 3, kt, 7, 7, seed=62), dtype)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, (st, 2, 2), (pt, 3, 3))
+    gy = q(rnd(*yr.shape, seed=63), dtype)
+    yr.backward(gy)
+
+    a = ops.new_act(N, T, H + 6, W + 6, 3, dtype, gpu, cpitch=4, zero=True)
+    ops.call('dv_ingest_ncdhw_pad', dtype, x.to(gpu), a, N, 3, T, H, W, 3 * T * H * W, 4, None, None, None, 0, 3)
+    frames = a.buf.view(N, T, H + 6, W + 6, 4).float().cpu()
+    assert torch.equal(frames[:, :, 3:-3, 3:-3, :3].permute(0, 4, 1, 2, 3), x)
+    assert float(frames[:, :, :3].abs().max()) == 0 and float(frames[:, :, -3:].abs().max()) == 0
+    assert float(frames[:, :, :, :3].abs().max()) == 0 and float(frames[:, :, :, -3:].abs().max()) == 0
+
+    pairs = ops.Act(a.buf.view(-1, 8), N, T, H + 6, (W + 6) // 2, 8, 8, 0, dtype, 8)
+    To, Ho, Wo = yr.shape[2:]
+    y = ops.new_act(N, To, Ho, Wo, O, dtype, gpu)
+    d = ops.conv_desc(dtype, pairs, y, (kt, 7, 4), (st, 2, 1), (pt, 0, 0))
+    w8 = torch.zeros(O, 3, kt, 7, 8)
+    w8[..., :7] = w
+    wp = ops.pack_weight(w8, 4).to(gpu)                       # [O][kt*7*8 taps][4] == [O][kt*7*4 pair taps][8]
+    wq = wp if dtype == DV_F32 else wp.bfloat16()
+    ops.conv_fwd(d, pairs, wq, None, y, None)
+    close(ops.act_to_ncdhw(y), yr.detach(), dtype, 'stem fwd')
+
+    dy = ops.act_from_ncdhw(gy.to(gpu), dtype)
+    dw = torch.zeros(O, kt * 7 * 8, 4, device=gpu)
+    ops.conv_wgrad(d, pairs, dy, dw)
+    assert float(dw.view(O, 3 if False else kt, 7, 8, 4)[:, :, :, 7].abs().max()) > 0      # the pad tap saw real pixels
+    ops.call('dv_fill_cols_f32', dw, O * kt * 7, 32, 28, 4, 0.0)
+    got = dw.view(O, kt, 7, 8, 4).cpu()
+    assert float(got[:, :, :, 7].abs().max()) == 0 and float(got[..., 3].abs().max()) == 0
+    close(got[:, :, :, :7, :3].permute(0, 4, 1, 2, 3), wr.grad, dtype, 'stem wgrad')
+
+
+@pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
 @pytest.mark.parametrize('C_,residual,relu', [(64, False, True), (83, True, True), (24, True, False), (1152, False, True)])
 def test_batchnorm_fwd_bwd(gpu, dtype, C_, residual, relu):
     N, T, H, W = 3, 2, 5, 4
