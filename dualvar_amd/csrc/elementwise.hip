@@ -551,13 +551,19 @@ __global__ void maxpool_bwd_kernel(PoolArgs a, const T* __restrict__ dy, const u
 }
 
 // ------------------------------------------------------------------ spatial mean / gating
+// One workgroup per (sample, slice of the S positions): with one workgroup per sample (N = 128) half the CUs had no
+// work and the others one resident workgroup each (~1.5 TB/s).  Slices are added with fp32 atomics into the zeroed
+// output (the host wrappers memset it on the same stream).
 template <typename T>
 __global__ void spatial_mean_kernel(const T* __restrict__ x, int ldx, int S, int C, int CP, float* __restrict__ out) {
   constexpr int V = DT<T>::VEC;
   const int n = blockIdx.x;
   const float inv = 1.f / (float)S;
+  const int rps = (S + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int s0 = (int)blockIdx.y * rps, s1 = min(S, s0 + rps);
+  if (s0 >= s1) return;
   column_reduce<V, 1>(
-      (int64_t)n * S, (int64_t)(n + 1) * S, CP,
+      (int64_t)n * S + s0, (int64_t)n * S + s1, CP,
       [&](int64_t r, int c0, float(&acc)[1][V]) {
         float v[V];
         Pack16<T>::load(x + r * ldx + c0, v);
@@ -567,7 +573,10 @@ __global__ void spatial_mean_kernel(const T* __restrict__ x, int ldx, int S, int
       [&](int c0, float(&acc)[1][V]) {
 #pragma unroll
         for (int e = 0; e < V; ++e)
-          if (c0 + e < C) out[(size_t)n * C + c0 + e] = acc[0][e] * inv;
+          if (c0 + e < C) {
+            if (gridDim.y > 1) atomicAdd(out + (size_t)n * C + c0 + e, acc[0][e] * inv);
+            else out[(size_t)n * C + c0 + e] = acc[0][e] * inv;
+          }
       });
 }
 
@@ -577,8 +586,11 @@ __global__ void gate_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const
                                        int x_is_output) {
   constexpr int V = DT<T>::VEC;
   const int n = blockIdx.x;
+  const int rps = (S + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int s0 = (int)blockIdx.y * rps, s1 = min(S, s0 + rps);
+  if (s0 >= s1) return;
   column_reduce<V, 1>(
-      (int64_t)n * S, (int64_t)(n + 1) * S, CP,
+      (int64_t)n * S + s0, (int64_t)n * S + s1, CP,
       [&](int64_t r, int c0, float(&acc)[1][V]) {
         float a[V], b[V];
         Pack16<T>::load(dy + r * lddy + c0, a);
@@ -591,7 +603,9 @@ __global__ void gate_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const
         for (int e = 0; e < V; ++e)
           if (c0 + e < C) {
             float gg = g[(size_t)n * C + c0 + e];
-            dpre[(size_t)n * C + c0 + e] = x_is_output ? acc[0][e] * (1.f - gg) : acc[0][e] * gg * (1.f - gg);
+            const float r = x_is_output ? acc[0][e] * (1.f - gg) : acc[0][e] * gg * (1.f - gg);
+            if (gridDim.y > 1) atomicAdd(dpre + (size_t)n * C + c0 + e, r);
+            else dpre[(size_t)n * C + c0 + e] = r;
           }
       });
 }
@@ -606,6 +620,7 @@ __global__ void rowscale_kernel(const T* __restrict__ a, int lda, const float* _
   constexpr int V = DT<T>::VEC;
   const uint32_t CV = fcv.d;
   const float invS = 1.f / (float)fS.d;
+  const bool vec = (C % V) == 0 && (MODE == 2 || ((uintptr_t)g & 15) == 0) && (MODE == 0 || ((uintptr_t)dm & 15) == 0);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const uint32_t row = fd_div(i, fcv);
     const int c0 = (int)(i - row * CV) * V;
@@ -613,15 +628,25 @@ __global__ void rowscale_kernel(const T* __restrict__ a, int lda, const float* _
     float v[V], old[V];
     if (MODE != 2) Pack16<T>::load(a + (size_t)row * lda + c0, v);
     if (accumulate) Pack16<T>::load(o + (size_t)row * ldo + c0, old);
+    float gv[V], dv[V];
+    if (vec) {                                     // C % V == 0: the [N][C] fp32 rows are read as float4s
+      if (MODE != 2) load_params<V>(g + (size_t)n * C, c0, gv);
+      if (MODE != 0) load_params<V>(dm + (size_t)n * C, c0, dv);
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const bool in = c0 + e < C;
+        gv[e] = (MODE != 2 && in) ? g[(size_t)n * C + c0 + e] : 0.f;
+        dv[e] = (MODE != 0 && in) ? dm[(size_t)n * C + c0 + e] : 0.f;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      const int c = c0 + e;
-      float r = 0.f;
-      if (c < C) {
-        if (MODE == 0) r = v[e] * g[(size_t)n * C + c];
-        else if (MODE == 1) r = v[e] * g[(size_t)n * C + c] + dm[(size_t)n * C + c] * invS;
-        else r = dm[(size_t)n * C + c] * invS;
-      }
+      float r;
+      if (MODE == 0) r = v[e] * gv[e];
+      else if (MODE == 1) r = v[e] * gv[e] + dv[e] * invS;
+      else r = dv[e] * invS;
+      if (!vec && c0 + e >= C) r = 0.f;
       v[e] = accumulate ? old[e] + r : r;
     }
     Pack16<T>::store(o + (size_t)row * ldo + c0, v);
@@ -967,6 +992,15 @@ extern "C" int dv_maxpool3d_bwd(const dv_pool_desc* d, const void* dy, const uin
   return dv_launch_status();
 }
 
+// slices of the S positions per sample: ~1024 workgroups in all, at least 128 positions each (below that the extra
+// memset + atomics cost more than the idle CUs)
+static int s_splits(int N, int S) {
+  int sp = (1024 + N - 1) / N;
+  const int cap = S / 128 > 0 ? S / 128 : 1;
+  if (sp > cap) sp = cap;
+  return sp < 1 ? 1 : sp;
+}
+
 extern "C" int dv_spatial_mean(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t S, int32_t C, float* out,
                                void* stream) {
   const int CP = cp8(C);
@@ -974,7 +1008,10 @@ extern "C" int dv_spatial_mean(int32_t dtype, const void* x, int32_t ldx, int32_
   if (!aligned16(x)) return DV_EALIGN;
   DISPATCH_T(dtype, {
     if (ldx % DT<T>::VEC) return DV_EALIGN;
-    hipLaunchKernelGGL((spatial_mean_kernel<T>), dim3(N), dim3(kThreads), 0, ST(stream), (const T*)x, ldx, S, C, CP, out);
+    const int sp = s_splits(N, S);
+    if (sp > 1 && hipMemsetAsync(out, 0, (size_t)N * C * sizeof(float), ST(stream)) != hipSuccess) return dv_launch_status();
+    hipLaunchKernelGGL((spatial_mean_kernel<T>), dim3(N, sp), dim3(kThreads), 0, ST(stream), (const T*)x, ldx, S, C,
+                       CP, out);
   });
   return dv_launch_status();
 }
@@ -1020,7 +1057,9 @@ extern "C" int dv_gate_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, c
   if (!aligned16(dy) || !aligned16(x)) return DV_EALIGN;
   DISPATCH_T(dtype, {
     if (lddy % DT<T>::VEC || ldx % DT<T>::VEC) return DV_EALIGN;
-    hipLaunchKernelGGL((gate_bwd_reduce_kernel<T>), dim3(N), dim3(kThreads), 0, ST(stream), (const T*)dy, lddy,
+    const int sp = s_splits(N, S);
+    if (sp > 1 && hipMemsetAsync(dpre, 0, (size_t)N * C * sizeof(float), ST(stream)) != hipSuccess) return dv_launch_status();
+    hipLaunchKernelGGL((gate_bwd_reduce_kernel<T>), dim3(N, sp), dim3(kThreads), 0, ST(stream), (const T*)dy, lddy,
                        (const T*)x, ldx, g, S, C, CP, dpre, x_is_output);
   });
   return dv_launch_status();
