@@ -36,7 +36,7 @@ struct ConvArgs {
   const void* w;         // [N rows][Ktot] K-contiguous, pitch ldw
   void* out;             // [M][ldo]
   const float* bias;
-  float* stats;          // [m_tiles][2][N]
+  float* stats;          // [2][N][m_tiles]
   int M, N, NP;          // rows, real cols, cols to write (zeros beyond N)
   int lds_, ldo, ldw;    // pitches in elements (src, out, weights)
   int ntn;               // number of N tiles
@@ -466,6 +466,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   // the forward kernel 16..50 more VGPRs (one resident workgroup per CU less) than the otherwise identical dgrad.
   constexpr bool STATS_MODE = (MODE == MODE_FWD);
   const bool do_stats = STATS_MODE && (flags & DV_STATS);
+  const int n_mt = (a.M + BM - 1) / BM;        // partials are stored [2][N][n_mt]: a channel's tiles are contiguous
   const bool full_tile = m0 + BM <= a.M;
   float st_c[TN], st_s1[TN], st_s2[TN];
 #pragma unroll
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
 #pragma unroll
         for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + tid];
         meanb[tid] = s / (float)rows_here;
-        if (n0 + tid < a.N) a.stats[((size_t)tile_m * 2 + 0) * a.N + n0 + tid] = s;
+        if (n0 + tid < a.N) a.stats[(size_t)(n0 + tid) * n_mt + tile_m] = s;
       }
       __syncthreads();
 #pragma unroll
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + tid];
-        a.stats[((size_t)tile_m * 2 + 1) * a.N + n0 + tid] = s;
+        a.stats[(size_t)(a.N + n0 + tid) * n_mt + tile_m] = s;
       }
     }
   }
@@ -640,8 +641,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
             n += nq;
           }
         }
-        a.stats[((size_t)tile_m * 2 + 0) * a.N + n0 + tid] = S;
-        a.stats[((size_t)tile_m * 2 + 1) * a.N + n0 + tid] = fmaxf(M2, 0.f);
+        a.stats[(size_t)(n0 + tid) * n_mt + tile_m] = S;
+        a.stats[(size_t)(a.N + n0 + tid) * n_mt + tile_m] = fmaxf(M2, 0.f);
       }
     }
   }

@@ -62,7 +62,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh /*>= blockDim/64 f
 }
 
 // ------------------------------------------------------------------ BN forward statistics
-// one block per channel: partials [tiles][2][C] -> local [2C+1]; with `fin` set (single rank) the block also
+// one block per channel: partials [2][P][tiles] (a channel's tiles contiguous: coalesced) -> local [2C+1]; with `fin` set (single rank) the block also
 // finalises the channel (mean / invstd / scale / shift / running statistics), saving a launch per BN layer
 struct BnFinalize {
   const float* gamma; const float* beta; float eps, momentum;
@@ -73,15 +73,17 @@ __device__ __forceinline__ void bn_reduce_stats_body(const float* __restrict__ p
                                                      const BnFinalize& f, int c) {
   __shared__ float sh[32];
   float s = 0.f;
-  for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s += part[((size_t)i * 2) * P + c];
+  const float* ps = part + (size_t)c * n_tiles;                 // sums of channel c, one per tile
+  const float* pq = part + ((size_t)P + c) * n_tiles;           // M2 about the tile mean
+  for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s += ps[i];
   const float S = block_sum(s, sh);
   const float mean = S / (float)M;
   float m2 = 0.f;
   for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
     int64_t left = M - (int64_t)i * tile_rows;
     float n_i = (float)(left < tile_rows ? left : tile_rows);
-    float d = part[((size_t)i * 2) * P + c] / n_i - mean;
-    m2 += part[((size_t)i * 2 + 1) * P + c] + n_i * d * d;
+    float d = ps[i] / n_i - mean;
+    m2 += pq[i] + n_i * d * d;
   }
   const float M2 = block_sum(m2, sh + 16);
   if (threadIdx.x == 0) {

@@ -482,7 +482,7 @@ class ConvOp(Op):
         self.d = ops.conv_desc(self.dtype, x, self.y, k, s, p, flags=DV_STATS if stats else 0)
         self.tiles = ops.stat_tiles(self.d)
         self.tile_rows = ops.tile_rows(self.d)
-        self.stats = plan.f32(self.tiles, 2, slot.Cout) if stats else None
+        self.stats = plan.f32(2, slot.Cout, self.tiles) if stats else None
         self.need_dx = plan.with_grad and x.grad is not None and slot.wd_off >= 0
         self.alg_k = None
         self.zero_pad_taps = None
@@ -568,7 +568,7 @@ class BNGroupOp(Op):
         for i, m in enumerate(self.members):
             it, bn, x, y, res = arr[i], m.bn, m.x, m.y, m.res
             gs, bs = st.slot(bn.weight), st.slot(bn.bias)
-            it.partials = m.conv.stats.data_ptr() + 4 * (x.off - m.conv.y.off)
+            it.partials = m.conv.stats.data_ptr() + 4 * (x.off - m.conv.y.off) * m.conv.tiles      # [2][Cout][tiles]
             it.local_stats = self.local.data_ptr() + 4 * m.loff
             it.gamma, it.beta = st.w_master(gs), st.w_master(bs)
             it.running_mean = bn.running_mean.data_ptr() if bn.running_mean is not None else 0
@@ -627,7 +627,7 @@ class BNGroupOp(Op):
             # x may be a channel slice of a merged conv's output: its partials are columns [coff, coff+C) of a wider table
             coff = x.off - m.conv.y.off
             spitch = m.conv.slot.Cout
-            sptr = m.conv.stats.data_ptr() + 4 * coff
+            sptr = m.conv.stats.data_ptr() + 4 * coff * m.conv.tiles        # partials are [2][Cout][tiles]
             if R == 1:
                 f_red.append(Launch('bn_stats_finalize', 'bn_reduce_stats', lib.dv_bn_stats_finalize,
                                     (sptr, m.conv.tiles, m.conv.tile_rows, spitch, M, Cn, local, st.w_master(gs), st.w_master(bs),

@@ -89,7 +89,7 @@ int dv_conv3d_tile_rows(const dv_conv_desc* d);
 /* the GEMM tile (rows x columns) dv_conv3d_fwd (dgrad = 0) or dv_conv3d_dgrad (dgrad = 1) will use for this
  * problem: informational (profiling labels, grid size = ceil(M/rows) * ceil(Npitch/cols)) */
 int dv_conv3d_tile_shape(const dv_conv_desc* d, int32_t dgrad, int32_t* rows, int32_t* cols);
-/* y = conv(x, w) [+bias][act]; with DV_STATS also stats[tile][2][Cout] = (sum, M2 about the
+/* y = conv(x, w) [+bias][act]; with DV_STATS also stats[2][Cout][tiles] = (sum, M2 about the
  * tile mean) of the values as stored.  */
 int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
                   void* y, float* stats, void* stream);
@@ -135,7 +135,7 @@ int dv_fill_cols_f32(float* p, int64_t rows, int32_t pitch, int32_t col0, int32_
  * BatchNorm3d, training mode (nn.BatchNorm3d at s3dg.py:16,46-47, r21d.py:56,99,106,111,228, ...;
  * SyncBatchNorm math torch/nn/modules/_functions.py:39-200).
  * Forward is split so that the cross-rank exchange can sit between the two calls:
- *   dv_bn_reduce_stats : conv-epilogue partials [tiles][2][C] -> local (sum, M2, count) [2*C+1]
+ *   dv_bn_reduce_stats : conv-epilogue partials [2][C][tiles] -> local (sum, M2, count) [2*C+1]
  *   dv_bn_finalize     : R ranks' (sum, M2, count) -> mean, invstd, scale=gamma*invstd,
  *                        shift=beta-mean*scale; running stats updated with momentum
  *                        (unbiased variance, PyTorch semantics).
@@ -154,8 +154,9 @@ int dv_fill_cols_f32(float* p, int64_t rows, int32_t pitch, int32_t col0, int32_
 /* Per-channel fp32 arrays read by the apply / backward kernels (scale, shift, mean, invstd, gamma, sums) are
  * accessed with 16-byte loads: they must be 16-byte aligned and readable up to CP = round_up(C, 8) floats;
  * `sums` arrays are laid out [2][CP]. */
-/* partials: [tiles][2][pitch] with this layer's C channels starting at the pointer (pitch > C when several
- * convolutions that share their input were run as one GEMM) */
+/* partials: [2][pitch][n_tiles] (a channel's tiles are contiguous, so the one-workgroup-per-channel reduction reads
+ * coalesced); the pointer is at this layer's first channel, i.e. base + first_channel * n_tiles (pitch > C when
+ * several convolutions that share their input were run as one GEMM) */
 int dv_bn_reduce_stats(const float* partials, int32_t n_tiles, int32_t tile_rows, int32_t pitch, int64_t M, int32_t C,
                        float* local_stats /*[2*C+1]*/, void* stream);
 int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int32_t tile_rows, int32_t pitch, int64_t M, int32_t C,

@@ -74,7 +74,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, dtype, case):
     wp = ops.pack_weight(w.to(gpu), cin_pitch)
     wpc = wp.to(ops.TORCH_DTYPE[dtype])
     tiles = ops.stat_tiles(d)
-    stats = torch.zeros(tiles, 2, Cout, device=gpu)
+    stats = torch.zeros(2, Cout, tiles, device=gpu)            # [2][Cout][tiles]
     ops.conv_fwd(d, xa, wpc, None, ya, stats)
     torch.cuda.synchronize()
     close(ops.act_to_ncdhw(ya), yr, dtype, name + ' fwd')
@@ -238,11 +238,11 @@ def test_batchnorm_fwd_bwd(gpu, dtype, C_, residual, relu):
     # statistics straight from the tensor (as the conv epilogue would emit them): one 128-row tile each
     tiles = (M + 127) // 128
     xs = xa.buf[:, :C_].float()
-    part = torch.zeros(tiles, 2, C_, device=gpu)
+    part = torch.zeros(2, C_, tiles, device=gpu)               # [2][C][tiles], as dv_conv3d_fwd writes them
     for i in range(tiles):
         blk = xs[i * 128:(i + 1) * 128]
-        part[i, 0] = blk.sum(0)
-        part[i, 1] = ((blk - blk.mean(0)) ** 2).sum(0)
+        part[0, :, i] = blk.sum(0)
+        part[1, :, i] = ((blk - blk.mean(0)) ** 2).sum(0)
     local = torch.zeros(2 * C_ + 1, device=gpu)
     ops.call('dv_bn_reduce_stats', part, tiles, 128, C_, M, C_, local)
     # two "ranks" with half the data each must give the same result as one (SyncBN identity)
