@@ -552,6 +552,104 @@ __global__ void maxpool_bwd_kernel(PoolArgs a, const T* __restrict__ dy, const u
   }
 }
 
+// ------------------------------------------------------------------ MaxPool3d 3x3x3, stride 1, padding 1, bf16
+// (the pool branch of every Inception block, s3dg.py:105).  The generic kernels above spend ~6 VALU instructions per
+// tap and element on convert / compare / select-value / select-index and are VALU bound (~1 TB/s).  Here a thread
+// owns FOUR consecutive outputs along W (6 input columns per (dt, dh): half the loads), and value and position are
+// ONE sortable 32-bit key per loaded element,
+//     key = [bf16 bits made order-preserving : 16][63 - position inside the thread's 3x3x6 input block : 6 .. 0]
+// so "larger value, earlier tap on ties" (PyTorch's first-max rule) is a plain unsigned max (v_max_u32)
+// over the three windows a column belongs to.  NaNs with the sign bit clear win as in PyTorch; -0.0 orders below +0.0 (a
+// tie in PyTorch) -- inputs here are post-ReLU.  Same outputs (values, uint8 tap index) as the generic kernel.
+struct Pool3Args {
+  int N, T, H, W, C, CP, ldx, ldy;
+  uint32_t total;           // N*T*H*ceil(W/4)*CV work items
+  FastDiv fcv, fWr, fH, fT;
+};
+
+__device__ __forceinline__ uint32_t pool_key(uint32_t x /* bf16 in the top half, low half zero */, uint32_t code) {
+  const uint32_t m = (uint32_t)((int32_t)x >> 31);
+  return x ^ ((m & 0x7fff0000u) | (0x80000000u | code));
+}
+
+__global__ __launch_bounds__(256) void maxpool333_fwd_kernel(Pool3Args a, const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                              uint8_t* __restrict__ idx) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.total; i += gridDim.x * blockDim.x) {
+    uint32_t q, cvi, run, h_, t_, n_;
+    fd_divmod(i, a.fcv, q, cvi);
+    fd_divmod(q, a.fWr, q, run);
+    fd_divmod(q, a.fH, q, h_);
+    fd_divmod(q, a.fT, n_, t_);
+    const int c0 = (int)cvi * 8, w0 = (int)run * 4, ho = (int)h_, to = (int)t_, n = (int)n_;
+    uint32_t best[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) best[j][e] = 0u;
+    // One (dt, dh) row of the window per iteration, NOT unrolled: unrolled, the compiler hoists all 54 loads and the
+    // kernel needs 175+ VGPRs (2 waves per SIMD, slower than the generic kernel); software-pipelining the rows by
+    // hand (114 VGPRs) was slower too -- resident waves hide the latency better than either.
+#pragma unroll 1
+    for (int cmb = 0; cmb < 9; ++cmb) {
+      const int dt = cmb / 3, dh = cmb - dt * 3;
+      const int t = to - 1 + dt, hh = ho - 1 + dh;
+      if ((unsigned)t >= (unsigned)a.T || (unsigned)hh >= (unsigned)a.H) continue;
+      const bf16_t* rowp = x + ((int64_t)((n * a.T + t) * a.H + hh) * a.W) * a.ldx + c0;
+#pragma unroll
+      for (int jj = 0; jj < 6; ++jj) {
+        const int w = w0 - 1 + jj;
+        if ((unsigned)w >= (unsigned)a.W) continue;                // padding: below every real key, nothing to do
+        const uint32_t code = 63u - (uint32_t)(cmb * 6 + jj);
+        const uint4 v = *reinterpret_cast<const uint4*>(rowp + (int64_t)w * a.ldx);
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t key = pool_key((e & 1) ? (d[e >> 1] & 0xffff0000u) : (d[e >> 1] << 16), code);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (jj - j >= 0 && jj - j <= 2) best[j][e] = max(best[j][e], key);     // column jj feeds outputs jj-2 .. jj
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int wo = w0 + j;
+      if (wo >= a.W) break;
+      const int64_t m = (int64_t)((n * a.T + to) * a.H + ho) * a.W + wo;
+      uint32_t ov[4];
+      uint32_t ib[2] = {0u, 0u};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t key = best[j][e];
+        const uint32_t s16 = key >> 16;
+        const uint32_t bits = (s16 & 0x8000u) ? (s16 ^ 0x8000u) : (~s16 & 0xffffu);
+        const uint32_t pos = 63u - (key & 63u);                 // (dt*3+dh)*6 + jj
+        const uint32_t dtdh = (pos * 43u) >> 8;                 // pos / 6 for pos < 64
+        const uint32_t tap = dtdh * 3u + (pos - dtdh * 6u) - (uint32_t)j;
+        if (e & 1) ov[e >> 1] |= bits << 16; else ov[e >> 1] = bits;
+        ib[e >> 2] |= (tap & 0xffu) << (8 * (e & 3));
+      }
+      *reinterpret_cast<uint4*>(y + m * a.ldy + c0) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+      *reinterpret_cast<uint2*>(idx + m * a.CP + c0) = make_uint2(ib[0], ib[1]);
+    }
+  }
+}
+
+static bool pool333(const dv_pool_desc* d) {
+  return d->dtype == DV_BF16 && d->kt == 3 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 &&
+         d->pt == 1 && d->ph == 1 && d->pw == 1;
+}
+static bool pool333_args(const PoolArgs& p, Pool3Args& a) {
+  a.N = p.N; a.T = p.Ti; a.H = p.Hi; a.W = p.Wi; a.C = p.C; a.CP = p.CP; a.ldx = p.ldx; a.ldy = p.ldy;
+  const int runs = (p.Wi + 3) / 4, cv = p.CP / 8;
+  const int64_t total = (int64_t)p.N * p.Ti * p.Hi * runs * cv;
+  if (total >= (1ll << 31)) return false;
+  a.total = (uint32_t)total;
+  a.fcv = make_fastdiv((uint32_t)cv); a.fWr = make_fastdiv((uint32_t)runs);
+  a.fH = make_fastdiv((uint32_t)p.Hi); a.fT = make_fastdiv((uint32_t)p.Ti);
+  return true;
+}
+
 // ------------------------------------------------------------------ spatial mean / gating
 // One workgroup per (sample, slice of the S positions): with one workgroup per sample (N = 128) half the CUs had no
 // work and the others one resident workgroup each (~1.5 TB/s).  Slices are added with fp32 atomics into the zeroed
@@ -971,6 +1069,12 @@ extern "C" int dv_maxpool3d_fwd(const dv_pool_desc* d, const void* x, void* y, u
   if (rc) return rc;
   if (!x || !y || !idx) return DV_EINVAL;
   if (!aligned16(x) || !aligned16(y) || (reinterpret_cast<uintptr_t>(idx) & 7)) return DV_EALIGN;
+  Pool3Args a3;
+  if (pool333(d) && pool333_args(a, a3)) {
+    hipLaunchKernelGGL(maxpool333_fwd_kernel, dim3(grid_for(a3.total, 16384)), dim3(kThreads), 0, ST(stream), a3,
+                       (const bf16_t*)x, (bf16_t*)y, idx);
+    return dv_launch_status();
+  }
   DISPATCH_T(d->dtype, {
     const int64_t total = (int64_t)a.N * a.To * a.Ho * a.Wo * (a.CP / DT<T>::VEC);
     hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(total, 16384)), dim3(kThreads), 0, ST(stream), a, (const T*)x,

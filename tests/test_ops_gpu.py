@@ -330,6 +330,36 @@ def test_maxpool(gpu, dtype, k, s, p):
     close(ops.act_to_ncdhw(dxa), 2 * xr.grad, dtype, 'maxpool bwd accum', factor=2)
 
 
+@pytest.mark.parametrize('W', [3, 7, 14])
+def test_maxpool_333_fast_path_signed_values(gpu, W):
+    """the bf16 3x3x3 / stride 1 / padding 1 kernel orders values through integer keys: negative values, every
+    run-length remainder of W (runs of four outputs) and the uint8 tap index all have to agree with PyTorch"""
+    N, C_, T, H = 2, 40, 3, 5
+    x = q(rnd(N, C_, T, H, W, seed=71) * 3 - 1, DV_BF16)
+    x[:, :8] = -x[:, :8].abs()                                      # windows whose maximum is negative
+    xr = x.clone().requires_grad_(True)
+    yr, ir = F.max_pool3d(xr, 3, 1, 1, return_indices=True)
+    gy = q(rnd(*yr.shape, seed=72), DV_BF16)
+    yr.backward(gy)
+    xa = ops.act_from_ncdhw(x.to(gpu), DV_BF16)
+    ya = ops.new_act(N, T, H, W, C_, DV_BF16, gpu)
+    idx = torch.zeros(ya.rows, ops.cp8(C_), dtype=torch.uint8, device=gpu)
+    d = ops.pool_desc(DV_BF16, xa, ya, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    ops.call('dv_maxpool3d_fwd', d, xa, ya, idx)
+    assert torch.equal(ops.act_to_ncdhw(ya).cpu(), yr.detach())
+    # tap index -> flat input index, as PyTorch reports it
+    tap = idx.view(N, T, H, W, -1)[..., :C_].permute(0, 4, 1, 2, 3).long().cpu()
+    dt, dh, dw = tap // 9, tap // 3 % 3, tap % 3
+    tt = torch.arange(T).view(1, 1, T, 1, 1) - 1 + dt
+    hh = torch.arange(H).view(1, 1, 1, H, 1) - 1 + dh
+    ww = torch.arange(W).view(1, 1, 1, 1, W) - 1 + dw
+    assert torch.equal((tt * H + hh) * W + ww, ir)
+    dya = ops.act_from_ncdhw(gy.to(gpu), DV_BF16)
+    dxa = ops.new_act(N, T, H, W, C_, DV_BF16, gpu)
+    ops.call('dv_maxpool3d_bwd', d, dya, idx, dxa, 0)
+    close(ops.act_to_ncdhw(dxa), q(xr.grad, DV_BF16), DV_BF16, 'maxpool333 bwd')
+
+
 @pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
 def test_self_gating_and_mean(gpu, dtype):
     N, C_, T, H, W = 3, 48, 2, 5, 5
