@@ -77,14 +77,21 @@ class KernelTimer:
         self.only = only               # None: time every launch (calibration); else a kernel-name
         self.rec = []                  # (launch, start, end)
 
-    def __call__(self, launch, stream):
+    def __call__(self, launch, stream, stream_obj=None):
+        """stream: raw hipStream_t the launch goes to; stream_obj: its torch stream when it is not the current one
+        (the plan issues weight gradients on a side stream) -- the events are recorded on the launch's own stream"""
         if self.only is not None and launch.kname != self.only:
             launch(stream)
             return
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        launch(stream)
-        b.record()
+        if stream_obj is None:
+            a.record()
+            launch(stream)
+            b.record()
+        else:
+            a.record(stream_obj)
+            launch(stream)
+            b.record(stream_obj)
         self.rec.append((launch, a, b))
 
     def summary(self):

@@ -13,6 +13,7 @@ Gradients accumulate in a twin arena (one flat all-reduce for data parallel), bf
 copies and the dgrad-layout weights are refreshed by two launches after every update.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -27,6 +28,10 @@ BN_REPLICAS = 8       # replicas of the BN-backward atomic accumulators (dv_bn_b
 
 def _align8(n):
     return (n + 7) & ~7
+
+
+# weight gradients on a side stream (see Plan.run_backward); DUALVAR_WGRAD_STREAM=0 keeps everything on one stream
+WGRAD_SIDE_STREAM = os.environ.get('DUALVAR_WGRAD_STREAM', '1') != '0'
 
 
 class Slot:
@@ -312,6 +317,8 @@ class Plan:
         self.timer = None            # set by bench.py: callable(launch, stream) recording HIP events
         self._zero_words = 0         # fp32 words that must be zero at the start of every backward (atomic targets)
         self.zero_arena = None
+        self._side = None            # side stream + events of run_backward
+        self._events = None
 
     # ------------------------------------------------------------------ buffers
     def act(self, N, T, H, W, C_, dtype=None, cpitch=None, grad=None, zero=False):
@@ -423,7 +430,42 @@ class Plan:
         self._run(self.f_list)
 
     def run_backward(self):
-        self._run(self.b_list)
+        """Weight gradients leave the critical path: a conv's wgrad needs only the finished gradient of its own
+        output and a forward activation, and nothing reads its result before the optimizer -- so every conv_wgrad
+        (and the stem's pad-tap clear that follows it) is issued on a SIDE stream behind an event recorded on the main
+        stream at its list position, and the main stream joins the side stream at the end.  The dgrad / BatchNorm /
+        pool chain of the small late layers leaves most CUs idle; the wgrads fill them."""
+        if not WGRAD_SIDE_STREAM or not self.b_list:
+            return self._run(self.b_list)
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._events = [torch.cuda.Event() for l in self.b_list if l.name == 'conv_wgrad']
+        side = self._side
+        sm, ss = main.cuda_stream, side.cuda_stream
+        t = self.timer
+        k = 0
+        on_side = False
+        for l in self.b_list:
+            nm = l.name
+            if nm == 'conv_wgrad':
+                ev = self._events[k]
+                k += 1
+                ev.record(main)
+                side.wait_event(ev)
+                on_side = True
+            elif nm != 'stem_pad_taps':
+                on_side = False
+            if on_side:
+                if t is None:
+                    l(ss)
+                else:
+                    t(l, ss, side)
+            elif t is None:
+                l(sm)
+            else:
+                t(l, sm)
+        main.wait_stream(side)
 
     def cost(self):
         """(algorithmic bytes, flops) of one forward+backward replay."""
