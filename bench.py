@@ -189,11 +189,17 @@ def main():
     for _ in range(max(args.warmup - 1, 1)):
         step()
     # calibration step: time every launch once to find the kernel with the largest share
+    # (single stream for this one step, so that every kernel's time is its own: in the timed region the weight
+    # gradients run on a side stream, concurrently with the main chain -- engine.Plan.run_backward)
+    import dualvar_amd.engine as _eng
+    side_default = _eng.WGRAD_SIDE_STREAM
+    _eng.WGRAD_SIDE_STREAM = False
     cal = KernelTimer()
     for p in all_plans(model):
         p.timer = cal
     step()
     torch.cuda.synchronize()
+    _eng.WGRAD_SIDE_STREAM = side_default
     csum = cal.summary()
     if args.dump_launches and rank == 0:
         with open(args.dump_launches, 'w') as fh:
@@ -243,12 +249,18 @@ def main():
         try:        # HBM bytes per launch of this kernel family from the committed PMC passes (tools/pmc_traffic.py)
             pj = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_traffic.json'))[-1]
             fam = json.load(open(os.path.join(ROOT, 'profiles', pj)))['families']
-            key = dominant.split('<')[0]
+            key = dominant
             if key in fam:
                 traffic = round(fam[key]['hbm_bytes_per_launch'])
                 roof_src = pj
         except Exception:
             traffic = None
+        # the same kernel alone on the GPU (calibration step, one stream): what the kernel itself achieves
+        cn, cms, cbytes, cflops = csum[dominant]
+        iso_bw, iso_tf = cbytes / (cms * 1e-3) / 1e9, cflops / (cms * 1e-3) / 1e12
+        roof['isolated'] = {'avg_launch_us': round(cms / cn * 1e3, 2), 'GB/s': round(iso_bw, 1), 'TFLOP/s': round(iso_tf, 2),
+                            'frac_hbm': round(iso_bw / HBM_PEAK_GBS, 4), 'frac_mfma': round(iso_tf / MFMA_PEAK_TF[args.dtype], 4)}
+        roof['concurrent'] = bool(side_default and dominant.startswith('conv_wgrad'))
         roof.update({'traffic': traffic, 'kernel': dominant, 'launches_per_step': n // args.steps,
                      'avg_launch_us': round(avg_ms * 1e3, 2), 'share_of_kernel_time': round(csum[dominant][1] / tot_ms, 3),
                      'other_bound_frac': round(min(f_hbm, f_mfma), 4),

@@ -18,13 +18,29 @@ import sys
 
 
 def short(name):
-    """map a mangled / demangled kernel name to the bench's kernel label family"""
+    """map a (mangled or rocprof-demangled) kernel name to the label dualvar_amd.engine gives the launch"""
     n = name
-    for key, pat in (('conv_wgrad', r'conv_wgrad_kernel'), ('conv_gemm', r'conv_gemm_kernel'),
-                     ('bn_bwd_reduce_multi', r'bn_bwd_reduce_multi'), ('bn_bwd_apply_multi', r'bn_bwd_apply_multi'),
-                     ('bn_apply_multi', r'bn_apply_multi'), ('bn_stats_multi', r'bn_stats_multi'),
-                     ('bn_bwd_reduce', r'bn_bwd_reduce_kernel'), ('bn_bwd_apply', r'bn_bwd_apply_kernel'),
-                     ('bn_apply', r'bn_apply_kernel'), ('maxpool_fwd', r'maxpool_fwd'), ('maxpool_bwd', r'maxpool_bwd')):
+    m = re.search(r'conv_wgrad_dma_kernelILi(\d+)ELi(\d+)E', n) or re.search(r'conv_wgrad_dma_kernel<(\d+), (\d+)>', n)
+    if m:
+        return 'conv_wgrad<bf16,16,%s,%s>' % m.groups()
+    m = re.search(r'conv_wgrad_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)E', n)
+    if m:
+        return 'conv_wgrad<%s,%s,%s,%s>' % ((('bf16' if m.group(1) == 'DF16b' else 'f32'),) + m.groups()[1:])
+    m = re.search(r'conv_gemm_kernelI(DF16b|f)Li(\d)ELi(\d+)ELi(\d+)ELi(\d+)E', n)
+    if m:
+        return 'conv_gemm<%s,%s,%s,%s,%s>' % ('bf16' if m.group(1) == 'DF16b' else 'f32', 'DGRAD' if m.group(2) == '1' else 'FWD',
+                                             m.group(3), m.group(4), m.group(5))
+    m = re.search(r'conv_gemm_kernel<bool _Accum, int, E, (\d+), (\d+), (\d+)', n)      # rocprof's demangler on <__bf16, 1, ...>
+    if m:
+        return 'conv_gemm<bf16,DGRAD,%s,%s,%s>' % m.groups()
+    m = re.search(r'conv_gemm_kernel<float, (\d), (\d+), (\d+), (\d+)', n)
+    if m:
+        return 'conv_gemm<f32,%s,%s,%s,%s>' % ((('DGRAD' if m.group(1) == '1' else 'FWD'),) + m.groups()[1:])
+    for key, pat in (('bn_bwd_reduce_multi<bf16>', r'bn_bwd_reduce_multi'), ('bn_bwd_apply_multi<bf16>', r'bn_bwd_apply_multi'),
+                     ('bn_apply_multi<bf16>', r'bn_apply_multi'), ('bn_stats_multi', r'bn_stats_multi'),
+                     ('bn_bwd_reduce<bf16>', r'bn_bwd_reduce_kernel'), ('bn_bwd_apply<bf16>', r'bn_bwd_apply_kernel'),
+                     ('bn_apply<bf16>', r'bn_apply_kernel'), ('maxpool_fwd<bf16>', r'maxpool(333)?_fwd'),
+                     ('maxpool_bwd<bf16>', r'maxpool_bwd')):
         if re.search(pat, n):
             return key
     return None
