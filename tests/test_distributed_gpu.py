@@ -76,8 +76,19 @@ def test_two_ranks_equal_one_process(gpu, kind):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
     [p.start() for p in procs]
     res = {}
-    for _ in range(2):
-        r, outs, grads, synced = q.get(timeout=600)
+    import queue
+    import time
+    deadline = time.time() + 300
+    while len(res) < 2:
+        try:
+            r, outs, grads, synced = q.get(timeout=2)
+        except queue.Empty:
+            # a rank that died takes its peer's collectives with it: fail at once instead of waiting them out
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() > deadline:
+                [p.kill() for p in procs if p.is_alive()]
+                pytest.fail('rank process died or timed out (exit codes %s)' % [p.exitcode for p in procs])
+            continue
         t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}    # noqa: E731
         res[r] = (t(outs), t(grads), t(synced))
     [p.join(timeout=120) for p in procs]
