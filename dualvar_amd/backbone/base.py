@@ -170,14 +170,14 @@ class HipBackbone(nn.Module):
     def _acquire_plan(self, x, use_perm, want_map, with_grad):
         N, _, T, H, W = x.shape
         n_seg = 0
-        key = (N, T, H, W, use_perm, want_map, with_grad, self.store.generation, self.dtype)
+        key = (N, T, H, W, use_perm, want_map, with_grad, self.store.generation, self.dtype, self.training)
         lst = self._plans.setdefault(key, [])
         for pl in lst:
             ref = pl._busy_ref
             if ref is None or ref() is None:
                 return pl
         comm = self.comm if self.comm is not None else Comm()
-        pl = Plan(self.store, self.dtype, x.device, with_grad=with_grad, comm=comm)
+        pl = Plan(self.store, self.dtype, x.device, with_grad=with_grad, comm=comm, training=self.training)
         pl.ingest = pl._push(IngestOp(pl, N, T, H, W, n_seg, pad=self.stem_pad))
         out = self.emit(pl, pl.ingest.y)
         pl.out_act = out
@@ -211,13 +211,16 @@ class HipBackbone(nn.Module):
             raise ValueError('frame width must be even (pixel-pair stem layout), got %d' % x.shape[4])
         if not x.is_cuda:
             raise L.DualVarHipError('dualvar_amd backbones run on the MI355X only (input is on %s)' % x.device)
-        if not self.training:
-            raise NotImplementedError('eval-mode (running-stat) BatchNorm is outside the pretrain hot path')
         self.prepare(x.device)
         if perm is not None:
             perm = torch.as_tensor(np.ascontiguousarray(perm), dtype=torch.int32).to(x.device) \
                 if not isinstance(perm, torch.Tensor) else perm.to(device=x.device, dtype=torch.int32).contiguous()
-        if torch.is_grad_enabled() and any(s.tensor.requires_grad for s in self.store.slots):
+        if not self.training:
+            # module.eval() (classifier.py's test / retrieval passes, the 'last'-layer finetune): BatchNorm with the
+            # running statistics, forward only -- the result carries no autograd history
+            if torch.is_grad_enabled() and x.requires_grad:
+                raise NotImplementedError('backward through an eval-mode backbone is not built')
+        elif torch.is_grad_enabled() and any(s.tensor.requires_grad for s in self.store.slots):
             return _BackboneFn.apply(self._anchor, x, self, perm, want_map)
         plan = self._acquire_plan(x, perm is not None, want_map, with_grad=False)
         self._run_plan(plan, x, perm)

@@ -912,6 +912,31 @@ extern "C" int dv_fill_cols_f32(float* p, int64_t rows, int32_t pitch, int32_t c
   return dv_launch_status();
 }
 
+// eval-mode BatchNorm (running statistics): scale = gamma * rsqrt(running_var + eps), shift = beta - running_mean * scale;
+// arrays are written up to round_up(C, 8) (pad lanes zero) for the 16-byte loads of dv_bn_apply
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C, int CP,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= CP) return;
+  float sc = 0.f, sh = 0.f;
+  if (c < C) {
+    sc = gamma[c] * rsqrtf(rv[c] + eps);
+    sh = beta[c] - rm[c] * sc;
+  }
+  scale[c] = sc;
+  shift[c] = sh;
+}
+
+extern "C" int dv_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                 float eps, int32_t C, float* scale, float* shift, void* stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0) return DV_EINVAL;
+  const int CP = cp8(C);
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((CP + 127) / 128), dim3(128), 0, ST(stream), gamma, beta, running_mean,
+                     running_var, eps, C, CP, scale, shift);
+  return dv_launch_status();
+}
+
 extern "C" int dv_bn_reduce_stats(const float* partials, int32_t n_tiles, int32_t tile_rows, int32_t pitch, int64_t M,
                                   int32_t C, float* local_stats, void* stream) {
   if (!partials || !local_stats || n_tiles <= 0 || C <= 0 || M <= 0 || pitch < C) return DV_EINVAL;

@@ -307,8 +307,10 @@ def _dt(dtype):
 class Plan:
     """Static forward/backward launch lists for one backbone at one input shape."""
 
-    def __init__(self, store, dtype, device, with_grad=True, comm=None):
+    def __init__(self, store, dtype, device, with_grad=True, comm=None, training=True):
         self.store, self.dtype, self.device, self.with_grad = store, dtype, device, with_grad
+        self.training = training     # False: eval-mode BatchNorm (running statistics), forward only
+        assert training or not with_grad, 'eval-mode plans are forward only' 
         self.comm = comm if comm is not None else Comm()
         self.ops = []
         self.f_list, self.b_list = [], []
@@ -521,6 +523,7 @@ class ConvOp(Op):
         To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
         self.y = out if out is not None else plan.act(x.N, To, Ho, Wo, slot.Cout)
         assert x.cpitch == slot.cin_pitch, (x.cpitch, slot.cin_pitch)
+        stats = stats and plan.training              # eval-mode BatchNorm needs no batch statistics
         self.d = ops.conv_desc(self.dtype, x, self.y, k, s, p, flags=DV_STATS if stats else 0)
         self.tiles = ops.stat_tiles(self.d)
         self.tile_rows = ops.tile_rows(self.d)
@@ -654,8 +657,29 @@ class BNGroupOp(Op):
                             (p.dtype, tab, n, ends[3], max(m.C for m in self.members)), tot(b_app, 'bytes'))]
         return f_red, f_app, b_red, b_app
 
+    def _eval_launches(self):
+        """module.eval(): y = act(x * scale + shift (+res)) with the affine map of the RUNNING statistics; no
+        exchange, no update, no backward"""
+        p, st, lib, dt = self.plan, self.plan.store, self.plan.lib, _dt(self.plan.dtype)
+        f = []
+        for m in self.members:
+            bn, x, y, res = m.bn, m.x, m.y, m.res
+            gs, bs = st.slot(bn.weight), st.slot(bn.bias)
+            if bn.running_mean is None:
+                raise NotImplementedError('eval-mode BatchNorm without running statistics')
+            f.append(Launch('bn_eval_coeffs', 'bn_eval_coeffs', lib.dv_bn_eval_coeffs,
+                            (st.w_master(gs), st.w_master(bs), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                             float(bn.eps), m.C, m.scale.data_ptr(), m.shift.data_ptr())))
+            f.append(Launch('bn_apply', 'bn_apply<%s>' % dt, lib.dv_bn_apply,
+                            (p.dtype, x.ptr, x.ld, m.scale.data_ptr(), m.shift.data_ptr(),
+                             res.ptr if res is not None else 0, res.ld if res is not None else 0, y.ptr, y.ld, m.M, m.C,
+                             DV_RELU if m.relu else 0), _abytes(x) * (3 if res is not None else 2), 0, 'M%d C%d' % (m.M, m.C)))
+        return f, []
+
     def launches(self):
         p, st, lib = self.plan, self.plan.store, self.plan.lib
+        if not p.training:
+            return self._eval_launches()
         R, dt = p.comm.world, _dt(p.dtype)
         f_red, f_fin, f_app, b_red, b_app = [], [], [], [], []
         for i, m in enumerate(self.members):

@@ -163,6 +163,11 @@ int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int32_t tile_ro
                          float* local_stats /*[2*C+1]*/, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
                          float* scale, float* shift, void* stream);
+/* Eval mode (module.eval(): nn.BatchNorm3d with running statistics, classifier.py's test / retrieval passes and the
+ * 'last'-layer finetune): the per-channel affine map of dv_bn_apply from the running statistics,
+ * scale = gamma * rsqrt(running_var + eps), shift = beta - running_mean * scale, written up to round_up(C, 8). */
+int dv_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, int32_t C, float* scale, float* shift, void* stream);
 int dv_bn_finalize(const float* stats /*[R] rows of (sum[C], M2[C], count), row pitch `stride` floats*/, int32_t R,
                    int32_t stride, int32_t C, const float* gamma,
                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,

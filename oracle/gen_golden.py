@@ -141,6 +141,43 @@ def case_backbones(ref):
     np.savez_compressed(os.path.join(GOLD, 'backbones.npz'), **rec)
 
 
+def case_eval(ref):
+    """module.eval() (classifier.py's test / retrieval passes): every backbone after ONE train-mode forward (so the
+    running statistics are not the trivial 0 / 1) evaluated on other clips, and the LinearClassifier around it."""
+    rec = {}
+    xa = P.procedural_clips(4, 1, **CLIP)[:, 0]
+    xb = P.procedural_clips(4, 1, seed=77, **CLIP)[:, 0]
+    for net in ('s3dg', 'r21d', 'r3d', 'r50'):
+        outs = []
+        for sel in (ref.select_backbone, O.select_backbone):
+            m, _ = sel(net)
+            P.procedural_init(m).train()
+            with torch.no_grad():
+                m(xa)
+                y = m.eval()(xb)
+            outs.append(y)
+        err = float((outs[0] - outs[1]).abs().max())
+        assert err < 1e-5, (net, err)
+        rec[net + '/eval_pooled'] = outs[0].mean(dim=(2, 3, 4)).numpy()
+        print('eval backbone', net, 'ref-vs-oracle', err)
+    for tag, kw in (('plain', dict(use_dropout=True)), ('l2bn', dict(use_dropout=False, use_l2_norm=True, use_final_bn=True)),
+                    ('mlp', dict(use_dropout=False, nonlinear=True))):
+        outs = []
+        for mk in (lambda **k: ref.linear_classifier('s3dg', **k), lambda **k: O.LinearClassifier(network='s3dg', **k)):
+            torch.manual_seed(0)
+            c = mk(num_class=101, **kw)
+            P.procedural_init(c).train()
+            with torch.no_grad():
+                c.backbone(xa)
+                logit, feat = c.eval()(xb)
+            outs.append((logit, feat))
+        err = max(float((outs[0][i] - outs[1][i]).abs().max()) for i in range(2))
+        assert err < 1e-5, (tag, err)
+        rec['clf_%s/logit' % tag], rec['clf_%s/feat' % tag] = outs[0][0].numpy(), outs[0][1].numpy()
+        print('eval classifier', tag, 'ref-vs-oracle', err)
+    np.savez_compressed(os.path.join(GOLD, 'eval.npz'), **rec)
+
+
 def case_models(ref):
     _init_pg()
     for kind, net, B in (('simclr_naked', 's3dg', 4), ('simclr_timeseriesv4', 's3dg', 4),
@@ -231,12 +268,14 @@ def case_losses():
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['backbones', 'models', 'losses']
+    which = sys.argv[1:] or ['backbones', 'models', 'losses', 'eval']
     if 'losses' in which:
         case_losses()
     ref = harness.load_reference()
     if 'backbones' in which:
         case_backbones(ref)
+    if 'eval' in which:
+        case_eval(ref)
     if 'models' in which:
         case_models(ref)
 

@@ -50,6 +50,7 @@ def load_reference():
     import backbone.select_backbone as SB
     import backbone.resnet_2d3d as R
     import utils.utils as U
+    import model.classifier as CL
     S.SimCLR_TimeSeriesV4.calc_contrast_loss = S.SimCLR_TimeSeriesV4.calc_clip_contrast_loss   # D1
     M.MoCo_TimeSeriesV4.calc_contrast_loss = M.MoCo_TimeSeriesV4.calc_clip_contrast_loss       # D1
 
@@ -62,4 +63,9 @@ def load_reference():
             return r50(first_channel), {'feature_size': 2048}
         return SB.select_backbone(name, first_channel)
 
-    return types.SimpleNamespace(simclr=S, moco=M, select_backbone=select_backbone, utils=U, r50=r50)
+    def linear_classifier(network, **kw):                                # D7 again: build around a working backbone factory
+        CL.select_backbone = select_backbone
+        return CL.LinearClassifier(network=network, **kw)
+
+    return types.SimpleNamespace(simclr=S, moco=M, select_backbone=select_backbone, utils=U, r50=r50,
+                                 linear_classifier=linear_classifier)

@@ -783,6 +783,43 @@ class MoCo_TimeSeriesV4(_MoCoBase):
         return ret
 
 
+class LinearClassifier(nn.Module):
+    """Downstream classifier (model/classifier.py:10-70): backbone -> AdaptiveAvgPool3d(1) -> [l2 norm] -> [BatchNorm1d]
+    -> [Dropout] -> Linear.  Same constructor arguments, sub-module names (`backbone`, `final_bn`, `final_fc`) and
+    (logit, feature) return as the reference; `final_fc` weights N(0, 0.01), biases 0 (classifier.py:64-70)."""
+
+    def __init__(self, num_class=101, network='resnet50', dropout=0.5, use_dropout=True, use_l2_norm=False,
+                 use_final_bn=False, nonlinear=False, proj_dim=128):
+        super().__init__()
+        self.network, self.num_class, self.dropout = network, num_class, dropout
+        self.use_dropout, self.use_l2_norm, self.use_final_bn = use_dropout, use_l2_norm, use_final_bn
+        self.backbone, self.param = select_backbone(network)
+        F_ = self.param['feature_size']
+        if use_final_bn:
+            self.final_bn = nn.BatchNorm1d(F_)
+            self.final_bn.weight.data.fill_(1)
+            self.final_bn.bias.data.zero_()
+        if use_dropout:
+            self.final_fc = nn.Sequential(nn.Dropout(dropout), nn.Linear(F_, num_class))
+        elif nonlinear:
+            self.final_fc = nn.Sequential(nn.Linear(F_, proj_dim), nn.ReLU(), nn.Linear(proj_dim, num_class))
+        else:
+            self.final_fc = nn.Sequential(nn.Linear(F_, num_class))
+        for name, prm in self.final_fc.named_parameters():
+            if 'bias' in name:
+                nn.init.constant_(prm, 0.0)
+            elif 'weight' in name:
+                nn.init.normal_(prm, mean=0.0, std=0.01)
+
+    def forward(self, block):
+        B = block.shape[0]
+        feat3d = F.adaptive_avg_pool3d(self.backbone(block), (1, 1, 1)).view(B, self.param['feature_size'])
+        if self.use_l2_norm:
+            feat3d = F.normalize(feat3d, p=2, dim=1)
+        logit = self.final_fc(self.final_bn(feat3d)) if self.use_final_bn else self.final_fc(feat3d)
+        return logit, feat3d
+
+
 def get_model(args):
     """pretrain.py:61-77."""
     kw = dict(n_series=args.n_series, series_dim=args.series_dim, series_T=args.series_T,

@@ -169,3 +169,61 @@ def test_bf16_step_close_to_reference(gpu, kind, net, B):
     print(kind, 'bf16 loss err', err)
     assert np.isfinite(float(loss)) and err < 0.25 * len([k for k in ret if 'loss' in k]), err
     assert all(torch.isfinite(st.grad).all() for st in m.stores())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# module.eval(): BatchNorm with running statistics (classifier.py's test / retrieval passes)
+@pytest.mark.parametrize('net', ['s3dg', 'r21d', 'r3d', 'r50'])
+def test_eval_mode_backbone_against_reference_fixture(gpu, net):
+    """one train-mode forward (updates the running statistics), then eval() on other clips == the reference doing
+    the same (tests/golden/eval.npz, generated from the reference's own backbones by oracle/gen_golden.py)"""
+    from dualvar_amd.backbone import select_backbone
+    P = _P()
+    g = gold('eval')
+    m, _ = select_backbone(net)
+    P.procedural_init(m)
+    m.set_compute_dtype('fp32').train().to(gpu)
+    xa = P.procedural_clips(4, 1, **CLIP)[:, 0].to(gpu)
+    xb = P.procedural_clips(4, 1, seed=77, **CLIP)[:, 0].to(gpu)
+    with torch.no_grad():
+        m.forward_pooled(xa)
+        pooled = m.eval().forward_pooled(xb)
+        fmap = m(xb)
+    e = rel_err(pooled.cpu().numpy(), g[net + '/eval_pooled'])
+    print(f'{net} eval-mode pooled rel err {e:.2e}')
+    assert e < 3e-4
+    assert rel_err(fmap.mean(dim=(2, 3, 4)).cpu().numpy(), g[net + '/eval_pooled']) < 3e-4
+    # bf16 storage: the same pass stays close to the fp32 one (no batch statistics to amplify rounding in eval mode)
+    m.set_compute_dtype('bf16')
+    with torch.no_grad():
+        pb = m.forward_pooled(xb)
+    eb = rel_err(pb.cpu().numpy(), g[net + '/eval_pooled'])
+    print(f'{net} eval-mode bf16 pooled rel err {eb:.2e}')
+    assert eb < 5e-2
+
+
+@pytest.mark.parametrize('tag,kw', [('plain', dict(use_dropout=True)),
+                                    ('l2bn', dict(use_dropout=False, use_l2_norm=True, use_final_bn=True)),
+                                    ('mlp', dict(use_dropout=False, nonlinear=True))])
+def test_linear_classifier_eval_against_reference_fixture(gpu, tag, kw):
+    """LinearClassifier.eval()(clips) -> (logit, feature) == the reference's model/classifier.py on the same procedural
+    weights; state_dict keys equal the oracle's (hence the reference's)"""
+    from dualvar_amd.model import LinearClassifier
+    from oracle import torch_ref as O
+    P = _P()
+    g = gold('eval')
+    c = LinearClassifier(num_class=101, network='s3dg', **kw)
+    assert list(c.state_dict().keys()) == list(O.LinearClassifier(num_class=101, network='s3dg', **kw).state_dict().keys())
+    P.procedural_init(c)
+    c.set_compute_dtype('fp32').train().to(gpu)
+    xa = P.procedural_clips(4, 1, **CLIP)[:, 0].to(gpu)
+    xb = P.procedural_clips(4, 1, seed=77, **CLIP)[:, 0].to(gpu)
+    with torch.no_grad():
+        c.backbone.forward_pooled(xa)
+        with pytest.raises(NotImplementedError):
+            c(xb)                                   # train-mode head: not built
+        logit, feat = c.eval()(xb)
+    assert tuple(logit.shape) == (4, 101) and tuple(feat.shape) == (4, 1024)
+    ef, el = rel_err(feat.cpu().numpy(), g[f'clf_{tag}/feat']), rel_err(logit.cpu().numpy(), g[f'clf_{tag}/logit'])
+    print(f'classifier {tag}: feature rel err {ef:.2e}, logit rel err {el:.2e}')
+    assert ef < 3e-4 and el < 1e-3

@@ -35,6 +35,22 @@ def test_backbone_fixture(net):
     assert np.max(np.abs(y.numpy() - g[net + '/feat'])) <= tol * np.max(np.abs(g[net + '/feat']))
 
 
+def test_eval_mode_and_classifier_fixture():
+    """eval-mode BatchNorm (running statistics after one train-mode forward) and the downstream LinearClassifier of the
+    oracle reproduce tests/golden/eval.npz (the reference's backbone.eval() / model/classifier.py outputs)"""
+    from oracle import procedural as P, torch_ref as O
+    g = gold('eval')
+    xa = P.procedural_clips(4, 1, **CLIP)[:, 0]
+    xb = P.procedural_clips(4, 1, seed=77, **CLIP)[:, 0]
+    c = O.LinearClassifier(num_class=101, network='s3dg', use_dropout=False, use_l2_norm=True, use_final_bn=True)
+    P.procedural_init(c).train()
+    with torch.no_grad():
+        c.backbone(xa)
+        logit, feat = c.eval()(xb)
+    for got, key in ((logit, 'clf_l2bn/logit'), (feat, 'clf_l2bn/feat')):
+        assert np.max(np.abs(got.numpy() - g[key])) <= 2e-4 * np.max(np.abs(g[key])), key
+
+
 @pytest.mark.parametrize('kind,net,B', [('simclr_naked', 'r3d', 2), ('simclr_timeseriesv4', 'r21d', 2),
                                         ('simclr_naked', 's3dg', 4), ('moco_timeseriesv4', 's3dg', 4)])
 def test_model_first_step_fixture(kind, net, B):
