@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdualvar_hip.so')
 
 DV_F32, DV_BF16 = 0, 1
-DV_BIAS, DV_RELU, DV_SIGMOID, DV_ACCUM, DV_STATS, DV_NO_RELU_MASK = 1, 2, 4, 8, 16, 32
+DV_BIAS, DV_RELU, DV_SIGMOID, DV_ACCUM, DV_STATS, DV_NO_RELU_MASK, DV_MASK_FROM_X = 1, 2, 4, 8, 16, 32, 64
 
 _ERR = {-1: 'DV_EINVAL (inconsistent shapes / unsupported parameter)',
         -2: 'DV_EALIGN (pointer or pitch misaligned)',

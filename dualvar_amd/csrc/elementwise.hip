@@ -297,24 +297,29 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const T* __restrict__ dy, int
                                                    const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                    const float* __restrict__ invstd, int64_t M, int C, int CP, int flags,
                                                    int64_t rows_per_block, float* __restrict__ sums_all, int n_rep,
-                                                   uint32_t bid) {
+                                                   uint32_t bid, const float* __restrict__ scale = nullptr,
+                                                   const float* __restrict__ shift = nullptr) {
   constexpr int V = DT<T>::VEC;
   // atomics on one address serialise at the memory side (~12 ns each): spread the blocks over n_rep replicas
   float* sums = sums_all + (size_t)(bid % n_rep) * 2 * CP;
   const int64_t r0 = (int64_t)bid * rows_per_block;
   const int64_t r1 = min(M, r0 + rows_per_block);
   const bool mask = !(flags & DV_NO_RELU_MASK);
-  float mu[V], is[V];
+  // DV_MASK_FROM_X: the ReLU mask is recomputed from x exactly as the forward computed y = relu(x*scale + shift)
+  // (same expression, same rounding), so the output tensor is not read at all: 2 tensor reads instead of 3
+  const bool fromx = mask && (flags & DV_MASK_FROM_X);
+  float mu[V], is[V], sc[V], sh[V];
   column_reduce<V, 2>(
       r0, r1, CP,
       [&](int64_t r, int c0, float(&acc)[2][V]) {
         float g[V], yy[V], xx[V];
         Pack16<T>::load(dy + r * lddy + c0, g);
-        if (mask) Pack16<T>::load(y + r * ldy + c0, yy);
+        if (mask && !fromx) Pack16<T>::load(y + r * ldy + c0, yy);
         Pack16<T>::load(x + r * ldx + c0, xx);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          float gg = (mask && !(yy[e] > 0.f)) ? 0.f : g[e];
+          const float act = fromx ? xx[e] * sc[e] + sh[e] : yy[e];
+          float gg = (mask && !(act > 0.f)) ? 0.f : g[e];
           acc[0][e] += gg;
           acc[1][e] += gg * (xx[e] - mu[e]) * is[e];
         }
@@ -324,7 +329,11 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const T* __restrict__ dy, int
         for (int e = 0; e < V; ++e)
           if (c0 + e < C) { atomicAdd(sums + c0 + e, acc[0][e]); atomicAdd(sums + CP + c0 + e, acc[1][e]); }
       },
-      [&](int c0) { load_params<V>(mean, c0, mu); load_params<V>(invstd, c0, is); });
+      [&](int c0) {
+        load_params<V>(mean, c0, mu);
+        load_params<V>(invstd, c0, is);
+        if (fromx) { load_params<V>(scale, c0, sc); load_params<V>(shift, c0, sh); }
+      });
 }
 
 template <typename T>
@@ -343,7 +352,7 @@ __global__ void bn_bwd_reduce_multi_kernel(const dv_bn_item* __restrict__ items,
   const int CP = (it.C + 7) & ~7;
   const int64_t rpb = (it.M + nblk - 1) / nblk;
   bn_bwd_reduce_body<T>((const T*)it.dy, it.lddy, (const T*)it.y, it.ldy, (const T*)it.x, it.ldx, it.mean, it.invstd, it.M,
-                        it.C, CP, it.bwd_flags, rpb, it.sums, it.n_rep, bid);
+                        it.C, CP, it.bwd_flags, rpb, it.sums, it.n_rep, bid, it.scale, it.shift);
 }
 
 // partials [n_blocks][W] -> out[W] (+=): 32 columns x 8 row lanes per block
@@ -382,9 +391,12 @@ __device__ __forceinline__ void bn_bwd_apply_body(const T* __restrict__ dy, int 
                                                   const float* __restrict__ sums_g, int rep_g, float inv_count,
                                                   float dscale, float* dgamma, float* dbeta, T* __restrict__ dx,
                                                   int lddx, T* __restrict__ dres, int lddres, uint32_t total, int C,
-                                                  int CP, const FastDiv& fcv, int flags, uint32_t bid, uint32_t nblk) {
+                                                  int CP, const FastDiv& fcv, int flags, uint32_t bid, uint32_t nblk,
+                                                  const float* __restrict__ scale = nullptr,
+                                                  const float* __restrict__ shift = nullptr) {
   constexpr int V = DT<T>::VEC;
-  extern __shared__ __attribute__((aligned(16))) float coef[];      // [3][CP]
+  extern __shared__ __attribute__((aligned(16))) float coef[];      // [3][CP] (+ [2][CP] scale, shift with DV_MASK_FROM_X)
+  const bool fromx = !(flags & DV_NO_RELU_MASK) && (flags & DV_MASK_FROM_X);
   if (bid == 0 && dgamma) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float sb = 0.f, sg = 0.f;
@@ -403,6 +415,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(const T* __restrict__ dy, int 
       k3 = -k1 * sg * inv_count - k2 * mean[c];
     }
     coef[c] = k1; coef[CP + c] = k2; coef[2 * CP + c] = k3;
+    if (fromx) { coef[3 * CP + c] = c < C ? scale[c] : 0.f; coef[4 * CP + c] = c < C ? shift[c] : 0.f; }
   }
   __syncthreads();
   const uint32_t CV = fcv.d;
@@ -410,17 +423,19 @@ __device__ __forceinline__ void bn_bwd_apply_body(const T* __restrict__ dy, int 
   for (uint32_t i = bid * blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
     const uint32_t row = fd_div(i, fcv);
     const int c0 = (int)(i - row * CV) * V;
-    float g[V], yy[V], xx[V], o[V], ro[V], k1[V], k2[V], k3[V];
+    float g[V], yy[V], xx[V], o[V], ro[V], k1[V], k2[V], k3[V], sc[V], sh[V];
     Pack16<T>::load(dy + (size_t)row * lddy + c0, g);
-    if (mask) Pack16<T>::load(y + (size_t)row * ldy + c0, yy);
+    if (mask && !fromx) Pack16<T>::load(y + (size_t)row * ldy + c0, yy);
     Pack16<T>::load(x + (size_t)row * ldx + c0, xx);
     if (dres && (flags & DV_ACCUM)) Pack16<T>::load(dres + (size_t)row * lddres + c0, ro);
     load_params<V>(coef, c0, k1);
     load_params<V>(coef + CP, c0, k2);
     load_params<V>(coef + 2 * CP, c0, k3);
+    if (fromx) { load_params<V>(coef + 3 * CP, c0, sc); load_params<V>(coef + 4 * CP, c0, sh); }
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      const float gg = (mask && !(yy[e] > 0.f)) ? 0.f : g[e];
+      const float act = fromx ? xx[e] * sc[e] + sh[e] : yy[e];     // the forward's expression: same mask bit for bit
+      const float gg = (mask && !(act > 0.f)) ? 0.f : g[e];
       o[e] = k1[e] * gg + k2[e] * xx[e] + k3[e];
       if (dres) ro[e] = (flags & DV_ACCUM) ? ro[e] + gg : gg;
     }
@@ -451,7 +466,7 @@ __global__ void bn_bwd_apply_multi_kernel(const dv_bn_item* __restrict__ items, 
   bn_bwd_apply_body<T>((const T*)it.dy, it.lddy, (const T*)it.y, it.ldy, (const T*)it.x, it.ldx, it.mean, it.invstd,
                        it.gamma, it.sums, it.n_rep, it.inv_count, it.dparam_scale, it.dgamma, it.dbeta, (T*)it.dx, it.lddx,
                        (T*)it.dres, it.lddres, (uint32_t)(it.M * (CP / V)), it.C, CP, fastdiv_dev((uint32_t)(CP / V)),
-                       it.bwd_flags, bid, nblk);
+                       it.bwd_flags, bid, nblk, it.scale, it.shift);
 }
 
 // ------------------------------------------------------------------ MaxPool3d
@@ -978,8 +993,8 @@ extern "C" int dv_bn_bwd_apply_multi(int32_t dtype, const dv_bn_item* items, int
                                      void* stream) {
   if (!items || n <= 0 || total_blocks <= 0 || max_c <= 0) return DV_EINVAL;
   const int CP = cp8(max_c);
-  if (3 * CP * 4 > 60 * 1024) return DV_EUNSUPPORTED;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_multi_kernel<T>), dim3(total_blocks), dim3(kThreads), 3 * CP * sizeof(float),
+  if (5 * CP * 4 > 60 * 1024) return DV_EUNSUPPORTED;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_multi_kernel<T>), dim3(total_blocks), dim3(kThreads), 5 * CP * sizeof(float),
                                        ST(stream), items, n));
   return dv_launch_status();
 }

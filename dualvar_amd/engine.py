@@ -20,6 +20,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 from . import ops
+from ._lib import DV_MASK_FROM_X
 from .ops import DV_ACCUM, DV_BF16, DV_BIAS, DV_F32, DV_NO_RELU_MASK, DV_RELU, DV_SIGMOID, DV_STATS, Act, cp8
 
 
@@ -577,6 +578,9 @@ class BNMember:
         # per-channel arrays are read with 16-byte loads: padded to CP
         self.mean, self.invstd, self.scale, self.shift = (plan.f32(self.CP) for _ in range(4))
         self.width = 2 * self.C + 1
+        # y = relu(x*scale + shift) with nothing added: the backward recomputes the ReLU mask from x (which it reads for
+        # xhat anyway) with the forward's expression and never touches y -- 5 tensor passes per BatchNorm instead of 7
+        self.mask_from_x = bool(relu) and residual is None
         self.sums_off = plan.reserve_zero(BN_REPLICAS * 2 * self.CP) if plan.with_grad else 0
         self.sums_len = BN_REPLICAS * 2 * self.CP
 
@@ -631,6 +635,8 @@ class BNGroupOp(Op):
             if p.with_grad:
                 dres = res.grad if (res is not None and res.grad is not None) else None
                 mflag = 0 if m.relu else DV_NO_RELU_MASK
+                if m.mask_from_x:
+                    mflag |= DV_MASK_FROM_X
                 it.dy, it.lddy, it.dx, it.lddx = y.grad.ptr, y.grad.ld, x.grad.ptr, x.grad.ld
                 it.dres, it.lddres = (dres.ptr, dres.ld) if dres is not None else (0, 0)
                 it.sums, it.n_rep = p.zero_ptr(m.sums_off), BN_REPLICAS
@@ -711,7 +717,7 @@ class BNGroupOp(Op):
             if p.with_grad:
                 dy = y.grad
                 mflag = 0 if m.relu else DV_NO_RELU_MASK
-                nact = 3 if m.relu else 2
+                nact = 3 if (m.relu and not m.mask_from_x) else 2
                 sums = p.zero_ptr(m.sums_off)
                 b_red.append(Launch('bn_bwd_reduce', 'bn_bwd_reduce<%s>' % dt, lib.dv_bn_bwd_reduce,
                                     (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, m.mean.data_ptr(), m.invstd.data_ptr(),
@@ -725,9 +731,13 @@ class BNGroupOp(Op):
                                      x.grad.ptr, x.grad.ld, dres.ptr if dres is not None else 0,
                                      dres.ld if dres is not None else 0, M, Cn, bflags), _abytes(x) * (nact + 1 + nres), 0,
                                     'M%d C%d' % (M, Cn)))
-        if len(self.members) > 1:
-            # multi-tensor launches: one per phase for the whole group (the layers are small and latency bound)
+        if len(self.members) > 1 or (p.with_grad and self.members[0].mask_from_x):
+            # multi-tensor launches: one per phase for the whole group (the layers are small and latency bound); also
+            # the form that carries scale / shift for the mask-from-x backward
+            f1, a1 = f_red, f_app
             f_red, f_app, b_red, b_app = self._multi(R, f_red, f_app, b_red, b_app)
+            if len(self.members) == 1:
+                f_red, f_app = f1, a1        # a lone (large) layer keeps the single-tensor forward kernels (1024-thread stats)
         f = list(f_red)
         b = list(b_red)
         if R > 1:

@@ -50,7 +50,9 @@ enum {
   DV_SIGMOID = 4,      /* 1/(1+exp(-.))                                   */
   DV_ACCUM = 8,        /* out += result (dgrad into a shared input)       */
   DV_STATS = 16,       /* conv fwd: also emit per-tile BatchNorm partials */
-  DV_NO_RELU_MASK = 32 /* bn backward: activation was identity            */
+  DV_NO_RELU_MASK = 32, /* bn backward: activation was identity            */
+  DV_MASK_FROM_X = 64   /* bn backward (multi-tensor forms, no residual): recompute the ReLU mask from x with the item's
+                           scale / shift -- relu(x*scale+shift) exactly as the forward -- instead of reading y */
 };
 
 int dv_abi_version(void);
