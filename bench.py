@@ -175,8 +175,11 @@ def main():
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)
     block = torch.randn(B, V, 3, args.frames, args.size, args.size, generator=g).to(dev)
+    gsync = GradSync() if distributed else None
+    if gsync is not None:
+        gsync.attach(model)           # bucket-wise all-reduce from inside the backward pass (single-pass objectives)
     opt = SGD([p for p in model.parameters() if p.requires_grad], lr=0.003, momentum=0.9, weight_decay=1e-4,
-              stores=model.stores(), grad_sync=GradSync() if distributed else None)
+              stores=model.stores(), grad_sync=gsync)
 
     def step():
         ret = model(block)

@@ -117,6 +117,8 @@ class HipBackbone(nn.Module):
         self._norm = None
         self.comm = None
         self.after_backward = None      # set by the data-parallel wrapper (gradient all-reduce hook)
+        self.grad_ready = None          # parallel.GradSync.attach: bucket-wise all-reduce from inside the backward list
+        self.bucket_elems = 0
 
     # -- configuration
     def set_compute_dtype(self, name):
@@ -199,6 +201,10 @@ class HipBackbone(nn.Module):
         plan.ingest.n_seg = perm.shape[1] if perm is not None else 0
         plan.ingest.bind(x, perm, mean, istd)
         plan.after_backward = self.after_backward
+        plan.grad_ready = self.grad_ready
+        if self.grad_ready is not None and not plan.bucket_starts:
+            from ..parallel import bucket_ranges
+            plan.bucket_starts = tuple(a for a, _ in bucket_ranges(self.store.total, self.bucket_elems))
         with torch.no_grad():
             if self.training:
                 self.store.bump_bn_counters()

@@ -33,6 +33,8 @@ def _align8(n):
 
 # weight gradients on a side stream (see Plan.run_backward); DUALVAR_WGRAD_STREAM=0 keeps everything on one stream
 WGRAD_SIDE_STREAM = os.environ.get('DUALVAR_WGRAD_STREAM', '1') != '0'
+# backward launches whose results only the optimizer reads: weight gradients, the gate FCs' bias gradients
+SIDE_LAUNCHES = ('conv_wgrad', 'gate_db')
 
 
 class Slot:
@@ -272,10 +274,11 @@ class Comm:
 
 class Launch:
     """One kernel launch of a plan: a bound C-ABI call plus its algorithmic cost (for the roofline report)."""
-    __slots__ = ('name', 'kname', 'fn', 'args', 'bytes', 'flops', 'shape')
+    __slots__ = ('name', 'kname', 'fn', 'args', 'bytes', 'flops', 'shape', 'gend')
 
     def __init__(self, name, kname, fn, args, nbytes=0, flops=0, shape=''):
         self.name, self.kname, self.fn, self.args, self.bytes, self.flops, self.shape = name, kname, fn, args, nbytes, flops, shape
+        self.gend = 0                # end (element offset) of the highest gradient-arena range this launch writes
 
     def __call__(self, stream):
         rc = self.fn(*self.args, stream)
@@ -322,6 +325,9 @@ class Plan:
         self.zero_arena = None
         self._side = None            # side stream + events of run_backward
         self._events = None
+        self.grad_ready = None       # callable(plan, lo): gradient-arena elements [lo, total) are final (GradSync.attach)
+        self.bucket_starts = ()      # ... called when lo drops to / below each of these element offsets
+        self._triggers = None
 
     # ------------------------------------------------------------------ buffers
     def act(self, N, T, H, W, C_, dtype=None, cpitch=None, grad=None, zero=False):
@@ -440,10 +446,11 @@ class Plan:
         pool chain of the small late layers leaves most CUs idle; the wgrads fill them."""
         if not WGRAD_SIDE_STREAM or not self.b_list:
             return self._run(self.b_list)
+        trig = self._grad_triggers() if self.grad_ready is not None else {}
         main = torch.cuda.current_stream(self.device)
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-            self._events = [torch.cuda.Event() for l in self.b_list if l.name == 'conv_wgrad']
+            self._events = [torch.cuda.Event() for l in self.b_list if l.name in SIDE_LAUNCHES]
         side = self._side
         sm, ss = main.cuda_stream, side.cuda_stream
         t = self.timer
@@ -451,7 +458,7 @@ class Plan:
         on_side = False
         for l in self.b_list:
             nm = l.name
-            if nm == 'conv_wgrad':
+            if nm in SIDE_LAUNCHES:
                 ev = self._events[k]
                 k += 1
                 ev.record(main)
@@ -468,12 +475,38 @@ class Plan:
                 l(sm)
             else:
                 t(l, sm)
+            if trig:
+                lo = trig.get(id(l))
+                if lo is not None:
+                    self.grad_ready(self, lo)
         main.wait_stream(side)
+
+    def _grad_triggers(self):
+        """{id(launch): lo}: once that launch has been issued, no later launch of the backward list writes the
+        gradient arena at or above element lo -- for the bucket starts GradSync asked about (highest first)."""
+        key = tuple(self.bucket_starts)
+        if self._triggers is None or self._triggers[0] != key:
+            trig, remaining = {}, sorted(key, reverse=True)
+            frontier = 0                                   # max gend over launches AFTER position i, built backwards
+            after = [0] * len(self.b_list)
+            for i in range(len(self.b_list) - 1, -1, -1):
+                after[i] = frontier
+                frontier = max(frontier, getattr(self.b_list[i], 'gend', 0))
+            for i, l in enumerate(self.b_list):
+                while remaining and after[i] <= remaining[0]:
+                    trig[id(l)] = remaining.pop(0)          # several buckets may become final at once: keep the lowest
+            self._triggers = (key, trig)
+        return self._triggers[1]
 
     def cost(self):
         """(algorithmic bytes, flops) of one forward+backward replay."""
         ls = self.f_list + self.b_list
         return sum(l.bytes for l in ls), sum(l.flops for l in ls)
+
+
+def _gend(*slots):
+    """highest gradient-arena element a launch writing these slots touches (+1)"""
+    return max(s.off + (s.size if s.kind != 'vec' else s.tensor.numel()) for s in slots)
 
 
 def overlap_bn_exchange(b_list):
@@ -555,9 +588,11 @@ class ConvOp(Op):
             b.append(Launch('conv_wgrad', 'conv_wgrad<%s,%d,%s>' % (_dt(self.dtype), gv, '64,128' if ((sl.Cout + 63) // 64 * 64 < (sl.Cout + 127) // 128 * 128) else '128,64'), lib.dv_conv3d_wgrad,
                             (C.byref(self.d_w), x.ptr, y.grad.ptr, st.w_grad(sl)),
                             _abytes(x) + _abytes(y) + sl.Cout * kdim * 4, flops, shp))
+            b[-1].gend = sl.off + sl.size
             if self.zero_pad_taps is not None:
                 rows, pitch, c0, nc = self.zero_pad_taps
                 b.append(Launch('stem_pad_taps', 'fill_cols', lib.dv_fill_cols_f32, (st.w_grad(sl), rows, pitch, c0, nc, 0.0)))
+                b[-1].gend = sl.off + sl.size
             if self.need_dx:
                 acc = bool(self.acc.get('x'))
                 self.d_g = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=DV_ACCUM if acc else 0)
@@ -661,6 +696,7 @@ class BNGroupOp(Op):
                             (p.dtype, tab, n, ends[2]), tot(b_red, 'bytes'))]
             b_app = [Launch('bn_bwd_apply_multi', 'bn_bwd_apply_multi<%s>' % dt, lib.dv_bn_bwd_apply_multi,
                             (p.dtype, tab, n, ends[3], max(m.C for m in self.members)), tot(b_app, 'bytes'))]
+            b_app[0].gend = _gend(*[st.slot(t) for m in self.members for t in (m.bn.weight, m.bn.bias)])
         return f_red, f_app, b_red, b_app
 
     def _eval_launches(self):
@@ -731,6 +767,7 @@ class BNGroupOp(Op):
                                      x.grad.ptr, x.grad.ld, dres.ptr if dres is not None else 0,
                                      dres.ld if dres is not None else 0, M, Cn, bflags), _abytes(x) * (nact + 1 + nres), 0,
                                     'M%d C%d' % (M, Cn)))
+                b_app[-1].gend = _gend(gs, bs)
         if len(self.members) > 1 or (p.with_grad and self.members[0].mask_from_x):
             # multi-tensor launches: one per phase for the whole group (the layers are small and latency bound); also
             # the form that carries scale / shift for the mask-from-x backward
@@ -862,6 +899,8 @@ class GateGroupOp(Op):
                  Launch('gate_db', 'reduce_rows', lib.dv_colsum_f32, (self.dpre.data_ptr(), Ct, N, Ct, st.w_grad(bias0))),
                  Launch('gate_bwd_apply', 'rowscale<%s,1>' % dt, lib.dv_gate_bwd_apply,
                         (p.dtype, dy.ptr, dy.ld, g, self.dmean.data_ptr(), N, S, Ct, dy.ptr, dy.ld, 0), 2 * _abytes(cat))]
+            b[1].gend = _gend(*[st.slot(fc.weight) for fc, _, _ in self.fcs])
+            b[2].gend = _gend(*[st.slot(fc.bias) for fc, _, _ in self.fcs])
         return f, b
 
 

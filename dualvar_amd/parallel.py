@@ -3,9 +3,10 @@
 What the reference gets from DistributedDataParallel + SyncBatchNorm + GatherLayer (pretrain.py:244-252,
 SURVEY 2.2 C1-C6) is here:
   * C1 gradient averaging  -> `GradSync`: the whole encoder's gradient is ONE flat fp32 arena, so the
-    all-reduce is a handful of large bucket collectives (default 32 MiB: ring all-reduce over xGMI is
-    per-link bound, fewer/larger messages amortise the ~20-50 us launch+sync cost) issued on a side
-    HIP stream; the 1/W averaging is folded into the SGD kernel's grad_scale.
+    all-reduce is a handful of large bucket collectives (default 8 MiB: ring all-reduce over xGMI is
+    per-link bound, few large messages amortise the ~20-50 us launch+sync cost) issued on a side HIP
+    stream, from inside the backward pass where the model allows it (GradSync.attach); the 1/W averaging
+    is folded into the SGD kernel's grad_scale.
   * C2 buffer broadcast    -> not needed: BN running stats come from global statistics and MoCo queues are
     filled from all-gathered keys, so they are identical on every rank by construction.
   * C3/C4 SyncBN stats     -> engine.BNOp (all_gather of (sum, M2, count) / all_reduce of the two backward sums)
@@ -35,32 +36,73 @@ def bucket_ranges(total, bucket_elems):
 
 
 class GradSync:
-    """callable(store) -> grad_scale.  All-reduces store.grad (sum) in buckets; returns 1/world."""
+    """callable(store) -> grad_scale.  All-reduces store.grad (sum) in buckets; returns 1/world.
 
-    def __init__(self, bucket_mb=32, group=None, side_stream=True):
+    `attach(model)` (optional) overlaps the reduction with the backward pass of models that back-propagate through
+    their encoder exactly ONCE per step (`model.single_backward_pass`: SimCLR_Naked, MoCo_Naked): the launch plan
+    knows, for every point of its backward list, above which arena offset no gradient will be written any more
+    (`engine.Plan._grad_triggers`), and calls `_on_ready` as each bucket -- last layers first, the heads' gradients
+    are complete before the encoder's backward starts -- becomes final; that bucket's all-reduce then runs on the
+    side stream underneath the rest of the backward.  The call from the optimizer reduces whatever is left and waits
+    for everything.  Models with two encoder passes per step (the TimeSeriesV4 objectives accumulate both into the
+    arena) keep the plain reduce-after-backward."""
+
+    def __init__(self, bucket_mb=8, group=None, side_stream=True):
         self.group = group
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.rank, self.world = world_info(group)
         self.side_stream = side_stream
         self._stream = None
+        self._works = {}             # id(flat) -> {bucket start: work handle} for the step in flight
 
+    # ---- overlap with backward
+    def attach(self, model):
+        if self.world == 1 or not getattr(model, 'single_backward_pass', False):
+            return False
+        for m in model.modules():
+            if hasattr(m, '_plans') and hasattr(m, 'grad_ready'):
+                m.grad_ready = self._on_ready
+                m.bucket_elems = self.bucket_elems
+        return True
+
+    def _comm_stream(self, flat, *wait_for):
+        if not (self.side_stream and flat.is_cuda):
+            if flat.is_cuda:                 # collective on the current stream: it must still see the other streams' work
+                for s_ in wait_for:
+                    if s_ is not None:
+                        torch.cuda.current_stream(flat.device).wait_stream(s_)
+            return _null()
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=flat.device)
+        self._stream.wait_stream(torch.cuda.current_stream(flat.device))
+        for s_ in wait_for:
+            if s_ is not None:
+                self._stream.wait_stream(s_)
+        return torch.cuda.stream(self._stream)
+
+    def _on_ready(self, plan, lo):
+        """gradient-arena elements [lo, total) are final: start the buckets that lie in there"""
+        flat = plan.store.grad
+        works = self._works.setdefault(id(flat), {})
+        todo = [(a, b) for a, b in bucket_ranges(flat.numel(), self.bucket_elems) if a >= lo and a not in works]
+        if not todo:
+            return
+        with self._comm_stream(flat, getattr(plan, '_side', None)):
+            for a, b in todo:
+                works[a] = dist.all_reduce(flat[a:b], group=self.group, async_op=True)
+
+    # ---- the reduction proper (optimizer step)
     def reduce_flat(self, flat):
         if self.world == 1:
             return 1.0
-        use_side = self.side_stream and flat.is_cuda
-        if use_side:
-            if self._stream is None:
-                self._stream = torch.cuda.Stream(device=flat.device)
-            self._stream.wait_stream(torch.cuda.current_stream(flat.device))
-            ctx = torch.cuda.stream(self._stream)
-        else:
-            ctx = _null()
-        with ctx:
-            works = [dist.all_reduce(flat[a:b], group=self.group, async_op=True)
-                     for a, b in bucket_ranges(flat.numel(), self.bucket_elems)]
-            for w in works:
+        works = self._works.pop(id(flat), {})
+        with self._comm_stream(flat):
+            for a, b in bucket_ranges(flat.numel(), self.bucket_elems):
+                if a not in works:
+                    works[a] = dist.all_reduce(flat[a:b], group=self.group, async_op=True)
+            for w in works.values():
                 w.wait()
-        if use_side:
+        if self.side_stream and flat.is_cuda:
             torch.cuda.current_stream(flat.device).wait_stream(self._stream)
         return 1.0 / self.world
 

@@ -174,8 +174,10 @@ def main_worker(gpu, ngpus_per_node, args):
     model.set_input_normalization(MEAN, STD)            # T.Normalize(channel=1) of pretrain.py:280-282, fused
     model.cuda(args.gpu)
     params = [{'params': [p]} for p in model.parameters() if p.requires_grad]     # pretrain.py:262-271
-    optimizer = SGD(params, lr=args.lr, weight_decay=args.wd, momentum=0.9, stores=model.stores(),
-                    grad_sync=GradSync() if args.distributed else None)
+    gsync = GradSync() if args.distributed else None
+    if gsync is not None:
+        gsync.attach(model)         # single-pass objectives: bucket-wise all-reduce from inside the backward pass
+    optimizer = SGD(params, lr=args.lr, weight_decay=args.wd, momentum=0.9, stores=model.stores(), grad_sync=gsync)
 
     per_rank = max(args.epoch_size // max(args.world_size, 1), args.batch_size)
     dataset = SyntheticClips(args, per_rank * max(args.world_size, 1))

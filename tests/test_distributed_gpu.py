@@ -60,6 +60,26 @@ def _worker(rank, world, port, kind, q):
         scale = sync(m.store)
         torch.cuda.synchronize()
         synced = {k: (p.grad.detach().float().cpu() * scale).numpy() for k, p in m.named_parameters()}
+        if kind == 'SimCLR_Naked':
+            # the same step with the all-reduce issued bucket by bucket from INSIDE the backward pass (GradSync.attach):
+            # the synchronised gradient must not change (beyond the fp32-atomic summation order of the wgrad kernels)
+            for side in (False, True):
+                m.store.zero_grad()
+                sync2 = GradSync(bucket_mb=1, side_stream=side)
+                assert sync2.attach(m)
+                np.random.seed(1234)
+                _run(m, full[rank * n:(rank + 1) * n].to(dev))
+                early = len(sync2._works.get(id(m.store.grad), {}))
+                scale2 = sync2(m.store)
+                torch.cuda.synchronize()
+                assert early >= 2, 'no bucket was reduced during the backward pass (%d)' % early
+                for k, p in m.named_parameters():
+                    got = (p.grad.detach().float().cpu() * scale2).numpy()
+                    tol = 1e-4 * float(np.abs(synced[k]).max()) + 1e-9
+                    assert float(np.abs(got - synced[k]).max()) <= tol, (side, k, float(np.abs(got - synced[k]).max()), tol)
+                for mod in m.modules():
+                    if hasattr(mod, 'grad_ready'):
+                        mod.grad_ready = None
         q.put((rank, {k: v.numpy() for k, v in outs.items()}, {k: v.numpy() for k, v in grads.items()}, synced))
         dist.barrier()
     finally:
