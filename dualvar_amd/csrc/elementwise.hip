@@ -952,6 +952,26 @@ extern "C" int dv_bn_eval_coeffs(const float* gamma, const float* beta, const fl
   return dv_launch_status();
 }
 
+// BatchNorm partials of a small fp32 [M][C] matrix (BatchNorm1d of the classifier head, M = batch): one thread per
+// channel, ONE tile: partials [2][C][1] = (sum, M2 about the mean), the format dv_bn_stats_finalize consumes
+__global__ void bn_rows_partials_kernel(const float* __restrict__ x, int ldx, int M, int C, float* __restrict__ part) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < M; ++r) s += x[(size_t)r * ldx + c];
+  const float mu = s / (float)M;
+  float q = 0.f;
+  for (int r = 0; r < M; ++r) { const float d = x[(size_t)r * ldx + c] - mu; q += d * d; }
+  part[c] = s;
+  part[C + c] = q;
+}
+
+extern "C" int dv_bn_rows_partials_f32(const float* x, int32_t ldx, int32_t M, int32_t C, float* partials, void* stream) {
+  if (!x || !partials || M <= 0 || C <= 0 || ldx < C) return DV_EINVAL;
+  hipLaunchKernelGGL(bn_rows_partials_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), x, ldx, M, C, partials);
+  return dv_launch_status();
+}
+
 extern "C" int dv_bn_reduce_stats(const float* partials, int32_t n_tiles, int32_t tile_rows, int32_t pitch, int64_t M,
                                   int32_t C, float* local_stats, void* stream) {
   if (!partials || !local_stats || n_tiles <= 0 || C <= 0 || M <= 0 || pitch < C) return DV_EINVAL;

@@ -378,6 +378,47 @@ extern "C" int dv_infonce_fwd(const float* q, const float* k, const float* queue
   return dv_launch_status();
 }
 
+// Softmax cross-entropy with integer targets (nn.CrossEntropyLoss, mean reduction: classifier.py:330,465): one wave
+// per row.  loss_rows[r] = logsumexp(logits[r]) - logits[r][label]; dlogits = (softmax - onehot) / R; rank0[r] = number
+// of classes scoring above the target (top-k accuracy without a sort).
+__global__ void softmax_ce_rows_kernel(const float* __restrict__ logits, int ld, int R, int K, const int* __restrict__ labels,
+                                       float* __restrict__ loss_rows, float* __restrict__ dlogits, int ldd,
+                                       int* __restrict__ rank0) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int lane = threadIdx.x & 63;
+  const float* lg = logits + (size_t)r * ld;
+  const int y = labels[r];
+  const float ly = lg[y];
+  float mx = -INFINITY;
+  for (int j = lane; j < K; j += 64) mx = fmaxf(mx, lg[j]);
+  mx = wave_max(mx);
+  float se = 0.f, cnt = 0.f;
+  for (int j = lane; j < K; j += 64) {
+    const float v = lg[j];
+    se += __expf(v - mx);
+    if (v > ly) cnt += 1.f;
+  }
+  se = wave_sum(se);
+  cnt = wave_sum(cnt);
+  const float lse = logf(se) + mx;
+  const float gs = 1.f / (float)R;
+  if (dlogits)
+    for (int j = lane; j < K; j += 64) dlogits[(size_t)r * ldd + j] = (__expf(lg[j] - lse) - (j == y ? 1.f : 0.f)) * gs;
+  if (lane == 0) {
+    loss_rows[r] = lse - ly;
+    if (rank0) rank0[r] = (int)cnt;
+  }
+}
+
+extern "C" int dv_softmax_ce_fwd(const float* logits, int32_t ld, int32_t R, int32_t K, const int32_t* labels, float* loss_rows,
+                                 float* dlogits, int32_t ldd, int32_t* rank0, void* stream) {
+  if (!logits || !labels || !loss_rows || R <= 0 || K <= 0 || ld < K || (dlogits && ldd < K)) return DV_EINVAL;
+  hipLaunchKernelGGL(softmax_ce_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, ST(stream), logits, ld, R, K, labels, loss_rows,
+                     dlogits, ldd, rank0);
+  return dv_launch_status();
+}
+
 extern "C" int dv_rank_margin(const float* feats, int32_t Bn, int32_t s, int32_t D, float theta, float clip, float weight,
                               float* logits, float* loss, float* dfeats, float* scratch /*[Bn]*/, void* stream) {
   if (!feats || !logits || !loss || !dfeats || !scratch || Bn <= 0 || s < 2 || s > 8 || D <= 0 || theta <= 0.f) return DV_EINVAL;

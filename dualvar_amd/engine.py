@@ -205,6 +205,25 @@ class ParamStore:
         self._dirty = True
         self._versions = None
 
+    def trainable_ranges(self):
+        """[(first element, count)] of the maximal runs of arena slots whose tensors require gradients (alignment
+        padding between trainable neighbours is included: it is zero and stays zero)"""
+        sig = tuple(bool(s.tensor.requires_grad) for s in self.slots)
+        if getattr(self, '_tr_sig', None) != (sig, self.generation):
+            out, start, end = [], None, 0
+            for s, rg in zip(self.slots, sig):
+                if rg:
+                    if start is None:
+                        start = s.off
+                    end = s.off + _align8(s.size)
+                elif start is not None:
+                    out.append((start, end - start))
+                    start = None
+            if start is not None:
+                out.append((start, end - start))
+            self._tr_sig, self._tr = (sig, self.generation), out
+        return self._tr
+
     def attach_grads(self):
         """Re-attach .grad views (e.g. after zero_grad(set_to_none=True)); zeroes the arena if any was dropped."""
         dropped = False

@@ -282,3 +282,178 @@ class _RankMarginFn(torch.autograd.Function):
 def rank_margin(feats_vm, n_series, theta, clip, weight):
     """feats_vm [Bn, 2*n_series, D] (view-major per sample).  clip <= 0 disables the clamp (MoCo variant)."""
     return _RankMarginFn.apply(feats_vm, n_series, float(theta), float(clip) if clip else 0.0, float(weight))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# downstream classifier head (model/classifier.py:10-70, trained by classifier.py:422-498)
+class _LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b (+ReLU) with W, b in a ParamStore arena; dW, db accumulate into the gradient arena"""
+
+    @staticmethod
+    def forward(ctx, x, anchor, store, lin, relu):
+        _need_gpu(x)
+        xc = _f32c(x)
+        ws, bs = store.slot(lin.weight), store.slot(lin.bias)
+        n, fin, fout = xc.shape[0], ws.Cin, ws.Cout
+        assert fin == ws.cin_pitch, 'linear input widths must be multiples of 8'
+        fp = (fout + 7) // 8 * 8
+        y = torch.empty(n, fp, dtype=torch.float32, device=x.device)
+        ax = Act(xc, n, 1, 1, 1, fin, fin, 0, DV_F32, fin)
+        ay = Act(y, n, 1, 1, 1, fout, fp, 0, DV_F32, fp)
+        d = ops.conv_desc(DV_F32, ax, ay, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=DV_BIAS | (DV_RELU if relu else 0))
+        _chk(_lib().dv_conv3d_fwd(C.byref(d), xc.data_ptr(), store.w_master(ws), store.w_master(bs), y.data_ptr(), 0,
+                                  ops.stream_ptr()), 'linear fwd')
+        ctx.store, ctx.lin, ctx.relu = store, lin, relu
+        ctx.save_for_backward(xc, y)
+        return y[:, :fout]
+
+    @staticmethod
+    def backward(ctx, dy):
+        st, lin, lib, s = ctx.store, ctx.lin, _lib(), ops.stream_ptr()
+        x, y = ctx.saved_tensors
+        st.attach_grads()
+        ws, bs = st.slot(lin.weight), st.slot(lin.bias)
+        n, fin, fout = x.shape[0], ws.Cin, ws.Cout
+        g = _f32c(dy)
+        if ctx.relu:
+            g2 = torch.empty_like(g)
+            yv = y[:, :fout].contiguous()
+            _chk(lib.dv_relu_bwd_f32(g.data_ptr(), yv.data_ptr(), g.numel(), g2.data_ptr(), s), 'linear relu bwd')
+            g = g2
+        if lin.weight.requires_grad:
+            _chk(lib.dv_gemm_f32(fout, fin, n, g.data_ptr(), 1, fout, x.data_ptr(), fin, 1, st.w_grad(ws), ws.cin_pitch, 1.0, 1, s),
+                 'linear dW')
+            _chk(lib.dv_colsum_f32(g.data_ptr(), fout, n, fout, st.w_grad(bs), s), 'linear db')
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(n, fin, dtype=torch.float32, device=x.device)
+            _chk(lib.dv_gemm_f32(n, fin, fout, g.data_ptr(), fout, 1, st.w_master(ws), ws.cin_pitch, 1, dx.data_ptr(), fin, 1.0, 0, s),
+                 'linear dx')
+        return dx, None, None, None, None
+
+
+def _anchor_for(x, *params):
+    """The parameters of these ops live in an arena, not in the autograd graph: when the INPUT carries no gradient (a
+    frozen backbone) a dummy requires-grad input keeps the op on the tape so that its backward still fills the arena."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return torch.zeros((), device=x.device, requires_grad=True)
+    return None
+
+
+def linear(x, store, lin, relu=False):
+    return _LinearFn.apply(x, _anchor_for(x, lin.weight, lin.bias), store, lin, relu)
+
+
+class _BN1dTrainFn(torch.autograd.Function):
+    """train-mode nn.BatchNorm1d on [B, F] fp32 (model/classifier.py:29-32): batch statistics, running-statistic update,
+    backward through the same dv_bn_* kernels as the 3-D layers (one 'tile' = the batch)"""
+
+    @staticmethod
+    def forward(ctx, x, anchor, store, bn):
+        _need_gpu(x)
+        xc = _f32c(x)
+        lib, s = _lib(), ops.stream_ptr()
+        n, Fd = xc.shape
+        assert Fd % 8 == 0
+        gs, bs = store.slot(bn.weight), store.slot(bn.bias)
+        dev = x.device
+        part = torch.empty(2 * Fd, dtype=torch.float32, device=dev)
+        local = torch.empty(2 * Fd + 1, dtype=torch.float32, device=dev)
+        mean, invstd, scale, shift = (torch.empty(Fd, dtype=torch.float32, device=dev) for _ in range(4))
+        _chk(lib.dv_bn_rows_partials_f32(xc.data_ptr(), Fd, n, Fd, part.data_ptr(), s), 'bn1d partials')
+        mom = float(bn.momentum if bn.momentum is not None else 0.1)
+        _chk(lib.dv_bn_stats_finalize(part.data_ptr(), 1, n, Fd, n, Fd, local.data_ptr(), store.w_master(gs), store.w_master(bs),
+                                      float(bn.eps), mom, bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean.data_ptr(),
+                                      invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), s), 'bn1d finalize')
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        y = torch.empty_like(xc)
+        _chk(lib.dv_bn_apply(DV_F32, xc.data_ptr(), Fd, scale.data_ptr(), shift.data_ptr(), 0, 0, y.data_ptr(), Fd, n, Fd, 0, s),
+             'bn1d apply')
+        ctx.store, ctx.bn = store, bn
+        ctx.save_for_backward(xc, y, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        st, bn, lib, s = ctx.store, ctx.bn, _lib(), ops.stream_ptr()
+        x, y, mean, invstd = ctx.saved_tensors
+        st.attach_grads()
+        n, Fd = x.shape
+        g = _f32c(dy)
+        gs, bs = st.slot(bn.weight), st.slot(bn.bias)
+        sums = torch.zeros(2 * Fd, dtype=torch.float32, device=x.device)
+        no_mask = 32                                                     # DV_NO_RELU_MASK
+        _chk(lib.dv_bn_bwd_reduce(DV_F32, g.data_ptr(), Fd, y.data_ptr(), Fd, x.data_ptr(), Fd, mean.data_ptr(), invstd.data_ptr(),
+                                  n, Fd, no_mask, sums.data_ptr(), 1, s), 'bn1d bwd reduce')
+        dx = torch.empty_like(x)
+        _chk(lib.dv_bn_bwd_apply(DV_F32, g.data_ptr(), Fd, y.data_ptr(), Fd, x.data_ptr(), Fd, mean.data_ptr(), invstd.data_ptr(),
+                                 st.w_master(gs), sums.data_ptr(), 1, 1.0 / n, 1.0, st.w_grad(gs), st.w_grad(bs), dx.data_ptr(), Fd,
+                                 0, 0, n, Fd, no_mask, s), 'bn1d bwd apply')
+        return dx, None, None, None
+
+
+def batchnorm1d_train(x, store, bn):
+    return _BN1dTrainFn.apply(x, _anchor_for(x, bn.weight, bn.bias), store, bn)
+
+
+class _RowScaleFn(torch.autograd.Function):
+    """y = x * m elementwise on [B, F] fp32 (inverted-dropout mask); dx = dy * m"""
+
+    @staticmethod
+    def forward(ctx, x, m):
+        _need_gpu(x)
+        xc = _f32c(x)
+        n, Fd = xc.shape
+        y = torch.empty_like(xc)
+        _chk(_lib().dv_gate_scale(DV_F32, xc.data_ptr(), Fd, m.data_ptr(), n, 1, Fd, y.data_ptr(), Fd, ops.stream_ptr()), 'dropout')
+        ctx.save_for_backward(m)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (m,) = ctx.saved_tensors
+        g = _f32c(dy)
+        n, Fd = g.shape
+        dx = torch.empty_like(g)
+        _chk(_lib().dv_gate_scale(DV_F32, g.data_ptr(), Fd, m.data_ptr(), n, 1, Fd, dx.data_ptr(), Fd, ops.stream_ptr()), 'dropout bwd')
+        return dx, None
+
+
+def dropout(x, p):
+    """nn.Dropout in training mode: the Bernoulli mask comes from torch's generator (it cannot reproduce the CPU
+    reference's stream anyway), scaled by 1/(1-p); the multiply and its backward are HIP"""
+    if p <= 0.0:
+        return x
+    mask = torch.empty(x.shape, dtype=torch.float32, device=x.device).bernoulli_(1.0 - p).mul_(1.0 / (1.0 - p))
+    return _RowScaleFn.apply(x, mask)
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        _need_gpu(logits)
+        lg = _f32c(logits)
+        R, K = lg.shape
+        tgt = target.to(device=lg.device, dtype=torch.int32).contiguous()
+        rows = torch.empty(R, dtype=torch.float32, device=lg.device)
+        dl = torch.empty_like(lg)
+        rank0 = torch.empty(R, dtype=torch.int32, device=lg.device)
+        loss = torch.empty((), dtype=torch.float32, device=lg.device)
+        s = ops.stream_ptr()
+        _chk(_lib().dv_softmax_ce_fwd(lg.data_ptr(), K, R, K, tgt.data_ptr(), rows.data_ptr(), dl.data_ptr(), K, rank0.data_ptr(), s),
+             'softmax ce')
+        _chk(_lib().dv_mean_f32(rows.data_ptr(), R, loss.data_ptr(), s), 'ce mean')
+        ctx.save_for_backward(dl)
+        ctx.mark_non_differentiable(rank0)
+        return loss, rank0
+
+    @staticmethod
+    def backward(ctx, dloss, _drank):
+        (dl,) = ctx.saved_tensors
+        return dl * dloss, None
+
+
+def cross_entropy(logits, target):
+    """nn.CrossEntropyLoss()(logits, target) -> (loss, rank of the target per row)"""
+    return _CrossEntropyFn.apply(logits, target)

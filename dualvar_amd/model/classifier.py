@@ -1,9 +1,14 @@
-"""Downstream `LinearClassifier` on the HIP engine, inference side (reference model/classifier.py:10-70; used by
-classifier.py's test / retrieval passes `:657-738,787-995` and the 'last'-layer finetune): backbone in eval mode
-(BatchNorm with running statistics) -> global average pool -> [L2 normalise] -> [BatchNorm1d] -> [Dropout = identity in
-eval] -> Linear / MLP.  Same constructor, sub-module names (`backbone`, `final_bn`, `final_fc.N`), state_dict keys and
-`(logit, feature)` return as the reference.  Training the head (dropout mask, cross-entropy) is the next SURVEY 8f row
-and raises."""
+"""Downstream `LinearClassifier` on the HIP engine (reference model/classifier.py:10-70; driven by classifier.py's
+train / validate / test / retrieval passes `:422-498,501-543,657-738,787-995`): backbone -> global average pool ->
+[L2 normalise] -> [BatchNorm1d] -> [Dropout] -> Linear / MLP.  Same constructor, sub-module names (`backbone`,
+`final_bn`, `final_fc.N`), state_dict keys and `(logit, feature)` return as the reference.
+
+Every sub-module follows ITS OWN `.training` flag, as in the reference's two modes (classifier.py:435-444):
+  * `--train_what ft`   : `model.train()` -- backbone with batch statistics and gradients, dropout active;
+  * `--train_what last` : `model.eval()` then `final_bn.train()` -- frozen eval-mode backbone (no autograd history),
+                          dropout off, only the head trains.
+The head's arithmetic (linear, BatchNorm1d, dropout multiply, and `DF.cross_entropy` for the criterion) runs in the HIP
+library through torch.autograd.Function wrappers (dualvar_amd/functional.py); parameter gradients land in the arena."""
 import ctypes as C
 
 import torch
@@ -52,20 +57,6 @@ class LinearClassifier(_Objective):
                 self.store.add_vec(m.bias)
 
     # ---- head pieces (fp32, [B, F] row-major)
-    def _linear(self, x, lin, relu):
-        st, lib = self.store, L.load()
-        ws, bs = st.slot(lin.weight), st.slot(lin.bias)
-        n, fin, fout = x.shape[0], ws.Cin, ws.Cout
-        assert fin == ws.cin_pitch, 'head input widths must be multiples of 8'
-        fp = cp8(fout)
-        y = torch.empty(n, fp, dtype=torch.float32, device=x.device)
-        ax = Act(x, n, 1, 1, 1, fin, fin, 0, DV_F32, fin)
-        ay = Act(y, n, 1, 1, 1, fout, fp, 0, DV_F32, fp)
-        d = ops.conv_desc(DV_F32, ax, ay, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=DV_BIAS | (DV_RELU if relu else 0))
-        L.check(lib.dv_conv3d_fwd(C.byref(d), x.data_ptr(), st.w_master(ws), st.w_master(bs), y.data_ptr(), 0,
-                                  ops.stream_ptr()), 'classifier linear')
-        return y[:, :fout]
-
     def _bn1d_eval(self, x):
         st, lib, bn = self.store, L.load(), self.final_bn
         n, Fdim = x.shape
@@ -81,16 +72,27 @@ class LinearClassifier(_Objective):
         return y
 
     def forward(self, block):
-        if self.training:
-            raise NotImplementedError('LinearClassifier training (dropout mask, cross-entropy, head gradients) is not built yet: '
-                                      'call .eval() for the test / retrieval / feature-extraction passes')
-        with torch.no_grad():
-            feat3d = self.backbone.forward_pooled(block).contiguous()                   # [B, F] fp32
-            if self.use_l2_norm:
-                feat3d = DF.l2_normalize(feat3d)
-            x = self._bn1d_eval(feat3d) if self.use_final_bn else feat3d
-            for i, m in enumerate(self.final_fc):
-                if isinstance(m, nn.Linear):
-                    nxt = self.final_fc[i + 1] if i + 1 < len(self.final_fc) else None
-                    x = self._linear(x.contiguous(), m, isinstance(nxt, nn.ReLU))
-            return x, feat3d
+        if self.backbone.training:
+            feat3d = self.backbone.forward_pooled(block)                                # [B, F] fp32, autograd-aware
+        else:
+            with torch.no_grad():
+                feat3d = self.backbone.forward_pooled(block)
+        feat3d = feat3d.contiguous()
+        if self.use_l2_norm:
+            feat3d = DF.l2_normalize(feat3d)
+        x = feat3d
+        if self.use_final_bn:
+            if self.final_bn.training:
+                x = DF.batchnorm1d_train(x, self.store, self.final_bn)
+            else:
+                if torch.is_grad_enabled() and x.requires_grad:
+                    raise NotImplementedError('backward through an eval-mode final_bn is not built')
+                x = self._bn1d_eval(x.detach())
+        for i, m in enumerate(self.final_fc):
+            if isinstance(m, nn.Dropout):
+                if m.training:
+                    x = DF.dropout(x, float(m.p))
+            elif isinstance(m, nn.Linear):
+                nxt = self.final_fc[i + 1] if i + 1 < len(self.final_fc) else None
+                x = DF.linear(x, self.store, m, isinstance(nxt, nn.ReLU))
+        return x, feat3d

@@ -39,8 +39,14 @@ class SGD(torch.optim.Optimizer):
             if self.grad_sync is not None:
                 scale = self.grad_sync(st)
             copy = st.cc if st.dtype != ops.DV_F32 else None
-            ops.call('dv_sgd_momentum', st.master, st.grad, self._momentum_buf(st), st.total, lr, mu, wd, scale,
-                     st.dtype, copy)
+            buf = self._momentum_buf(st)
+            es = ops.ESIZE[st.dtype]
+            # one launch over the whole arena, or one per contiguous run of trainable tensors when part of the model is
+            # frozen (classifier.py:240-246 '--train_what last': requires_grad = False on the backbone -- torch's SGD
+            # would not touch those tensors, not even with weight decay)
+            for a, n in st.trainable_ranges():
+                ops.call('dv_sgd_momentum', st.master.data_ptr() + 4 * a, st.grad.data_ptr() + 4 * a, buf.data_ptr() + 4 * a, n,
+                         lr, mu, wd, scale, st.dtype, (copy.data_ptr() + es * a) if copy is not None else None)
             st.mark_dirty(cast_done=True)
 
     def state_dict(self):

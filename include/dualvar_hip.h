@@ -168,6 +168,9 @@ int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int32_t tile_ro
 /* Eval mode (module.eval(): nn.BatchNorm3d with running statistics, classifier.py's test / retrieval passes and the
  * 'last'-layer finetune): the per-channel affine map of dv_bn_apply from the running statistics,
  * scale = gamma * rsqrt(running_var + eps), shift = beta - running_mean * scale, written up to round_up(C, 8). */
+/* partials [2][C][1] = (sum, M2 about the mean) of a small fp32 [M][C] matrix: train-mode BatchNorm1d of the classifier
+ * head (model/classifier.py:29-32) then runs through dv_bn_stats_finalize / dv_bn_apply / dv_bn_bwd_* like any other */
+int dv_bn_rows_partials_f32(const float* x, int32_t ldx, int32_t M, int32_t C, float* partials, void* stream);
 int dv_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, int32_t C, float* scale, float* shift, void* stream);
 int dv_bn_finalize(const float* stats /*[R] rows of (sum[C], M2[C], count), row pitch `stride` floats*/, int32_t R,
@@ -282,6 +285,11 @@ int dv_ntxent_fwd(const float* rows, const float* cols, int32_t R, int32_t n_loc
 int dv_infonce_fwd(const float* q, const float* k, const float* queue, int32_t B, int32_t D, int32_t K,
                    float inv_T, float* logits, float* loss_rows, int32_t* rank0, float* dlogits /*[B][1+K]*/,
                    float* dq, void* stream);
+/* nn.CrossEntropyLoss (mean) over integer targets, the downstream classifier's criterion (classifier.py:330,465):
+ * loss_rows[r] = logsumexp(logits[r]) - logits[r][labels[r]], dlogits (optional) = (softmax - onehot) / R,
+ * rank0 (optional) = classes scoring above the target (top-k accuracy without a sort) */
+int dv_softmax_ce_fwd(const float* logits, int32_t ld, int32_t R, int32_t K, const int32_t* labels, float* loss_rows,
+                      float* dlogits, int32_t ldd, int32_t* rank0, void* stream);
 int dv_rank_margin(const float* feats /*[Bn][2s][D]*/, int32_t Bn, int32_t s, int32_t D, float theta,
                    float clip /*<=0: none*/, float weight, float* logits, float* loss /*[1]*/, float* dfeats,
                    float* scratch /*[Bn]*/, void* stream);

@@ -178,6 +178,74 @@ def case_eval(ref):
     np.savez_compressed(os.path.join(GOLD, 'eval.npz'), **rec)
 
 
+def _clf_train(c, mode, xa, xb, labels, steps=2, lr=0.01):
+    """classifier.py:240-262,422-470 restated: 'ft' = model.train(), every parameter trained; 'last' = model.eval(),
+    final_bn.train(), backbone frozen.  SGD(momentum 0.9, wd 1e-4); CrossEntropyLoss."""
+    with torch.no_grad():
+        c.train()
+        c.backbone(xa)                                   # non-trivial running statistics
+    if mode == 'last':
+        for n_, p_ in c.named_parameters():
+            if 'backbone' in n_:
+                p_.requires_grad = False
+    params = [{'params': [p_]} for p_ in c.parameters() if p_.requires_grad]
+    opt = torch.optim.SGD(params, lr=lr, momentum=0.9, weight_decay=1e-4)
+    crit = torch.nn.CrossEntropyLoss()
+    rec = {}
+    for it in range(steps):
+        if mode == 'last':
+            c.eval()
+            if getattr(c, 'use_final_bn', False):
+                c.final_bn.train()
+        else:
+            c.train()
+        logit, feat = c(xb)
+        loss = crit(logit, labels)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            rec['logit0'], rec['feat0'] = logit.detach().numpy().copy(), feat.detach().numpy().copy()
+            for k, v in grad_summary(c).items():
+                rec['grad/' + k] = v
+        opt.step()
+        rec['loss%d' % it] = np.array(float(loss))
+    for k, v in param_checksum(c).items():
+        rec['param/' + k] = v
+    with torch.no_grad():
+        rec['eval_logit'] = c.eval()(xb)[0].numpy().copy()
+    return rec
+
+
+def case_classifier_train(ref):
+    """downstream finetune steps on r3d, B = 4: 'ft' without dropout (its mask cannot be reproduced
+    across devices) and 'last' with L2 norm + final BatchNorm1d (dropout is off in that mode anyway)"""
+    xa = P.procedural_clips(4, 1, **CLIP)[:, 0]
+    xb = P.procedural_clips(4, 1, seed=77, **CLIP)[:, 0]
+    labels = torch.tensor([3, 0, 2, 1])
+    out = {}
+    for mode, kw in (('ft', dict(use_dropout=False)), ('last', dict(use_dropout=True, use_l2_norm=True, use_final_bn=True))):
+        recs = []
+        for mk in (lambda **k: ref.linear_classifier('r3d', **k), lambda **k: O.LinearClassifier(network='r3d', **k)):
+            torch.manual_seed(0)
+            c = mk(num_class=10, **kw)
+            P.procedural_init(c)
+            recs.append(_clf_train(c, mode, xa, xb, labels))
+        err = compare(recs[0], recs[1], ('clf', mode))
+        # sensitivity: the reference re-run on a 1e-6-perturbed input
+        torch.manual_seed(0)
+        c = ref.linear_classifier('r3d', num_class=10, **kw)
+        P.procedural_init(c)
+        noise = torch.from_numpy(np.random.RandomState(99).standard_normal(xb.numel())).float().reshape(xb.shape)
+        pert = _clf_train(c, mode, xa, xb * (1 + 1e-6 * noise), labels)
+        for k in list(recs[0].keys()):
+            a, b = np.asarray(recs[0][k], dtype=np.float64), np.asarray(pert[k], dtype=np.float64)
+            recs[0]['sens/' + k] = np.array(float(np.max(np.abs(a - b))))
+        for k, v in recs[0].items():
+            out[mode + '/' + k] = v
+        print('classifier train', mode, 'ref-vs-oracle', err, 'loss', float(recs[0]['loss0']), float(recs[0]['loss1']))
+    np.savez_compressed(os.path.join(GOLD, 'classifier_train.npz'), **out)
+
+
 def case_models(ref):
     _init_pg()
     for kind, net, B in (('simclr_naked', 's3dg', 4), ('simclr_timeseriesv4', 's3dg', 4),
@@ -268,7 +336,7 @@ def case_losses():
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['backbones', 'models', 'losses', 'eval']
+    which = sys.argv[1:] or ['backbones', 'models', 'losses', 'eval', 'clf']
     if 'losses' in which:
         case_losses()
     ref = harness.load_reference()
@@ -276,6 +344,8 @@ def main():
         case_backbones(ref)
     if 'eval' in which:
         case_eval(ref)
+    if 'clf' in which:
+        case_classifier_train(ref)
     if 'models' in which:
         case_models(ref)
 

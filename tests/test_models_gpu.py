@@ -220,10 +220,72 @@ def test_linear_classifier_eval_against_reference_fixture(gpu, tag, kw):
     xb = P.procedural_clips(4, 1, seed=77, **CLIP)[:, 0].to(gpu)
     with torch.no_grad():
         c.backbone.forward_pooled(xa)
-        with pytest.raises(NotImplementedError):
-            c(xb)                                   # train-mode head: not built
         logit, feat = c.eval()(xb)
     assert tuple(logit.shape) == (4, 101) and tuple(feat.shape) == (4, 1024)
     ef, el = rel_err(feat.cpu().numpy(), g[f'clf_{tag}/feat']), rel_err(logit.cpu().numpy(), g[f'clf_{tag}/logit'])
     print(f'classifier {tag}: feature rel err {ef:.2e}, logit rel err {el:.2e}')
     assert ef < 3e-4 and el < 1e-3
+
+
+@pytest.mark.parametrize('mode,kw', [('ft', dict(use_dropout=False)),
+                                     ('last', dict(use_dropout=True, use_l2_norm=True, use_final_bn=True))])
+def test_classifier_finetune_steps_against_reference_fixture(gpu, mode, kw):
+    """classifier.py:240-262,422-470 on the HIP engine: two SGD steps of the downstream classifier on r3d -- 'ft' (all
+    parameters, train-mode backbone) and 'last' (frozen eval-mode backbone, L2 norm + train-mode final BatchNorm1d) --
+    against tests/golden/classifier_train.npz, recorded from the reference's own model/classifier.py."""
+    from dualvar_amd import functional as DF
+    from dualvar_amd.model import LinearClassifier
+    from dualvar_amd.optim import SGD
+    P = _P()
+    g = gold('classifier_train')
+    c = LinearClassifier(num_class=10, network='r3d', **kw)
+    P.procedural_init(c)
+    c.set_compute_dtype('fp32').train().to(gpu)
+    xa = P.procedural_clips(4, 1, **CLIP)[:, 0].to(gpu)
+    xb = P.procedural_clips(4, 1, seed=77, **CLIP)[:, 0].to(gpu)
+    labels = torch.tensor([3, 0, 2, 1], device=gpu)
+    with torch.no_grad():
+        c.backbone.forward_pooled(xa)
+    if mode == 'last':
+        for n_, p_ in c.named_parameters():
+            if 'backbone' in n_:
+                p_.requires_grad = False
+    opt = SGD([p_ for p_ in c.parameters() if p_.requires_grad], lr=0.01, momentum=0.9, weight_decay=1e-4, stores=c.stores())
+    frozen0 = {k: v.clone() for k, v in c.state_dict().items() if 'backbone' in k and v.dtype.is_floating_point} if mode == 'last' else {}
+
+    def bound(key, base):
+        return max(base, 5 * float(g[f'{mode}/sens/{key}']))
+    for it in range(2):
+        if mode == 'last':
+            c.eval()
+            c.final_bn.train()
+        else:
+            c.train()
+        logit, feat = c(xb)
+        loss, rank0 = DF.cross_entropy(logit, labels)
+        # the HIP criterion == torch's on the same logits
+        assert abs(float(loss) - float(torch.nn.functional.cross_entropy(logit.detach(), labels))) < 1e-5
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            assert rel_err(feat.detach().cpu().numpy(), g[f'{mode}/feat0']) < 3e-4
+            assert np.max(np.abs(logit.detach().cpu().numpy() - g[f'{mode}/logit0'])) < bound('logit0', 2e-4)
+            worst = 0.0
+            for k, v in grad_summary(c, P).items():
+                if mode == 'last' and k.startswith('backbone'):
+                    assert v[0] == 0.0, k              # frozen: the arena views stay, nothing is written into them
+                    continue
+                ref = g[f'{mode}/grad/{k}']
+                b = max(2e-2 * abs(ref[0]) + 1e-7, 5 * float(g[f'{mode}/sens/grad/{k}']))
+                worst = max(worst, abs(v[0] - ref[0]) / b)
+            assert worst < 1.0, worst
+        opt.step()
+        assert abs(float(loss) - float(g[f'{mode}/loss{it}'])) < bound(f'loss{it}', 1e-3), (it, float(loss), float(g[f'{mode}/loss{it}']))
+    for k, v in param_checksum(c, P).items():
+        ref = g[f'{mode}/param/{k}']
+        assert abs(v[0] - ref[0]) <= max(1e-4 * abs(ref[0]) + 1e-6, 25 * float(g[f'{mode}/sens/param/{k}'])), k
+    for k, v in frozen0.items():                      # frozen tensors: untouched, not even by weight decay
+        assert torch.equal(c.state_dict()[k], v), k
+    with torch.no_grad():
+        ev = c.eval()(xb)[0].cpu().numpy()
+    assert np.max(np.abs(ev - g[f'{mode}/eval_logit'])) < bound('eval_logit', 1e-3)

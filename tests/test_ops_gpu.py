@@ -537,3 +537,58 @@ def test_sgd_and_ema(gpu):
     kg = k.to(gpu)
     ops.call('dv_ema', kg, qq.to(gpu), n, 0.999, DV_F32, None)
     close(kg, k * 0.999 + qq * (1 - 0.999), DV_F32, 'ema')
+
+
+def test_classifier_head_ops(gpu):
+    """softmax cross-entropy (loss, gradient, rank of the target), inverted dropout, train-mode BatchNorm1d and the arena
+    Linear against torch on the same numbers"""
+    from dualvar_amd import functional as DF
+    from dualvar_amd.engine import ParamStore
+    R, K, Fd = 6, 101, 64
+    lg = (3 * rnd(R, K, seed=81)).to(gpu).requires_grad_(True)
+    tgt = torch.tensor([5, 100, 0, 17, 17, 42], device=gpu)
+    loss, rank0 = DF.cross_entropy(lg, tgt)
+    (2.0 * loss).backward()
+    lr = lg.detach().cpu().clone().requires_grad_(True)
+    ref = F.cross_entropy(lr, tgt.cpu())
+    (2.0 * ref).backward()
+    assert abs(float(loss) - float(ref)) < 1e-5
+    close(lg.grad, lr.grad, DV_F32, 'ce grad')
+    assert torch.equal(rank0.cpu().long(), (lr.detach() > lr.detach().gather(1, tgt.cpu()[:, None])).sum(1))
+    # dropout: kept entries scaled by 1/(1-p), gradient through the same mask
+    x = rnd(R, Fd, seed=82).to(gpu).requires_grad_(True)
+    torch.manual_seed(3)
+    y = DF.dropout(x, 0.5)
+    keep = (y != 0)
+    assert 0.2 < float(keep.float().mean()) < 0.8
+    assert torch.allclose(y[keep], 2.0 * x.detach()[keep])
+    y.sum().backward()
+    assert torch.equal(x.grad != 0, keep) and torch.allclose(x.grad[keep], torch.full_like(x.grad[keep], 2.0))
+    # BatchNorm1d (train) -> Linear through a ParamStore arena
+    bn, lin = torch.nn.BatchNorm1d(Fd), torch.nn.Linear(Fd, 10)
+    bn.weight.data.copy_(1 + 0.2 * rnd(Fd, seed=83))
+    bn.bias.data.copy_(0.1 * rnd(Fd, seed=84))
+    bn_r, lin_r = torch.nn.BatchNorm1d(Fd), torch.nn.Linear(Fd, 10)
+    bn_r.load_state_dict(bn.state_dict())
+    lin_r.load_state_dict(lin.state_dict())
+    st = ParamStore()
+    st.add_bn(bn)
+    st.add_conv(lin.weight, need_dgrad=False)
+    st.add_vec(lin.bias)
+    st.materialize(gpu, DV_F32)
+    xi = (2 * rnd(R, Fd, seed=85) + 0.3)
+    xg = xi.to(gpu).requires_grad_(True)
+    out = DF.linear(DF.batchnorm1d_train(xg, st, bn), st, lin)
+    gy = rnd(R, 10, seed=86)
+    out.backward(gy.to(gpu))
+    xr = xi.clone().requires_grad_(True)
+    out_r = lin_r(bn_r.train()(xr))
+    out_r.backward(gy)
+    close(out, out_r, DV_F32, 'bn1d+linear fwd', factor=5)
+    close(xg.grad, xr.grad, DV_F32, 'bn1d+linear dx', factor=20)
+    close(lin.weight.grad, lin_r.weight.grad, DV_F32, 'linear dW', factor=5)
+    close(lin.bias.grad, lin_r.bias.grad, DV_F32, 'linear db', factor=5)
+    close(bn.weight.grad, bn_r.weight.grad, DV_F32, 'bn1d dgamma', factor=20)
+    close(bn.bias.grad, bn_r.bias.grad, DV_F32, 'bn1d dbeta', factor=5)
+    close(bn.running_mean, bn_r.running_mean, DV_F32, 'bn1d running mean', factor=5)
+    close(bn.running_var, bn_r.running_var, DV_F32, 'bn1d running var', factor=5)
