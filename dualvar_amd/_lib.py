@@ -70,6 +70,7 @@ SIGNATURES = {
     'dv_ingest_ncdhw': [I32, P, P, I32, I32, I32, I32, I32, I64, I32, P, P, P, I32, P],
     'dv_ingest_ncdhw_pad': [I32, P, P, I32, I32, I32, I32, I32, I64, I32, P, P, P, I32, I32, P],
     'dv_fill_cols_f32': [P, I64, I32, I32, I32, F, P],
+    'dv_addcmul_f32': [P, P, P, F, I32, P],
     'dv_bn_eval_coeffs': [P, P, P, P, F, I32, P, P, P],
     'dv_bn_rows_partials_f32': [P, I32, I32, I32, P, P],
     'dv_softmax_ce_fwd': [P, I32, I32, I32, P, P, P, I32, P, P],

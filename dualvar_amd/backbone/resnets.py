@@ -238,3 +238,82 @@ class ResNet2d3d(HipBackbone):
             for bi, b in enumerate(layer):
                 x = b.emit(plan, x, force_relu=(li == 3 and bi == len(layer) - 1))
         return x
+
+
+# ------------------------------------------------------------------ 2D3D ResNet-18 (`r2d3d18`)
+class BasicBlock2d(nn.Module):
+    """resnet_2d3d.py:45-78: conv1x3x3-BN-ReLU-conv1x3x3-BN (+ identity / 1x1x1-conv shortcut) (+ReLU)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, use_final_relu=True):
+        super().__init__()
+        self.use_final_relu = use_final_relu
+        self.conv1 = nn.Conv3d(inplanes, planes, (1, 3, 3), (1, stride, stride), (0, 1, 1), bias=False)
+        self.bn1 = nn.BatchNorm3d(planes)
+        self.conv2 = nn.Conv3d(planes, planes, (1, 3, 3), 1, (0, 1, 1), bias=False)
+        self.bn2 = nn.BatchNorm3d(planes)
+        self.downsample = downsample
+
+    def register(self, store):
+        register_conv_bn(store, self.conv1, self.bn1)
+        register_conv_bn(store, self.conv2, self.bn2)
+        if self.downsample is not None:
+            register_conv_bn(store, self.downsample[0], self.downsample[1])
+
+    def emit(self, plan, x):
+        y = emit_conv_bn(plan, self.conv1, self.bn1, x)
+        shortcut = x
+        if self.downsample is not None:
+            shortcut = emit_conv_bn(plan, self.downsample[0], self.downsample[1], x, relu=False)
+        return emit_conv_bn(plan, self.conv2, self.bn2, y, relu=self.use_final_relu, residual=shortcut)
+
+
+class ResNet2d3dFull(HipBackbone):
+    """resnet_2d3d.py:203-270 `ResNet2d3d_full` as `r2d3d18()` builds it (:352-356): BasicBlock2d x [2,2,2,2]; the last
+    block of layer4 (256 planes) has no final ReLU and `forward` adds none -- the feature map is NOT rectified."""
+    feature_size = 256
+
+    def __init__(self, block=BasicBlock2d, layers=(2, 2, 2, 2)):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv3d(3, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3), bias=False)
+        self.bn1 = nn.BatchNorm3d(64)
+        self.maxpool = nn.MaxPool3d((1, 3, 3), (1, 2, 2), (0, 1, 1))
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 256, layers[3], stride=2, is_final=True)
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out')
+            elif isinstance(m, nn.BatchNorm3d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, block, planes, blocks, stride=1, is_final=False):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(nn.Conv3d(self.inplanes, planes * block.expansion, 1, (1, stride, stride), bias=False),
+                                       nn.BatchNorm3d(planes * block.expansion))
+        mods = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        n_plain = blocks - 2 if is_final else blocks - 1
+        mods += [block(self.inplanes, planes) for _ in range(n_plain)]
+        if is_final:
+            mods.append(block(self.inplanes, planes, use_final_relu=False))
+        return nn.Sequential(*mods)
+
+    def register_params(self, store):
+        register_conv_bn(store, self.conv1, self.bn1, first=True)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for b in layer:
+                b.register(store)
+
+    def emit(self, plan, x):
+        x = emit_conv_bn(plan, self.conv1, self.bn1, x)
+        mp = self.maxpool
+        x = plan.maxpool(x, _t3(mp.kernel_size), _t3(mp.stride), _t3(mp.padding))
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for b in layer:
+                x = b.emit(plan, x)
+        return x

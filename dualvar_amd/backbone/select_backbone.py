@@ -3,8 +3,9 @@
 Contract of the reference factory (backbone/select_backbone.py:7-31): the returned module maps clips
 [N,3,T,H,W] to a post-ReLU feature map [N,feature_size,T',H',W'].  Here the modules are the HIP-engine
 backbones, and 'r50' builds the 2D3D ResNet-50 the reference meant to build (its own call raises TypeError:
-SURVEY.md D7).  'c3d' and 'r2d3d18' are not on the pretrain hot path and are not provided."""
-from .resnets import Bottleneck2d, Bottleneck3d, R2Plus1DNet, R3DNet, ResNet2d3d
+SURVEY.md D7).  Every name of the reference factory is provided (s3d, s3dg, r21d, r3d, r50, r2d3d18, c3d)."""
+from .c3d import C3D
+from .resnets import Bottleneck2d, Bottleneck3d, R2Plus1DNet, R3DNet, ResNet2d3d, ResNet2d3dFull
 from .s3dg import S3D
 
 _FACTORIES = {
@@ -13,6 +14,8 @@ _FACTORIES = {
     'r21d': lambda ch: R2Plus1DNet(),
     'r3d': lambda ch: R3DNet(),
     'r50': lambda ch: ResNet2d3d([Bottleneck2d, Bottleneck2d, Bottleneck3d, Bottleneck3d], [3, 4, 6, 3], ch),
+    'r2d3d18': lambda ch: ResNet2d3dFull(),
+    'c3d': lambda ch: C3D(),
 }
 
 

@@ -972,6 +972,17 @@ extern "C" int dv_bn_rows_partials_f32(const float* x, int32_t ldx, int32_t M, i
   return dv_launch_status();
 }
 
+__global__ void addcmul_kernel(float* __restrict__ y, const float* __restrict__ a, const float* __restrict__ b, float alpha, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += alpha * a[i] * (b ? b[i] : 1.f);
+}
+
+extern "C" int dv_addcmul_f32(float* y, const float* a, const float* b, float alpha, int32_t n, void* stream) {
+  if (!y || !a || n <= 0) return DV_EINVAL;
+  hipLaunchKernelGGL(addcmul_kernel, dim3((n + 255) / 256), dim3(256), 0, ST(stream), y, a, b, alpha, n);
+  return dv_launch_status();
+}
+
 extern "C" int dv_bn_reduce_stats(const float* partials, int32_t n_tiles, int32_t tile_rows, int32_t pitch, int64_t M,
                                   int32_t C, float* local_stats, void* stream) {
   if (!partials || !local_stats || n_tiles <= 0 || C <= 0 || M <= 0 || pitch < C) return DV_EINVAL;

@@ -409,8 +409,13 @@ class Plan:
         op = self._push(BNGroupOp(self, specs))
         return [m.y for m in op.members]
 
-    def bn(self, bn_mod, x, relu=True, residual=None, out=None):
-        return self.bn_group([(bn_mod, x, relu, residual, out)])[0]
+    def bn(self, bn_mod, x, relu=True, residual=None, out=None, conv_bias=None):
+        """conv_bias: the bias vector of the conv that produced x (c3d.py: Conv3d(bias=True) + BatchNorm3d).  The conv
+        kernel runs bias-free: in train mode the bias cancels in the normalised output and only shifts the running mean,
+        in eval mode it folds into the shift; its gradient is identically zero (weight decay still applies)."""
+        ys = self.bn_group([(bn_mod, x, relu, residual, out)])
+        self.ops[-1].members[0].conv_bias = conv_bias
+        return ys[0]
 
     def maxpool(self, x, k, s, p):
         return self._push(PoolOp(self, x, k, s, p)).y
@@ -634,6 +639,7 @@ class BNMember:
         self.width = 2 * self.C + 1
         # y = relu(x*scale + shift) with nothing added: the backward recomputes the ReLU mask from x (which it reads for
         # xhat anyway) with the forward's expression and never touches y -- 5 tensor passes per BatchNorm instead of 7
+        self.conv_bias = None        # Plan.bn(conv_bias=...)
         self.mask_from_x = bool(relu) and residual is None
         self.sums_off = plan.reserve_zero(BN_REPLICAS * 2 * self.CP) if plan.with_grad else 0
         self.sums_len = BN_REPLICAS * 2 * self.CP
@@ -731,6 +737,9 @@ class BNGroupOp(Op):
             f.append(Launch('bn_eval_coeffs', 'bn_eval_coeffs', lib.dv_bn_eval_coeffs,
                             (st.w_master(gs), st.w_master(bs), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                              float(bn.eps), m.C, m.scale.data_ptr(), m.shift.data_ptr())))
+            if m.conv_bias is not None:          # y = scale*(conv + b) + shift
+                f.append(Launch('bn_bias_shift', 'addcmul', lib.dv_addcmul_f32,
+                                (m.shift.data_ptr(), m.scale.data_ptr(), st.w_master(st.slot(m.conv_bias)), 1.0, m.C)))
             f.append(Launch('bn_apply', 'bn_apply<%s>' % dt, lib.dv_bn_apply,
                             (p.dtype, x.ptr, x.ld, m.scale.data_ptr(), m.shift.data_ptr(),
                              res.ptr if res is not None else 0, res.ld if res is not None else 0, y.ptr, y.ld, m.M, m.C,
@@ -818,6 +827,12 @@ class BNGroupOp(Op):
                     pending.pop().wait()
                 b.append(HostStep('syncbn_allreduce_start', _start))
                 b.append(HostStep('syncbn_allreduce_wait', _wait))
+        for m in self.members:               # conv bias in front of the BN: only the running mean sees it
+            if m.conv_bias is not None and m.bn.running_mean is not None:
+                assert len(self.members) == 1
+                mom = float(m.bn.momentum if m.bn.momentum is not None else 0.1)
+                f.append(Launch('bn_bias_running_mean', 'addcmul', lib.dv_addcmul_f32,
+                                (m.bn.running_mean.data_ptr(), st.w_master(st.slot(m.conv_bias)), 0, mom, m.C)))
         f += f_app
         b += b_app
         return f, b

@@ -171,6 +171,10 @@ int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int32_t tile_ro
 /* partials [2][C][1] = (sum, M2 about the mean) of a small fp32 [M][C] matrix: train-mode BatchNorm1d of the classifier
  * head (model/classifier.py:29-32) then runs through dv_bn_stats_finalize / dv_bn_apply / dv_bn_bwd_* like any other */
 int dv_bn_rows_partials_f32(const float* x, int32_t ldx, int32_t M, int32_t C, float* partials, void* stream);
+/* y[i] += alpha * a[i] * (b ? b[i] : 1): per-channel fix-ups for a conv BIAS in front of a BatchNorm (c3d.py:15-47) --
+ * train mode: the bias cancels in the normalised output and only moves the running mean (running_mean += momentum*bias);
+ * eval mode: shift += scale * bias */
+int dv_addcmul_f32(float* y, const float* a, const float* b, float alpha, int32_t n, void* stream);
 int dv_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, int32_t C, float* scale, float* shift, void* stream);
 int dv_bn_finalize(const float* stats /*[R] rows of (sum[C], M2[C], count), row pitch `stride` floats*/, int32_t R,

@@ -246,6 +246,36 @@ def case_classifier_train(ref):
     np.savez_compressed(os.path.join(GOLD, 'classifier_train.npz'), **out)
 
 
+def case_backbones_extra(ref):
+    """the remaining names of the reference factory (select_backbone.py:9-27): r2d3d18 and c3d -- train-mode features,
+    then eval() on other clips (pins the conv-bias handling of c3d through the running mean)"""
+    rec = {}
+    xa = P.procedural_clips(4, 1, **CLIP)[:, 0]
+    xb = P.procedural_clips(4, 1, seed=77, **CLIP)[:, 0]
+    for net in ('r2d3d18', 'c3d'):
+        outs = []
+        for sel in (ref.select_backbone, O.select_backbone):
+            m, _ = sel(net)
+            P.procedural_init(m).train()
+            with torch.no_grad():
+                y = m(xa)
+                ye = m.eval()(xb)
+            outs.append((y, ye, m))
+        err = max(float((outs[0][i] - outs[1][i]).abs().max()) for i in range(2))
+        assert err < 1e-5, (net, err)
+        rec[net + '/feat'] = outs[0][0].numpy()
+        rec[net + '/pooled'] = outs[0][0].mean(dim=(2, 3, 4)).numpy()
+        rec[net + '/eval_pooled'] = outs[0][1].mean(dim=(2, 3, 4)).numpy()
+        m = outs[0][2]
+        with torch.no_grad():
+            m2, _ = ref.select_backbone(net)
+            P.procedural_init(m2).train()
+            y64 = m2.double()(xa.double())
+        rec[net + '/fp32_vs_fp64'] = np.array(float((outs[0][0].double() - y64).abs().max() / y64.abs().max()))
+        print('backbone', net, tuple(outs[0][0].shape), 'ref-vs-oracle', err, 'fp32-vs-fp64', float(rec[net + '/fp32_vs_fp64']))
+    np.savez_compressed(os.path.join(GOLD, 'backbones_extra.npz'), **rec)
+
+
 def case_models(ref):
     _init_pg()
     for kind, net, B in (('simclr_naked', 's3dg', 4), ('simclr_timeseriesv4', 's3dg', 4),
@@ -336,7 +366,7 @@ def case_losses():
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['backbones', 'models', 'losses', 'eval', 'clf']
+    which = sys.argv[1:] or ['backbones', 'models', 'losses', 'eval', 'clf', 'extra']
     if 'losses' in which:
         case_losses()
     ref = harness.load_reference()
@@ -346,6 +376,8 @@ def main():
         case_eval(ref)
     if 'clf' in which:
         case_classifier_train(ref)
+    if 'extra' in which:
+        case_backbones_extra(ref)
     if 'models' in which:
         case_models(ref)
 

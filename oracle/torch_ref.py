@@ -379,6 +379,93 @@ class ResNet2d3d(nn.Module):
         return F.relu(x)
 
 
+class BasicBlock2d(nn.Module):
+    """resnet_2d3d.py:45-78: two 1x3x3 convs (+BN), identity / 1x1x1-conv shortcut, optional final ReLU."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, use_final_relu=True):
+        super().__init__()
+        self.use_final_relu = use_final_relu
+        self.conv1 = nn.Conv3d(inplanes, planes, (1, 3, 3), (1, stride, stride), (0, 1, 1), bias=False)
+        self.bn1 = nn.BatchNorm3d(planes)
+        self.conv2 = nn.Conv3d(planes, planes, (1, 3, 3), 1, (0, 1, 1), bias=False)
+        self.bn2 = nn.BatchNorm3d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))
+        out = out + (x if self.downsample is None else self.downsample(x))
+        return F.relu(out) if self.use_final_relu else out
+
+
+class ResNet2d3dFull(nn.Module):
+    """resnet_2d3d.py:203-270 `ResNet2d3d_full` as `r2d3d18()` instantiates it (:352-356): BasicBlock2d x [2,2,2,2], stem
+    1x7x7 / (1,2,2), layer4 at 256 planes whose last block has no final ReLU -- and, unlike ResNet2d3d, no ReLU after it
+    either (`forward` :259-270)."""
+
+    def __init__(self, block=BasicBlock2d, layers=(2, 2, 2, 2)):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv3d(3, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3), bias=False)
+        self.bn1 = nn.BatchNorm3d(64)
+        self.maxpool = nn.MaxPool3d((1, 3, 3), (1, 2, 2), (0, 1, 1))
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 256, layers[3], stride=2, is_final=True)
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out')
+            elif isinstance(m, nn.BatchNorm3d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, block, planes, blocks, stride=1, is_final=False):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(nn.Conv3d(self.inplanes, planes * block.expansion, 1, (1, stride, stride), bias=False),
+                                       nn.BatchNorm3d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        if is_final:
+            layers += [block(self.inplanes, planes) for _ in range(1, blocks - 1)]
+            layers.append(block(self.inplanes, planes, use_final_relu=False))
+        else:
+            layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.maxpool(F.relu(self.bn1(self.conv1(x))))
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            x = layer(x)
+        return x
+
+
+class C3D(nn.Module):
+    """c3d.py:9-86: eight 3x3x3 convs WITH bias, each followed by BatchNorm3d + ReLU; pools (1,2,2) then (2,2,2) x 3."""
+
+    def __init__(self):
+        super().__init__()
+        cfg = (('1', 3, 64), ('2', 64, 128), ('3a', 128, 256), ('3b', 256, 256), ('4a', 256, 512), ('4b', 512, 512),
+               ('5a', 512, 512), ('5b', 512, 512))
+        for tag, cin, cout in cfg:
+            setattr(self, 'conv' + tag, nn.Conv3d(cin, cout, 3, padding=1))
+            setattr(self, 'bn' + tag, nn.BatchNorm3d(cout))
+        self.pool1 = nn.MaxPool3d((1, 2, 2), (1, 2, 2))
+        self.pool2 = nn.MaxPool3d(2, 2)
+        self.pool3 = nn.MaxPool3d(2, 2)
+        self.pool4 = nn.MaxPool3d(2, 2)
+
+    def forward(self, x):
+        def cbr(tag, v):
+            return F.relu(getattr(self, 'bn' + tag)(getattr(self, 'conv' + tag)(v)))
+        x = self.pool1(cbr('1', x))
+        x = self.pool2(cbr('2', x))
+        x = self.pool3(cbr('3b', cbr('3a', x)))
+        x = self.pool4(cbr('4b', cbr('4a', x)))
+        return cbr('5b', cbr('5a', x))
+
+
 def select_backbone(network, first_channel=3):
     """select_backbone.py:7-31; 'r50' built as the survey's D7 repair."""
     param = {'feature_size': 1024}
@@ -395,6 +482,12 @@ def select_backbone(network, first_channel=3):
     elif network == 'r3d':
         param['feature_size'] = 512
         model = R3DNet()
+    elif network == 'r2d3d18':
+        param['feature_size'] = 256
+        model = ResNet2d3dFull()
+    elif network == 'c3d':
+        param['feature_size'] = 512
+        model = C3D()
     else:
         raise NotImplementedError(network)
     return model, param

@@ -289,3 +289,28 @@ def test_classifier_finetune_steps_against_reference_fixture(gpu, mode, kw):
     with torch.no_grad():
         ev = c.eval()(xb)[0].cpu().numpy()
     assert np.max(np.abs(ev - g[f'{mode}/eval_logit'])) < bound('eval_logit', 1e-3)
+
+
+@pytest.mark.parametrize('net', ['r2d3d18', 'c3d'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_remaining_factory_backbones(gpu, net, dtype):
+    """select_backbone('r2d3d18' / 'c3d') (select_backbone.py:9-27): train-mode features and eval-mode
+    features after that forward, against the reference's own classes (tests/golden/backbones_extra.npz).  c3d's convs
+    carry a bias in front of their BatchNorm: the eval output checks that it reached the running mean."""
+    from dualvar_amd.backbone import select_backbone
+    P = _P()
+    g = gold('backbones_extra')
+    m, prm = select_backbone(net)
+    assert prm['feature_size'] == g[net + '/pooled'].shape[1]
+    P.procedural_init(m)
+    m.set_compute_dtype(dtype).train().to(gpu)
+    xa = P.procedural_clips(4, 1, **CLIP)[:, 0].to(gpu)
+    xb = P.procedural_clips(4, 1, seed=77, **CLIP)[:, 0].to(gpu)
+    with torch.no_grad():
+        fmap = m(xa)
+        ev = m.eval().forward_pooled(xb)
+    e1 = rel_err(fmap.cpu().numpy(), g[net + '/feat'])
+    e2 = rel_err(ev.cpu().numpy(), g[net + '/eval_pooled'])
+    print(f'{net} {dtype}: train map rel err {e1:.2e}, eval pooled rel err {e2:.2e}')
+    tol = max(3e-4, 4 * float(g[net + '/fp32_vs_fp64'])) if dtype == 'fp32' else 8e-2
+    assert e1 < tol and e2 < tol

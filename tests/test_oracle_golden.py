@@ -35,6 +35,20 @@ def test_backbone_fixture(net):
     assert np.max(np.abs(y.numpy() - g[net + '/feat'])) <= tol * np.max(np.abs(g[net + '/feat']))
 
 
+@pytest.mark.parametrize('net', ['r2d3d18', 'c3d'])
+def test_extra_backbone_fixture(net):
+    from oracle import procedural as P, torch_ref as O
+    g = gold('backbones_extra')
+    m, _ = O.select_backbone(net)
+    P.procedural_init(m).train()
+    with torch.no_grad():
+        y = m(P.procedural_clips(4, 1, **CLIP)[:, 0])
+        ye = m.eval()(P.procedural_clips(4, 1, seed=77, **CLIP)[:, 0]).mean(dim=(2, 3, 4))
+    tol = max(2e-5, 3 * float(g[net + '/fp32_vs_fp64']))
+    assert np.max(np.abs(y.numpy() - g[net + '/feat'])) <= tol * np.max(np.abs(g[net + '/feat']))
+    assert np.max(np.abs(ye.numpy() - g[net + '/eval_pooled'])) <= tol * np.max(np.abs(g[net + '/eval_pooled']))
+
+
 def test_eval_mode_and_classifier_fixture():
     """eval-mode BatchNorm (running statistics after one train-mode forward) and the downstream LinearClassifier of the
     oracle reproduce tests/golden/eval.npz (the reference's backbone.eval() / model/classifier.py outputs)"""
