@@ -270,7 +270,10 @@ def main():
                      'algorithmic_bytes_per_launch': round(nbytes / n),
                      'traffic_source': (roof_src + ' (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)') if traffic else None})
         out = {
-            'metric': 'clips/sec (whole node), S3D-G 8x112^2 SimCLR pretrain step', 'value': round(clips / dt, 2),
+            'metric': ('clips/sec (whole node), S3D-G 8x112^2 SimCLR pretrain step'
+                       if (args.net, args.model, args.frames, args.size) == ('s3dg', 'simclr_naked', 8, 112) else
+                       f'clips/sec (whole node), {args.net} {args.frames}x{args.size}^2 {args.model} pretrain step'),
+            'value': round(clips / dt, 2),
             'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
