@@ -1,0 +1,161 @@
+"""Size-independent properties at the BASELINE sizes (128 clips of 8x112x112 per GPU, bf16) -- where the CPU oracle would
+take minutes per layer, the kernels are checked through identities that hold at any size:
+
+  * conv: <conv(x, w), dy> == <x, dgrad(dy, w)> == <w, wgrad(x, dy)>  (fwd / dgrad / wgrad are mutual adjoints) on the
+    largest S3D-G layers, and exact homogeneity conv(x, 2w) == 2 conv(x, w) (a power-of-two scale is exact in bf16);
+  * BatchNorm: output statistics (mean beta, variance gamma^2), sum(dx) == 0 and sum(dx * xhat) == 0 in the backward;
+  * max-pool: every output is the maximum of its window maxima bound, gradient mass is conserved (sum dx == sum dy);
+  * the whole step: a permutation of the batch permutes the logits (the statistics are batch-symmetric) and the loss of a
+    full-size step equals the loss formula evaluated on the CPU from the returned logits.
+All calls go through the C ABI (dualvar_amd.ops -> libdualvar_hip.so)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dualvar_amd import ops  # noqa: E402
+from dualvar_amd.ops import DV_BF16  # noqa: E402
+
+N_CLIPS = 128
+
+# (name, T, H, W, Cin, Cout, k, s, p) at 128 clips: the largest S3D-G layers and one stride-2 case
+BIG_LAYERS = [
+    ('Conv_2c.conv1 1x3x3', 4, 28, 28, 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('Conv_2c.conv2 3x1x1', 4, 28, 28, 192, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ('Conv_1a.conv2 7x1x1 s2', 8, 56, 56, 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0)),
+    ('Mixed_3c entry 1x1x1', 4, 14, 14, 256, 288, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+]
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+@pytest.mark.parametrize('layer', BIG_LAYERS, ids=[c[0] for c in BIG_LAYERS])
+def test_conv_adjoint_identities_at_full_size(gpu, layer):
+    name, T, H, W, Ci, Co, k, s, p = layer
+    g = torch.Generator(device='cpu').manual_seed(7)
+    x = ops.new_act(N_CLIPS, T, H, W, Ci, DV_BF16, gpu)
+    x.buf.copy_(torch.randn(x.buf.shape, generator=g).relu_().to(torch.bfloat16))
+    To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
+    y, dy = ops.new_act(N_CLIPS, To, Ho, Wo, Co, DV_BF16, gpu), ops.new_act(N_CLIPS, To, Ho, Wo, Co, DV_BF16, gpu)
+    dy.buf.copy_(torch.randn(dy.buf.shape, generator=g).to(torch.bfloat16))
+    taps = k[0] * k[1] * k[2]
+    wf = (torch.randn(Co, taps, Ci, generator=g) * (taps * Ci) ** -0.5).to(gpu)            # master layout [Co][tap][Ci]
+    w16 = wf.to(torch.bfloat16)
+    wd = w16.float().permute(2, 1, 0).contiguous().to(torch.bfloat16)                      # dgrad layout [Ci][tap][Co]
+    d = ops.conv_desc(DV_BF16, x, y, k, s, p)
+    ops.conv_fwd(d, x, w16, None, y, None)
+    dx = x.like()
+    ops.conv_dgrad(d, dy, wd, dx)
+    dw = torch.zeros(Co, taps * Ci, device=gpu)
+    ops.conv_wgrad(d, x, dy, dw)
+    torch.cuda.synchronize()
+    a = _dot(y.buf, dy.buf)                    # <conv(x,w), dy>   (y is bf16-rounded: 2^-9 relative per element)
+    b = _dot(x.buf, dx.buf)                    # <x, dgrad(dy,w)>
+    c = _dot(w16.float().reshape(Co, -1), dw)  # <w, wgrad(x,dy)>  (fp32 accumulation, exact up to summation order)
+    scale = float(y.buf.double().norm() * dy.buf.double().norm())
+    print(f'{name}: <y,dy>={a:.6e} <x,dx>={b:.6e} <w,dw>={c:.6e} (|y||dy|={scale:.3e})')
+    # rounding of y / dx to bf16 is unbiased: the inner products agree to ~2^-9 / sqrt(#elements) of |y||dy|
+    assert abs(a - c) <= 2e-4 * scale and abs(b - c) <= 2e-4 * scale
+    # homogeneity: doubling the weights doubles every output bit for bit
+    y2 = y.like()
+    ops.conv_fwd(d, x, (w16.float() * 2).to(torch.bfloat16), None, y2, None)
+    assert torch.equal(y2.buf.float(), y.buf.float() * 2)
+
+
+def test_batchnorm_statistics_and_backward_orthogonality_at_full_size(gpu):
+    """the stem's BatchNorm (M = 128*8*56*56 = 3.2 M rows, C = 64): conv epilogue partials -> statistics -> apply ->
+    backward reduce / apply"""
+    from dualvar_amd._lib import DV_NO_RELU_MASK
+    T, H, W, C_ = 8, 56, 56, 64
+    g = torch.Generator().manual_seed(11)
+    xin = ops.new_act(N_CLIPS, T, H, W, 64, DV_BF16, gpu)
+    xin.buf.copy_(torch.randn(xin.buf.shape, generator=g).to(torch.bfloat16))
+    x = ops.new_act(N_CLIPS, T, H, W, C_, DV_BF16, gpu)
+    d = ops.conv_desc(DV_BF16, xin, x, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=ops.DV_STATS)
+    w16 = (torch.randn(C_, 64, generator=g) / 8).to(gpu).to(torch.bfloat16)
+    tiles = ops.stat_tiles(d)
+    part = torch.zeros(2, C_, tiles, device=gpu)
+    ops.conv_fwd(d, xin, w16, None, x, part)
+    M = x.rows
+    gamma, beta = (1 + 0.2 * torch.randn(C_, generator=g)).to(gpu), (0.1 * torch.randn(C_, generator=g)).to(gpu)
+    local = torch.zeros(2 * C_ + 1, device=gpu)
+    mean, invstd, scale, shift = (torch.zeros(C_, device=gpu) for _ in range(4))
+    ops.call('dv_bn_stats_finalize', part, tiles, ops.tile_rows(d), C_, M, C_, local, gamma, beta, 1e-5, 0.1, None, None,
+             mean, invstd, scale, shift)
+    xs = x.buf.float()
+    assert torch.allclose(mean, xs.mean(0), atol=2e-5, rtol=1e-4)                       # fused partials == direct statistics
+    assert torch.allclose(invstd, (xs.var(0, unbiased=False) + 1e-5).rsqrt(), rtol=2e-4)
+    y = x.like()
+    ops.call('dv_bn_apply', DV_BF16, x, x.ld, scale, shift, None, 0, y, y.ld, M, C_, 0)
+    ys = y.buf.float()
+    assert float((ys.mean(0) - beta).abs().max()) < 2e-3                                 # bf16 storage of y
+    assert float((ys.var(0, unbiased=False).sqrt() - gamma.abs()).abs().max()) < 5e-3
+    dy = x.like()
+    dy.buf.copy_(torch.randn(dy.buf.shape, generator=g).to(torch.bfloat16))
+    CP = ops.cp8(C_)
+    sums = torch.zeros(8, 2, CP, device=gpu)
+    ops.call('dv_bn_bwd_reduce', DV_BF16, dy, dy.ld, y, y.ld, x, x.ld, mean, invstd, M, C_, DV_NO_RELU_MASK, sums, 8)
+    dx = x.like()
+    dgam, dbet = torch.zeros(C_, device=gpu), torch.zeros(C_, device=gpu)
+    ops.call('dv_bn_bwd_apply', DV_BF16, dy, dy.ld, y, y.ld, x, x.ld, mean, invstd, gamma, sums, 8, 1.0 / M, 1.0, dgam, dbet,
+             dx, dx.ld, None, 0, M, C_, DV_NO_RELU_MASK)
+    torch.cuda.synchronize()
+    gs = dy.buf.float()
+    assert torch.allclose(dbet, gs.sum(0), rtol=1e-3, atol=1e-1)
+    xhat = (xs - mean) * invstd
+    assert torch.allclose(dgam, (gs * xhat).sum(0), rtol=2e-3, atol=1.0)
+    # the BatchNorm backward projects out the constant and the xhat direction of every channel
+    dxs = dx.buf.float()
+    tot = dxs.abs().sum(0)
+    assert float((dxs.sum(0).abs() / tot).max()) < 2e-3 and float(((dxs * xhat).sum(0).abs() / tot).max()) < 2e-3
+
+
+@pytest.mark.parametrize('k,s,p,T,H,W,C_', [((3, 3, 3), (1, 1, 1), (1, 1, 1), 4, 14, 14, 256),
+                                            ((1, 3, 3), (1, 2, 2), (0, 1, 1), 4, 56, 56, 64)])
+def test_maxpool_bounds_and_gradient_mass_at_full_size(gpu, k, s, p, T, H, W, C_):
+    g = torch.Generator().manual_seed(13)
+    x = ops.new_act(N_CLIPS, T, H, W, C_, DV_BF16, gpu)
+    x.buf.copy_(torch.randn(x.buf.shape, generator=g).relu_().to(torch.bfloat16))
+    To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
+    y = ops.new_act(N_CLIPS, To, Ho, Wo, C_, DV_BF16, gpu)
+    idx = torch.zeros(y.rows, ops.cp8(C_), dtype=torch.uint8, device=gpu)
+    d = ops.pool_desc(DV_BF16, x, y, k, s, p)
+    ops.call('dv_maxpool3d_fwd', d, x, y, idx)
+    xs, ys = x.buf.view(N_CLIPS, T, H, W, C_), y.buf.view(N_CLIPS, To, Ho, Wo, C_)
+    # the centre tap of every window is inside it: y >= x at the window centres; and y never exceeds the global maximum
+    ctr = xs[:, (k[0] // 2 - p[0])::s[0], (k[1] // 2 - p[1])::s[1], (k[2] // 2 - p[2])::s[2]][:, :To, :Ho, :Wo]
+    assert bool((ys >= ctr).all()) and float(ys.float().max()) == float(xs.float().max())
+    assert int(idx.max()) < k[0] * k[1] * k[2]
+    dy = y.like()
+    dy.buf.copy_(torch.randn(dy.buf.shape, generator=g).to(torch.bfloat16))
+    dx = x.like()
+    ops.call('dv_maxpool3d_bwd', d, dy, idx, dx, 0)
+    torch.cuda.synchronize()
+    sy, sx = dy.buf.double().sum(0), dx.buf.double().sum(0)               # per channel: every dy lands on exactly one input
+    assert float((sy - sx).abs().max()) <= 2e-3 * float(dy.buf.double().abs().sum(0).max())
+
+
+def test_full_size_step_is_batch_symmetric_and_loss_matches_its_logits(gpu):
+    """S3D-G SimCLR_Naked, 64 samples x 2 views of 8x112x112, bf16 (the bench workload)"""
+    from dualvar_amd import model as M
+    torch.manual_seed(0)
+    m = M.SimCLR_Naked('s3dg', 128, 0.07, False)
+    m.set_compute_dtype('bf16').train().to(gpu)
+    g = torch.Generator().manual_seed(5)
+    block = torch.randn(64, 2, 3, 8, 112, 112, generator=g).to(gpu)
+    perm = torch.randperm(64, generator=g).to(gpu)
+    with torch.no_grad():
+        r1 = m(block)
+        r2 = m(block[perm])
+    lg = r1['clip_logits'].float().cpu()
+    assert lg.shape == (128, 127) and bool(torch.isfinite(lg).all())
+    # the loss is the cross-entropy of the returned logits (positive in column 0)
+    ce = float(torch.nn.functional.cross_entropy(lg, torch.zeros(128, dtype=torch.long)))
+    assert abs(ce - float(r1['clip_contrast_loss'])) < 1e-4
+    # batch statistics do not depend on the order of the samples: same loss, and row i's positive logit moves with it
+    assert abs(float(r1['clip_contrast_loss']) - float(r2['clip_contrast_loss'])) < 5e-2
+    pos1, pos2 = lg[:64, 0], r2['clip_logits'].float().cpu()[:64, 0]
+    assert float((pos1[perm.cpu()] - pos2).abs().max()) < 0.15 * float(pos1.abs().max())
