@@ -44,6 +44,12 @@ struct ConvArgs {
   int src_bytes, w_bytes; // extents for the buffer descriptors (< 2 GiB)
   FastDiv fCP;           // k -> (tap, c)
   ConvGeom g;
+  // Strided dgrad, one launch per PARITY CLASS (cls_on): input positions t = t'*cst + cot (same for h, w) only receive
+  // the kernel taps d = crt + cst*j, so in (t', j) coordinates the class is a dense stride-1 problem -- `g` describes
+  // it (row space = the class's sub-lattice, kernel = its taps, padding (cot + pt - crt) / cst) -- instead of gathering
+  // all taps and multiplying zeros for the (st*sh*sw - 1)/(st*sh*sw) that miss.  The weights are not repacked: a class tap
+  // reads the ORIGINAL tap ((crt+cst*jt)*oKH + crh+csh*jh)*oKW + crw+csw*jw; output rows map back to the full input.
+  int cls_on, cst, csh, csw, cot, coh, cow, crt, crh, crw, oKH, oKW, oT, oH, oW;
 };
 
 template <int BYTES> struct VecB;
@@ -269,7 +275,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
       const int dw = tp % g.kw, t2 = tp / g.kw, dh = t2 % g.kh, dt = t2 / g.kh;
       const int toff = MODE == MODE_FWD ? (dt * g.sH + dh) * g.sW + dw
                                         : -(((dt >> st_s) * g.sH + (dh >> sh_s)) * g.sW + (dw >> sw_s));
-      taptab[tp] = make_int2(toff, dt | (dh << 8) | (dw << 16));
+      const int otap = a.cls_on ? ((a.crt + a.cst * dt) * a.oKH + a.crh + a.csh * dh) * a.oKW + a.crw + a.csw * dw : tp;
+      taptab[tp] = make_int2(toff, dt | (dh << 8) | (dw << 16) | (otap << 24));
     }
   }
   const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src), 0, a.src_bytes, 0x00020000);
@@ -308,6 +315,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   }
   // uniform-tap mode: wave-uniform K cursor (next tile to load) and per-row inverted tap masks
   int u_c0 = 0, u_tap = 0, u_dt = 0, u_dh = 0, u_dw = 0;
+  int u_otap = a.cls_on ? (a.crt * a.oKH + a.crh) * a.oKW + a.crw : 0;     // weight tap of class tap 0
   unsigned u_toffb = 0;                        // source byte offset of the current tap relative to tap 0
   unsigned imask[A_G];
   if constexpr (GM == 1) {
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
         const unsigned off = ((__builtin_amdgcn_ubfe(imask[p], (unsigned)u_tap, 1u)) << 31) | (rowoff[p] + s_a);
         dma_load16(src_dma, smem_base + buf * BUFB + (uwave + p * NW) * 1024, off);
       }
-      const unsigned s_b = (unsigned)(u_tap * g.CP + u_c0) * ES;
+      const unsigned s_b = (unsigned)(u_otap * g.CP + u_c0) * ES;
 #pragma unroll
       for (int p = 0; p < B_G; ++p)
         if (uwave + p * NW < BN / 16)
@@ -356,6 +364,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
         const int toff = MODE == MODE_FWD ? (u_dt * g.sH + u_dh) * g.sW + u_dw
                                           : -(((u_dt >> (g.st - 1)) * g.sH + (u_dh >> (g.sh - 1))) * g.sW + (u_dw >> (g.sw - 1)));
         u_toffb = (unsigned)toff * ldb;
+        u_otap = a.cls_on ? ((a.crt + a.cst * u_dt) * a.oKH + a.crh + a.csh * u_dh) * a.oKW + a.crw + a.csw * u_dw : u_tap;
       }
       return;
     }
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
     const unsigned c = k - tap * (unsigned)g.CP;
     const bool tin = (int)tap < ntaps;
     const int2 ti = taptab[tin ? tap : 0];
-    const unsigned dt = ti.y & 255, dh = (ti.y >> 8) & 255, dw = (unsigned)ti.y >> 16;
+    const unsigned dt = ti.y & 255, dh = (ti.y >> 8) & 255, dw = (ti.y >> 16) & 255, otap = (unsigned)ti.y >> 24;
     const unsigned tb = (unsigned)ti.x * ldb + c * ES;
 #pragma unroll
     for (int p = 0; p < A_G; ++p) {
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
         ra[p] = make_uint2(v.x, v.y);
       }
     }
-    const unsigned kb = (k < (unsigned)g.Ktot) ? k * ES : kOOB;
+    const unsigned kb = tin ? (otap * (unsigned)g.CP + c) * ES : kOOB;      // weights sit at the original tap index
 #pragma unroll
     for (int p = 0; p < B_G; ++p) {
       const unsigned off = (woff[p] | kb) >= kOOB ? kOOB : woff[p] + kb;
@@ -459,6 +468,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
   // ---------------- epilogue
   T* out = reinterpret_cast<T*>(a.out);
   const int flags = a.flags;
+  // row of the output tensor for row `m` of this launch (identity, or class sub-lattice -> full input: see ConvArgs)
+  auto out_row = [&](int m) -> size_t {
+    if (!a.cls_on) return (size_t)m;
+    uint32_t q_, w_, h_, t_, n_;
+    fd_divmod((uint32_t)m, g.dW, q_, w_);
+    fd_divmod(q_, g.dH, q_, h_);
+    fd_divmod(q_, g.dT, n_, t_);
+    return ((size_t)(n_ * a.oT + t_ * a.cst + a.cot) * a.oH + h_ * a.csh + a.coh) * a.oW + w_ * a.csw + a.cow;
+  };
   // BatchNorm partials of this tile (fwd + DV_STATS): per column the sum and M2 (about the tile mean) of the values AS
   // STORED, over valid rows.  One pass, fused into the conversion loop: each wave accumulates sum(v - c) and
   // sum((v - c)^2) about a provisional centre c = its first row's value (a sample of the column, so no cancellation
@@ -517,7 +535,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
         const int row = m0 + wm0 + i * 32 + rl, col0 = n0 + wn0 + ch * 8;
         if (row < a.M && col0 < a.NP) {
           bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + rl * SP + ch * 16);
-          T* p = out + (size_t)row * a.ldo + col0;
+          T* p = out + out_row(row) * a.ldo + col0;
           if (flags & DV_ACCUM) {
             const bf16x8 o = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
@@ -541,7 +559,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvA
           float v = act_apply(acc[i][j][r] + bv, flags);
           if (col >= a.N) v = 0.f;
           if (row < a.M && col < a.NP) {
-            T* p = out + (size_t)row * a.ldo + col;
+            T* p = out + out_row(row) * a.ldo + col;
             if (flags & DV_ACCUM) v += DT<T>::to_f(*p);
             T tv = DT<T>::from_f(v);
             *p = tv;
@@ -1164,6 +1182,7 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   a.N = d->Cout; a.NP = d->cout_pitch;
   a.lds_ = d->ldx; a.ldo = d->ldy; a.ldw = a.g.Ktot;
   a.flags = d->flags & (DV_BIAS | DV_RELU | DV_SIGMOID | DV_STATS);
+  a.cls_on = 0;
   {
     const int64_t es = d->dtype == DV_F32 ? 4 : 2;
     const int64_t sb = ((int64_t)d->N * d->Ti * d->Hi * d->Wi - 1) * d->ldx * es + (int64_t)d->cin_pitch * es;
@@ -1213,11 +1232,43 @@ extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void
     a.src_bytes = (int)sb; a.w_bytes = (int)wb;
     a.fCP = make_fastdiv((uint32_t)a.g.CP);
   }
+  hipStream_t s = (hipStream_t)stream;
+  a.cls_on = 0;
+  const bool strided = d->st > 1 || d->sh > 1 || d->sw > 1;
+  if (strided && d->kt >= d->st && d->kh >= d->sh && d->kw >= d->sw) {
+    // one dense stride-1 launch per parity class of the input positions (see ConvArgs): every class has >= 1 tap
+    const int taps_orig = d->kt * d->kh * d->kw;
+    for (int rt = 0; rt < d->st; ++rt)
+      for (int rh = 0; rh < d->sh; ++rh)
+        for (int rw = 0; rw < d->sw; ++rw) {
+          auto first = [](int r, int p, int st_) { return ((r - p) % st_ + st_) % st_; };   // smallest pos with (pos+p)%s == r
+          const int ot = first(rt, d->pt, d->st), oh = first(rh, d->ph, d->sh), ow = first(rw, d->pw, d->sw);
+          if (ot >= d->Ti || oh >= d->Hi || ow >= d->Wi) continue;
+          ConvArgs c = a;
+          ConvGeom& g = c.g;
+          g.rT = (d->Ti - ot + d->st - 1) / d->st; g.rH = (d->Hi - oh + d->sh - 1) / d->sh; g.rW = (d->Wi - ow + d->sw - 1) / d->sw;
+          g.kt = (d->kt - rt + d->st - 1) / d->st; g.kh = (d->kh - rh + d->sh - 1) / d->sh; g.kw = (d->kw - rw + d->sw - 1) / d->sw;
+          g.st = g.sh = g.sw = 1;
+          g.pt = (ot + d->pt - rt) / d->st; g.ph = (oh + d->ph - rh) / d->sh; g.pw = (ow + d->pw - rw) / d->sw;
+          g.Ktot = g.kt * g.kh * g.kw * g.CP;
+          g.dW = make_fastdiv((uint32_t)g.rW); g.dH = make_fastdiv((uint32_t)g.rH); g.dT = make_fastdiv((uint32_t)g.rT);
+          c.M = d->N * g.rT * g.rH * g.rW;
+          c.ldw = taps_orig * g.CP;
+          c.cls_on = 1; c.cst = d->st; c.csh = d->sh; c.csw = d->sw; c.cot = ot; c.coh = oh; c.cow = ow;
+          c.crt = rt; c.crh = rh; c.crw = rw; c.oKH = d->kh; c.oKW = d->kw; c.oT = d->Ti; c.oH = d->Hi; c.oW = d->Wi;
+          int bm, bn;
+          pick_tile(c.M, c.NP, bm, bn);
+          c.ntn = (c.NP + bn - 1) / bn;
+          const int grid = c.ntn * ((c.M + bm - 1) / bm);
+          if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, c, grid, s);
+          else launch_gemm<bf16_t, MODE_DGRAD, 16>(bm, bn, c, grid, s);
+        }
+    return dv_launch_status();
+  }
   int bm, bn;
   pick_tile(a.M, a.NP, bm, bn);
   a.ntn = (a.NP + bn - 1) / bn;
   const int grid = a.ntn * ((a.M + bm - 1) / bm);
-  hipStream_t s = (hipStream_t)stream;
   if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, a, grid, s);
   else launch_gemm<bf16_t, MODE_DGRAD, 16>(bm, bn, a, grid, s);
   return dv_launch_status();
