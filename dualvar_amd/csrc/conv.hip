@@ -211,8 +211,16 @@ __device__ __forceinline__ float act_apply(float v, int flags) {
 // row in the prologue, and a gather address costs three VALU instructions (add, bfe, lshl_or) instead of ~12 -- the K
 // loop was issue bound on exactly that address arithmetic (VALU ~ half of all issued cycles in the PMC profile).
 // NS: LDS stages of the DMA pipeline (tiles k+1 .. k+NS-1 are in flight while tile k is multiplied; counted vmcnt).
+// Waves per SIMD the register allocator is asked to make room for (the LDS footprint allows that many workgroups; the
+// K loop is issue bound and resident waves are what hides it): 6 for the 128x64 / 64x128 bf16 tiles (<= 80 VGPRs instead
+// of 84-88), 3 for 128x128 (<= 168 instead of 172), no request otherwise.
+constexpr int conv_waves_per_simd(int es, int gvb, int bm, int bn) {
+  return (es != 2 || gvb != 16) ? 1 : (bm * bn == 128 * 64) ? 6 : (bm == 128 && bn == 128) ? 3 : 1;
+}
+
 template <typename T, int MODE, int GVB, int BM, int BN, int WAVES_M, int WAVES_N, int GM, int NS = 2>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_gemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
+__attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))) void conv_gemm_kernel(ConvArgs a) {
   // DMA: 16-byte gathers go global -> LDS directly (buffer_load ... lds), no VGPR staging and no ds_write.  One wave
   // instruction fills 16 rows x 64 B = 1 KiB of a row-linear, UNPADDED tile; bank conflicts of the ds_read_b128 fragment
   // reads are avoided by XOR-swizzling the 16-byte slot with (row>>2)&3, applied on the source side (which k-slot a

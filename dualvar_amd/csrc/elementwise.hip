@@ -587,7 +587,7 @@ __device__ __forceinline__ uint32_t pool_key(uint32_t x /* bf16 in the top half,
   return x ^ ((m & 0x7fff0000u) | (0x80000000u | code));
 }
 
-__global__ __launch_bounds__(256) void maxpool333_fwd_kernel(Pool3Args a, const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void maxpool333_fwd_kernel(Pool3Args a, const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                               uint8_t* __restrict__ idx) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.total; i += gridDim.x * blockDim.x) {
     uint32_t q, cvi, run, h_, t_, n_;
