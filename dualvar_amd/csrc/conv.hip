@@ -891,7 +891,9 @@ __device__ __forceinline__ bf16x8 wg_frag(const unsigned char* tile, int col0, i
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int BI, int BJ>
+// NS: LDS stages -- tiles s+1 .. s+NS-1 are in flight while tile s is multiplied (counted vmcnt; every wave issues the
+// same NPW + NQW pieces per tile)
+template <int BI, int BJ, int NS>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradDmaArgs aa) {
   const WgradArgs& a = aa.w;
   constexpr int ROWS = 32;
@@ -905,7 +907,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradDmaArgs aa) {
   constexpr int WI = BI / 2, WJ = BJ / 2, TI = WI / 32, TJ = WJ / 32;
   constexpr unsigned kOOB = 0x80000000u;
 
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUFB];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * BUFB];
   __shared__ uint2 rowtab[2][RT];
 
   const ConvGeom& g = a.g;
@@ -1000,17 +1002,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradDmaArgs aa) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nsteps = (m_end - m_begin + ROWS - 1) / ROWS;
+  constexpr int D = NS - 1;                          // prefetch distance (D <= 7: the row table runs one round = 8 steps ahead)
+  static_assert(D >= 1 && D <= 7, "stages");
   decode(0);
   __syncthreads();
-  issue(0, 0);
-  dma_wait_all();
-  __syncthreads();
+  for (int t = 0; t < D && t < nsteps; ++t) issue(t, t);
+  int cur = 0, nxt = D % NS;
   for (int s = 0; s < nsteps; ++s) {
-    const int cur = s & 1;
-    // table of round R+1 is written during the first step of round R; its previous contents (round R-1) were last
-    // read two barriers ago, and its first reader (step 8R+7) is seven barriers ahead
+    dma_wait_upto(min(D - 1, nsteps - 1 - s) * (NPW + NQW));       // tile s has landed (this wave's pieces)
+    __syncthreads();                                 // ... everybody's; stage `nxt` (tile s-1) and the old row table are free
+    // table of round R+1 is written during the first step of round R; its previous contents (round R-1) were last read
+    // at least one barrier ago, and its first reader (the issue for step 8(R+1), at step 8(R+1)-D) is later
     if ((s & 7) == 0 && (s + 8) < nsteps) decode((s >> 3) + 1);
-    if (s + 1 < nsteps) issue(s + 1, cur ^ 1);
+    if (s + D < nsteps) issue(s + D, nxt);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[TI], bf[TJ];
@@ -1023,8 +1027,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradDmaArgs aa) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    dma_wait_all();                                  // tile s+1 has landed
-    __syncthreads();
+    cur = cur + 1 == NS ? 0 : cur + 1;
+    nxt = nxt + 1 == NS ? 0 : nxt + 1;
   }
 
   const int h = lane >> 5, l31 = lane & 31;
@@ -1319,8 +1323,16 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
     if (xb < (1ll << 31) && yb < (1ll << 31)) {
       WgradDmaArgs aa;
       aa.w = a; aa.x_bytes = (int)xb; aa.dy_bytes = (int)yb;
-      if (narrow) hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 128>), dim3(grid), dim3(256), 0, s, aa);
-      else hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 64>), dim3(grid), dim3(256), 0, s, aa);
+      // three stages below 50k rows (fewer resident workgroups there anyway: 690 -> 628 us over the 12 544-row layers of
+      // the S3D-G step), two above (1351 vs 1335 / 1392 us with three / four)
+      const int ns = a.M < 50000 ? 3 : 2;
+#define WGD(NS_)                                                                                               \
+  do {                                                                                                         \
+    if (narrow) hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 128, NS_>), dim3(grid), dim3(256), 0, s, aa);    \
+    else hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 64, NS_>), dim3(grid), dim3(256), 0, s, aa);           \
+  } while (0)
+      if (ns == 3) WGD(3); else WGD(2);
+#undef WGD
       return dv_launch_status();
     }
   }
