@@ -419,6 +419,39 @@ extern "C" int dv_softmax_ce_fwd(const float* logits, int32_t ld, int32_t R, int
   return dv_launch_status();
 }
 
+// Nearest-neighbour retrieval score (classifier.py:964-981: topk over sim = test . train^T, hit if any of the k nearest
+// train samples carries the test label): per test row the rank of its best same-label train sample, i.e. the number of
+// train samples scoring strictly above it; the k-NN accuracy is mean(rank < k) for every k at once, without a sort.
+// rank = n_train when no train sample has the label.  One wave per row.
+__global__ void knn_rank_rows_kernel(const float* __restrict__ sim, int ld, int R, int Nt, const int* __restrict__ train_labels,
+                                     const int* __restrict__ test_labels, int* __restrict__ rank) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int lane = threadIdx.x & 63;
+  const float* row = sim + (size_t)r * ld;
+  const int y = test_labels[r];
+  float best = -INFINITY;
+  for (int j = lane; j < Nt; j += 64)
+    if (train_labels[j] == y) best = fmaxf(best, row[j]);
+  best = wave_max(best);
+  float cnt = 0.f;
+  if (best > -INFINITY) {
+    for (int j = lane; j < Nt; j += 64) cnt += row[j] > best ? 1.f : 0.f;
+    cnt = wave_sum(cnt);
+  } else {
+    cnt = (float)Nt;
+  }
+  if (lane == 0) rank[r] = (int)cnt;
+}
+
+extern "C" int dv_knn_rank(const float* sim, int32_t ld, int32_t R, int32_t n_train, const int32_t* train_labels,
+                           const int32_t* test_labels, int32_t* rank, void* stream) {
+  if (!sim || !train_labels || !test_labels || !rank || R <= 0 || n_train <= 0 || ld < n_train) return DV_EINVAL;
+  hipLaunchKernelGGL(knn_rank_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, ST(stream), sim, ld, R, n_train, train_labels,
+                     test_labels, rank);
+  return dv_launch_status();
+}
+
 extern "C" int dv_rank_margin(const float* feats, int32_t Bn, int32_t s, int32_t D, float theta, float clip, float weight,
                               float* logits, float* loss, float* dfeats, float* scratch /*[Bn]*/, void* stream) {
   if (!feats || !logits || !loss || !dfeats || !scratch || Bn <= 0 || s < 2 || s > 8 || D <= 0 || theta <= 0.f) return DV_EINVAL;

@@ -289,6 +289,11 @@ int dv_ntxent_fwd(const float* rows, const float* cols, int32_t R, int32_t n_loc
 int dv_infonce_fwd(const float* q, const float* k, const float* queue, int32_t B, int32_t D, int32_t K,
                    float inv_T, float* logits, float* loss_rows, int32_t* rank0, float* dlogits /*[B][1+K]*/,
                    float* dq, void* stream);
+/* NN-retrieval score (classifier.py:964-981, torch.topk over the test x train similarity): rank[r] = number of train
+ * samples scoring strictly above test row r's best same-label train sample (n_train if the label is absent); the k-NN
+ * accuracy of the reference is mean(rank < k), for every k from one pass */
+int dv_knn_rank(const float* sim, int32_t ld, int32_t R, int32_t n_train, const int32_t* train_labels,
+                const int32_t* test_labels, int32_t* rank, void* stream);
 /* nn.CrossEntropyLoss (mean) over integer targets, the downstream classifier's criterion (classifier.py:330,465):
  * loss_rows[r] = logsumexp(logits[r]) - logits[r][labels[r]], dlogits (optional) = (softmax - onehot) / R,
  * rank0 (optional) = classes scoring above the target (top-k accuracy without a sort) */

@@ -592,3 +592,26 @@ def test_classifier_head_ops(gpu):
     close(bn.bias.grad, bn_r.bias.grad, DV_F32, 'bn1d dbeta', factor=5)
     close(bn.running_mean, bn_r.running_mean, DV_F32, 'bn1d running mean', factor=5)
     close(bn.running_var, bn_r.running_var, DV_F32, 'bn1d running var', factor=5)
+
+
+def test_nn_retrieval_matches_the_reference_recipe(gpu):
+    """dualvar_amd.utils.retrieval == classifier.py:964-981 (centre, normalise, matmul, topk hit-rate) in torch"""
+    from dualvar_amd.utils.retrieval import nn_retrieval, video_features
+    g = torch.Generator().manual_seed(91)
+    ncls, D = 7, 64
+    proto = torch.randn(ncls, D, generator=g)
+    ytr, yte = torch.randint(0, ncls, (90,), generator=g), torch.randint(0, ncls, (40,), generator=g)
+    clips_tr = proto[ytr].repeat_interleave(10, 0) + 9.0 * torch.randn(900, D, generator=g) + 0.7
+    clips_te = proto[yte].repeat_interleave(10, 0) + 9.0 * torch.randn(400, D, generator=g) + 0.7
+    ftr, fte = video_features(clips_tr.to(gpu), 10), video_features(clips_te.to(gpu), 10)
+    assert torch.allclose(ftr.cpu(), clips_tr.view(90, 10, D).mean(1), atol=1e-5)
+    acc, sim = nn_retrieval(fte, yte, ftr, ytr)
+    a, b = clips_te.view(40, 10, D).mean(1), clips_tr.view(90, 10, D).mean(1)
+    a, b = F.normalize(a - a.mean(0, keepdim=True), dim=1), F.normalize(b - b.mean(0, keepdim=True), dim=1)
+    ref = a @ b.t()
+    close(sim, ref, DV_F32, 'retrieval similarity', factor=10)
+    for k in (1, 5, 10, 20, 50):
+        idx = ref.topk(k, dim=1).indices
+        want = float((ytr[idx] == yte[:, None]).any(1).float().mean())
+        assert abs(acc[k] - want) < 1e-6, (k, acc[k], want)
+    assert 0.2 < acc[1] < 1.0 and acc[50] >= acc[1]           # a non-trivial case: neither chance nor saturated
