@@ -419,6 +419,28 @@ extern "C" int dv_softmax_ce_fwd(const float* logits, int32_t ld, int32_t R, int
   return dv_launch_status();
 }
 
+// Row softmax (F.softmax(logit, dim=-1) of the 10-clip test, classifier.py:716): one wave per row.
+__global__ void softmax_rows_kernel(const float* __restrict__ logits, int ld, int R, int K, float* __restrict__ probs, int ldp) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int lane = threadIdx.x & 63;
+  const float* lg = logits + (size_t)r * ld;
+  float mx = -INFINITY;
+  for (int j = lane; j < K; j += 64) mx = fmaxf(mx, lg[j]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int j = lane; j < K; j += 64) se += expf(lg[j] - mx);
+  se = wave_sum(se);
+  const float inv = 1.f / se;
+  for (int j = lane; j < K; j += 64) probs[(size_t)r * ldp + j] = expf(lg[j] - mx) * inv;
+}
+
+extern "C" int dv_softmax_rows_f32(const float* logits, int32_t ld, int32_t R, int32_t K, float* probs, int32_t ldp, void* stream) {
+  if (!logits || !probs || R <= 0 || K <= 0 || ld < K || ldp < K) return DV_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, ST(stream), logits, ld, R, K, probs, ldp);
+  return dv_launch_status();
+}
+
 // Nearest-neighbour retrieval score (classifier.py:964-981: topk over sim = test . train^T, hit if any of the k nearest
 // train samples carries the test label): per test row the rank of its best same-label train sample, i.e. the number of
 // train samples scoring strictly above it; the k-NN accuracy is mean(rank < k) for every k at once, without a sort.

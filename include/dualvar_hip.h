@@ -299,6 +299,8 @@ int dv_knn_rank(const float* sim, int32_t ld, int32_t R, int32_t n_train, const 
  * rank0 (optional) = classes scoring above the target (top-k accuracy without a sort) */
 int dv_softmax_ce_fwd(const float* logits, int32_t ld, int32_t R, int32_t K, const int32_t* labels, float* loss_rows,
                       float* dlogits, int32_t ldd, int32_t* rank0, void* stream);
+/* probs[r][:] = softmax(logits[r][:K])  (F.softmax(logit, dim=-1), classifier.py:716: the 10-clip test averages these) */
+int dv_softmax_rows_f32(const float* logits, int32_t ld, int32_t R, int32_t K, float* probs, int32_t ldp, void* stream);
 int dv_rank_margin(const float* feats /*[Bn][2s][D]*/, int32_t Bn, int32_t s, int32_t D, float theta,
                    float clip /*<=0: none*/, float weight, float* logits, float* loss /*[1]*/, float* dfeats,
                    float* scratch /*[Bn]*/, void* stream);

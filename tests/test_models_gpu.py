@@ -227,6 +227,42 @@ def test_linear_classifier_eval_against_reference_fixture(gpu, tag, kw):
     assert ef < 3e-4 and el < 1e-3
 
 
+def test_multi_clip_test_against_reference_fixture(gpu):
+    """classifier.py:657-738: a video = num_seq clips along the frame axis; per-clip softmax averaged per video, scored
+    top-k on the mean.  The four fixture clips are laid out as 2 videos x 2 clips; expected = softmax of the REFERENCE's
+    logits (tests/golden/eval.npz) averaged per video."""
+    from dualvar_amd.model import LinearClassifier
+    from dualvar_amd.utils import evaluation as E
+    P = _P()
+    g = gold('eval')
+    c = LinearClassifier(num_class=101, network='s3dg', use_dropout=True)
+    P.procedural_init(c)
+    c.set_compute_dtype('fp32').train().to(gpu)
+    xa = P.procedural_clips(4, 1, **CLIP)[:, 0].to(gpu)
+    xb = P.procedural_clips(4, 1, seed=77, **CLIP)[:, 0].to(gpu)                        # [4, 3, T, H, W]
+    with torch.no_grad():
+        c.backbone.forward_pooled(xa)
+    T = CLIP['T']
+    seq = xb.view(2, 2, 3, T, CLIP['H'], CLIP['W']).permute(0, 2, 1, 3, 4, 5).reshape(2, 3, 2 * T, CLIP['H'], CLIP['W'])
+    assert torch.equal(E.clips_from_sequence(seq, 2, T), xb)
+    with pytest.raises(RuntimeError):
+        E.ten_clip_probabilities(c, seq, num_seq=2, seq_len=T)                            # still in train mode
+    per, mean = E.ten_clip_probabilities(c.eval(), seq, num_seq=2, seq_len=T)
+    want_per = torch.softmax(torch.from_numpy(g['clf_plain/logit']).double(), -1).view(2, 2, -1)
+    want = want_per.mean(1)
+    e1 = float((per.cpu().double() - want_per).abs().max() / want_per.max())
+    e2 = float((mean.cpu().double() - want).abs().max() / want.max())
+    print(f'multi-clip test: per-clip prob err {e1:.2e}, video mean err {e2:.2e}')
+    assert e1 < 1e-3 and e2 < 1e-3
+    assert torch.allclose(per.sum(-1).cpu(), torch.ones(2, 2), atol=1e-5)
+    # top-k of the mean == calc_topk_accuracy's sort-based answer, for a target placed at a known rank
+    order = mean.argsort(dim=1, descending=True).cpu()
+    tgt = torch.stack([order[0, 0], order[1, 3]])                                         # rank 0 and rank 3
+    assert E.topk_of_mean(mean, tgt, (1, 3, 4, 5)) == [0.5, 0.5, 1.0, 1.0]
+    with pytest.raises(ValueError):
+        E.clips_from_sequence(seq, 3, T)
+
+
 @pytest.mark.parametrize('mode,kw', [('ft', dict(use_dropout=False)),
                                      ('last', dict(use_dropout=True, use_l2_norm=True, use_final_bn=True))])
 def test_classifier_finetune_steps_against_reference_fixture(gpu, mode, kw):
