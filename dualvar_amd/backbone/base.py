@@ -15,6 +15,7 @@ from .. import _lib as L
 from .. import ops
 from ..engine import Comm, Op, ParamStore, Plan
 from ..ops import DV_BF16, DV_F32
+from ..utils.transforms import FrameBatch
 
 _DTYPES = {'bf16': DV_BF16, 'bfloat16': DV_BF16, 'fp32': DV_F32, 'float32': DV_F32, 'f32': DV_F32}
 
@@ -34,15 +35,31 @@ class IngestOp(Op):
         self.y = plan.act(N, T, H + 2 * pad, W + 2 * pad, 3, cpitch=4, grad=False, zero=True)
         self.y.hw_pad = pad
         self.N, self.T, self.H, self.W, self.n_seg = N, T, H, W, n_seg
-        self.src = self.perm = self.mean = self.istd = None
+        self.src = self.perm = self.mean = self.istd = self.cmean = None
         self.stride_n = 3 * T * H * W
 
     def bind(self, x, perm, mean, istd):
         self.src, self.perm, self.mean, self.istd = x, perm, mean, istd
+        if isinstance(x, FrameBatch):
+            if self.cmean is None:
+                self.cmean = torch.empty(self.N * self.T, dtype=torch.float32, device=x.device)
+            return
         self.stride_n = x.stride(0) if x.dim() == 5 else 3 * self.T * self.H * self.W
 
     def _launch(self, stream):
         p = self.plan
+        if isinstance(self.src, FrameBatch):
+            # decoded uint8 frames + augmentation table -> the same NDHWC stem input (utils/transforms.py: FrameBatch)
+            fb = self.src
+            L.check(p.lib.dv_augment_ingest(p.dtype, fb.frames.data_ptr(), fb.frames.shape[0], fb.frames.shape[1],
+                                            fb.frames.shape[2], fb.table.data_ptr(), self.N, self.T, self.H, self.W,
+                                            self.y.ptr, self.y.ld, self.pad,
+                                            self.mean.data_ptr() if self.mean is not None else 0,
+                                            self.istd.data_ptr() if self.istd is not None else 0,
+                                            self.perm.data_ptr() if self.perm is not None else 0,
+                                            self.n_seg if self.perm is not None else 0, self.cmean.data_ptr(), stream),
+                    'dv_augment_ingest')
+            return
         L.check(p.lib.dv_ingest_ncdhw_pad(p.dtype, self.src.data_ptr(), self.y.ptr, self.N, 3, self.T, self.H, self.W,
                                           self.stride_n, self.y.ld,
                                           self.mean.data_ptr() if self.mean is not None else 0,
@@ -128,6 +145,9 @@ class HipBackbone(nn.Module):
 
     def set_input_normalization(self, mean, std):
         """Fuse utils.transforms.Normalize (pretrain.py:280-282) into the ingest kernel."""
+        if mean is None:
+            self._norm = None
+            return self
         self._norm = (torch.tensor(mean, dtype=torch.float32), 1.0 / torch.tensor(std, dtype=torch.float32))
         return self
 
@@ -194,7 +214,9 @@ class HipBackbone(nn.Module):
         return pl
 
     def _run_plan(self, plan, x, perm):
-        if x.dtype != torch.float32 or x.stride()[1:] != (x.shape[2] * x.shape[3] * x.shape[4], x.shape[3] * x.shape[4], x.shape[4], 1):
+        if isinstance(x, FrameBatch):
+            pass
+        elif x.dtype != torch.float32 or x.stride()[1:] != (x.shape[2] * x.shape[3] * x.shape[4], x.shape[3] * x.shape[4], x.shape[4], 1):
             x = x.float().contiguous()
         plan._keep = x
         mean, istd = self._norm if self._norm is not None else (None, None)

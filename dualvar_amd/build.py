@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdualvar_hip.so')
-SOURCES = ['conv.hip', 'elementwise.hip', 'loss.hip']
+SOURCES = ['conv.hip', 'elementwise.hip', 'loss.hip', 'augment.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-comment', '-Wno-inline-asm', '-ffp-contract=off']
 
 

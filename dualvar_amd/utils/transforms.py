@@ -20,3 +20,285 @@ class Normalize(object):
 
     def __call__(self, vid):
         return vid if self.fused else normalize(vid, self.mean, self.std, self.channel)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Augmentation on the GPU.  The classes below keep the names, constructor arguments and -- call for
+# call -- the RNG consumption (`random`, `numpy.random`) of the reference's tensor-side transforms
+# (utils/transforms.py:201-373), but instead of touching pixels they fill one `dv_aug_frame` row per output frame;
+# the pixels are produced by ONE pass of `dv_augment_ingest` straight into the stem's NDHWC input (FrameBatch below).
+import math
+import random
+
+import numpy as np
+
+AUG_NONE, AUG_BRIGHTNESS, AUG_CONTRAST, AUG_SATURATION, AUG_GRAY = 0, 1, 2, 3, 4
+AUG_ROW = np.dtype([('src', '<i4'), ('crop_i', '<i4'), ('crop_j', '<i4'), ('crop_h', '<i4'), ('crop_w', '<i4'), ('flip', '<i4'),
+                    ('op', '<i4', (4,)), ('factor', '<f4', (4,)), ('_pad', '<i4', (2,))])          # include/dualvar_hip.h
+
+
+class ClipState:
+    """what the reference's transforms see as `vid` [C, N, h, w]: N frames with a common window, plus the ops so far"""
+
+    def __init__(self, src, Hs, Ws):
+        self.src = list(src)
+        self.i, self.j, self.h, self.w = 0, 0, Hs, Ws          # window in the source frame
+        self.out = None                                        # (H, W) once a Resize / RandomSizedCrop fixed it
+        self.flip = False
+        self.ops = []                                          # [(code, factors[N])], in applied order
+
+    @property
+    def N(self):
+        return len(self.src)
+
+    def size(self):
+        return self.out if self.out is not None else (self.h, self.w)
+
+    def _no_colour_yet(self, what):
+        if self.ops:
+            raise ValueError('%s after a colour op is not expressible in one dv_augment_ingest row' % what)
+
+    def crop(self, i, j, h, w):
+        self._no_colour_yet('crop')
+        if self.out is not None:
+            raise ValueError('crop after a resize is not expressible in one dv_augment_ingest row')
+        if self.flip:
+            raise ValueError('crop after a flip: put the crop first')
+        self.i, self.j, self.h, self.w = self.i + i, self.j + j, h, w
+
+    def rows(self, H, W):
+        oh, ow = self.size()
+        if (oh, ow) != (H, W):
+            raise ValueError('pipeline produces %dx%d frames, the plan wants %dx%d' % (oh, ow, H, W))
+        if len(self.ops) > 4 or sum(1 for c, _ in self.ops if c == AUG_CONTRAST) > 1:
+            raise ValueError('at most four colour ops and one contrast per frame')
+        t = np.zeros(self.N, dtype=AUG_ROW)
+        t['src'], t['crop_i'], t['crop_j'], t['crop_h'], t['crop_w'] = self.src, self.i, self.j, self.h, self.w
+        t['flip'] = int(self.flip)
+        for n in range(self.N):
+            k = 0
+            for code, fac in self.ops:
+                if code == AUG_GRAY and not fac[n]:
+                    continue
+                t['op'][n, k], t['factor'][n, k] = code, fac[n]
+                k += 1
+        return t
+
+
+class RandomCrop(object):                                   # transforms.py:201-219
+    def __init__(self, size):
+        self.size = size
+
+    @staticmethod
+    def get_params(hw, output_size):
+        h, w = hw
+        th, tw = output_size
+        if w == tw and h == th:
+            return 0, 0, h, w
+        i = random.randint(0, h - th)
+        j = random.randint(0, w - tw)
+        return i, j, th, tw
+
+    def __call__(self, st):
+        st.crop(*self.get_params(st.size(), self.size))
+        return st
+
+
+class RandomSizedCrop(object):                              # transforms.py:221-247
+    def __init__(self, size):
+        self.size = size
+
+    @staticmethod
+    def get_params(hw, output_size):
+        h, w = hw
+        for attempt in range(10):
+            area = h * w
+            target_area = random.uniform(0.5, 1) * area
+            aspect_ratio = random.uniform(3. / 4, 4. / 3)
+            tw = int(round(math.sqrt(target_area * aspect_ratio)))
+            th = int(round(math.sqrt(target_area / aspect_ratio)))
+            if tw <= w and th <= h:
+                i = random.randint(0, h - th)
+                j = random.randint(0, w - tw)
+                return i, j, th, tw
+        th, tw = output_size
+        i = random.randint(0, h - th)
+        j = random.randint(0, w - tw)
+        return i, j, th, tw
+
+    def __call__(self, st):
+        st.crop(*self.get_params(st.size(), self.size))
+        st.out = tuple(self.size)
+        return st
+
+
+class CenterCrop(object):                                   # transforms.py:17-24,250-255
+    def __init__(self, size):
+        self.size = size
+
+    def __call__(self, st):
+        h, w = st.size()
+        th, tw = self.size
+        st.crop(int(round((h - th) / 2.)), int(round((w - tw) / 2.)), th, tw)
+        return st
+
+
+class Resize(object):                                       # transforms.py:33-42,258-263 (size = (h, w))
+    def __init__(self, size):
+        if isinstance(size, int):
+            raise NotImplementedError('Resize(int) rescales by a float factor; pass the (h, w) it produces')
+        self.size = tuple(size)
+
+    def __call__(self, st):
+        st._no_colour_yet('resize')
+        if st.out is not None:
+            raise ValueError('two resizes in one pipeline')
+        st.out = self.size
+        return st
+
+
+class RandomHorizontalFlip(object):                         # transforms.py:286-294
+    def __init__(self, p=0.5):
+        self.p = p
+
+    def __call__(self, st):
+        if random.random() < self.p:
+            st._no_colour_yet('flip')
+            st.flip = not st.flip
+        return st
+
+
+class RandomGray(object):                                   # transforms.py:80-88,305-311 (per-frame mask)
+    def __init__(self, p=0.5):
+        self.p = p
+
+    def __call__(self, st):
+        gray_map = np.random.uniform(size=(st.N,)) < self.p
+        if gray_map.sum() == 0:
+            return st
+        st.ops.append((AUG_GRAY, gray_map.astype(np.float32)))
+        return st
+
+
+class ColorJitter(object):                                  # transforms.py:313-373
+    def __init__(self, brightness=0, contrast=0, saturation=0, consistent=False, p=1.0, n_channel=1, gray_channel=0):
+        self.brightness = self._check_input(brightness, 'brightness')
+        self.contrast = self._check_input(contrast, 'contrast')
+        self.saturation = self._check_input(saturation, 'saturation')
+        self.consistent, self.p = consistent, p
+
+    @staticmethod
+    def _check_input(value, name, center=1, bound=(0, float('inf'))):
+        if isinstance(value, (int, float)):
+            if value < 0:
+                raise ValueError('If {} is a single number, it must be non negative.'.format(name))
+            value = [center - value, center + value]
+        elif isinstance(value, (tuple, list)) and len(value) == 2:
+            if not bound[0] <= value[0] <= value[1] <= bound[1]:
+                raise ValueError('{} values should be between {}'.format(name, bound))
+        else:
+            raise TypeError('{} should be a single number or a list/tuple with lenght 2.'.format(name))
+        if value[0] == value[1] == center:
+            value = None
+        return value
+
+    def _draw(self, rng, N):                                # random_adjust_*: transforms.py:165-190
+        if self.consistent:
+            return np.array([random.uniform(rng[0], rng[1])] * N)
+        return np.random.uniform(rng[0], rng[1], size=(N,))
+
+    def __call__(self, st):
+        if random.random() < self.p:
+            todo = []                                       # get_params: the list is shuffled BEFORE any factor is drawn
+            if self.brightness is not None:
+                todo.append((AUG_BRIGHTNESS, self.brightness))
+            if self.contrast is not None:
+                todo.append((AUG_CONTRAST, self.contrast))
+            if self.saturation is not None:
+                todo.append((AUG_SATURATION, self.saturation))
+            random.shuffle(todo)
+            for code, rng in todo:
+                st.ops.append((code, self._draw(rng, st.N).astype(np.float32)))
+        return st
+
+
+class Compose(object):
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, st):
+        for t in self.transforms:
+            st = t(st)
+        return st
+
+
+class FrameBatch(object):
+    """Decoded uint8 frames + one augmentation row per output frame: what the backbones' ingest consumes in place of a
+    float clip tensor.  Quacks like the `[B, V, 3, T, H, W]` (or `[N, 3, T, H, W]`) tensor the models index."""
+
+    def __init__(self, frames, table, shape):
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+            raise ValueError('frames must be uint8 [n_src, Hs, Ws, 3]')
+        self.frames = frames.contiguous()
+        self.table = table                                   # uint8 device tensor [rows * 64], rows in clip-major order
+        self.shape = torch.Size(shape)
+        rows = 1
+        for d in self.shape[:-4]:
+            rows *= d
+        if table.numel() != rows * self.shape[-3] * AUG_ROW.itemsize:
+            raise ValueError('table has %d bytes, shape %s needs %d rows' % (table.numel(), tuple(shape), rows * self.shape[-3]))
+        self.is_cuda, self.device, self.dtype, self.requires_grad = frames.is_cuda, frames.device, torch.float32, False
+
+    @classmethod
+    def build(cls, frames, clips, transform, size, views=1, device=None):
+        """frames: uint8 [n_src, Hs, Ws, 3]; clips: per sample the source-frame indices of its T frames; every one of
+        the `views` views of a sample draws its own augmentation (pretrain's two clips of a video)."""
+        Hs, Ws = frames.shape[1:3]
+        rows = []
+        for src in clips:
+            for _ in range(views):
+                rows.append(transform(ClipState(src, Hs, Ws)).rows(*size))
+        T = len(clips[0])
+        tab = np.concatenate(rows)
+        device = device if device is not None else frames.device
+        t = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
+        shape = (len(clips), views, 3, T) + tuple(size) if views > 1 else (len(clips), 3, T) + tuple(size)
+        return cls(frames.to(device), t, shape)
+
+    def dim(self):
+        return len(self.shape)
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
+    def contiguous(self):
+        return self
+
+    def float(self):
+        return self
+
+    def _flat(self):
+        s = self.shape
+        n = 1
+        for d in s[:-4]:
+            n *= d
+        return FrameBatch(self.frames, self.table, (n,) + tuple(s[-4:]))
+
+    def reshape(self, *shape):
+        shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        if len(shape) == 5 and shape[0] == -1 and tuple(shape[1:]) == tuple(self.shape[-4:]):
+            return self._flat()
+        if tuple(shape) == tuple(self.shape):
+            return self
+        raise NotImplementedError('FrameBatch only flattens its leading dimensions')
+
+    view = reshape
+
+    def __getitem__(self, idx):
+        # block[:, v]: one view of every sample
+        if isinstance(idx, tuple) and len(idx) == 2 and idx[0] == slice(None) and isinstance(idx[1], int) and self.dim() == 6:
+            B, V, _, T = self.shape[:4]
+            rb = T * AUG_ROW.itemsize
+            t = self.table.view(B, V, rb)[:, idx[1]].contiguous().view(-1)
+            return FrameBatch(self.frames, t, (B,) + tuple(self.shape[2:]))
+        raise NotImplementedError('FrameBatch supports block[:, v] only')

@@ -133,6 +133,30 @@ int dv_ingest_ncdhw_pad(int32_t dtype, const float* x, void* y, int32_t N, int32
 /* p[r][col0 .. col0+ncols) = value for r < rows (row pitch `pitch` floats) */
 int dv_fill_cols_f32(float* p, int64_t rows, int32_t pitch, int32_t col0, int32_t ncols, float value, void* stream);
 
+/* Augmenting ingest (replaces the CPU PIL/DataLoader pipeline of pretrain.py:491-564 with the
+ * reference's own tensor-side definitions, utils/transforms.py:13-63,66-78,90-163,201-312): decoded uint8 frames
+ * [n_src][Hs][Ws][3] -> for every output frame f = n*T + t one table row: source frame, crop window (resized to H x W
+ * with bilinear / align_corners=False when its size differs), horizontal flip, then up to four colour ops in table
+ * order on [0,1] floats -- brightness / contrast / saturation `clamp(f*x + (1-f)*ref)` with ref = 0 / mean luma of the
+ * frame at that point / luma of the pixel, or grayscale (x = luma) -- then Normalize, and the NDHWC store of
+ * dv_ingest_ncdhw_pad (4th channel zero, optional zero border, optional segment shuffle of table rows).
+ * `table` and `perm` are DEVICE arrays; indices and windows are clamped into the source, so a bad row cannot fault.
+ * At most one contrast op per frame.  scratch: N*T floats (mean luma in front of the contrast op).  Two launches. */
+enum { DV_AUG_NONE = 0, DV_AUG_BRIGHTNESS = 1, DV_AUG_CONTRAST = 2, DV_AUG_SATURATION = 3, DV_AUG_GRAY = 4 };
+typedef struct dv_aug_frame {
+  int32_t src;                     /* index of the source frame */
+  int32_t crop_i, crop_j;          /* top-left corner of the window in the source frame */
+  int32_t crop_h, crop_w;          /* its size; == (H, W): plain crop, else bilinear resize to H x W */
+  int32_t flip;                    /* 1: horizontal flip of the window */
+  int32_t op[4];                   /* DV_AUG_*, applied in this order */
+  float factor[4];                 /* blend ratio of op[k] (unused for DV_AUG_GRAY / DV_AUG_NONE) */
+  int32_t _pad[2];                 /* 64 bytes per row */
+} dv_aug_frame;
+int dv_augment_ingest(int32_t dtype, const uint8_t* frames, int32_t n_src, int32_t Hs, int32_t Ws,
+                      const dv_aug_frame* table, int32_t N, int32_t T, int32_t H, int32_t W, void* y, int32_t ldy,
+                      int32_t pad, const float* mean3, const float* istd3, const int32_t* perm, int32_t n_seg,
+                      float* scratch, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * BatchNorm3d, training mode (nn.BatchNorm3d at s3dg.py:16,46-47, r21d.py:56,99,106,111,228, ...;
  * SyncBatchNorm math torch/nn/modules/_functions.py:39-200).

@@ -363,10 +363,107 @@ def case_losses():
     np.savez_compressed(os.path.join(GOLD, 'losses.npz'), **rec)
 
 
+def _aug_frames(n_src=12, Hs=20, Ws=26):
+    r = np.random.RandomState(4242)
+    yy, xx = np.mgrid[0:Hs, 0:Ws]
+    base = np.stack([(np.sin(yy / 3.0 + k) * np.cos(xx / 4.0 - k) * 0.5 + 0.5) for k in range(3)], -1)     # smooth structure
+    fr = base[None] * r.uniform(0.3, 1.0, size=(n_src, 1, 1, 3)) + r.uniform(-0.15, 0.15, size=(n_src, Hs, Ws, 3))
+    return (fr.clip(0, 1) * 255).round().astype(np.uint8)
+
+
+def _ref_apply(RT, frames, src, win, out_hw, flip, ops_, mean, std):
+    """the reference's own functions (utils/transforms.py) on the clip `src`; ops_ = [(code, factors[N])]"""
+    from oracle import augment_ref as A
+    vid = RT.to_normalized_float_tensor(torch.from_numpy(frames[src]))                  # [N, H, W, C] -> [C, N, H, W]
+    i, j, h, w = win
+    vid = RT.crop(vid, i, j, h, w)
+    if (h, w) != tuple(out_hw):
+        vid = RT.resize(vid, tuple(out_hw))
+    if flip:
+        vid = RT.hflip(vid)
+    for code, fac in ops_:
+        f = torch.from_numpy(np.asarray(fac, dtype=np.float64))
+        if code == A.BRIGHTNESS:
+            vid = RT.adjust_brightness(vid, f, 1)
+        elif code == A.CONTRAST:
+            vid = RT.adjust_contrast(vid, f, 1, 0)
+        elif code == A.SATURATION:
+            vid = RT.adjust_saturation(vid, f, 1, 0)
+        elif code == A.GRAY:
+            # random_grayscale :80-88 with its luma taken over the colour axis (as written it indexes the frame axis and
+            # asserts unless the clip has exactly 3 frames): gray * mask + vid * (1 - mask)
+            m = torch.tensor(np.asarray(fac, dtype=np.float32)).view(1, -1, 1, 1)
+            vid = RT.rgb_to_grayscale(vid, 0).unsqueeze(0) * m + vid * (1 - m)
+    return RT.normalize(vid, mean, std, channel=0).permute(1, 0, 2, 3).contiguous()      # -> [N, C, H, W]
+
+
+def case_augment(ref):
+    """the augmenting ingest against the reference's tensor-side transforms.  (A) explicit
+    parameter rows through every op / order / resize / flip; (B) seeded pipelines: RandomCrop / RandomSizedCrop /
+    RandomHorizontalFlip / random_adjust_* consume `random` and `numpy.random` -- the build's parameter classes must
+    reproduce the outputs from the same seeds.  (ColorJitter.__call__ itself needs torchvision's Lambda/Compose,
+    absent here: its shuffle-then-draw order is restated, not pinned.)"""
+    import random
+    from oracle import augment_ref as A
+    RT = ref.transforms
+    frames = _aug_frames()
+    H = W = 16
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    rec = {'frames': frames, 'mean': np.float32(mean), 'std': np.float32(std), 'HW': np.int32([H, W])}
+    B, C_, S, G = A.BRIGHTNESS, A.CONTRAST, A.SATURATION, A.GRAY
+    clips = [                                                       # (src frames, window, flip, [(op, factors)])
+        ([0, 1, 2], (2, 5, 16, 16), 0, []),
+        ([3, 4, 5], (4, 10, 16, 16), 1, [(B, [0.2, 1.0, 1.8])]),
+        ([6, 7, 8], (0, 0, 16, 16), 0, [(C_, [0.2, 1.3, 1.8])]),
+        ([9, 10, 11], (3, 3, 16, 16), 1, [(S, [0.0, 0.6, 1.8])]),
+        ([0, 4, 8], (1, 2, 16, 16), 0, [(G, [1, 0, 1])]),
+        ([1, 5, 9], (0, 0, 20, 26), 0, [(B, [1.5, 0.7, 1.1]), (C_, [0.5, 1.6, 1.0]), (S, [1.7, 0.3, 1.2])]),
+        ([2, 6, 10], (2, 1, 13, 22), 1, [(S, [1.7, 0.3, 1.2]), (B, [1.5, 0.7, 1.1]), (C_, [0.5, 1.6, 1.0]), (G, [0, 1, 1])]),
+        ([3, 7, 11], (5, 7, 11, 9), 0, [(C_, [1.8, 1.8, 0.1]), (G, [1, 1, 0]), (B, [1.2, 0.4, 1.0])]),
+    ]
+    rows, want = [], []
+    for src, win, flip, ops_ in clips:
+        t = np.zeros(len(src), dtype=A.ROW)
+        t['src'], t['flip'] = src, flip
+        t['crop_i'], t['crop_j'], t['crop_h'], t['crop_w'] = win
+        for n in range(len(src)):
+            k = 0
+            for code, fac in ops_:
+                if code == G and not fac[n]:
+                    continue
+                t['op'][n, k], t['factor'][n, k] = code, fac[n]
+                k += 1
+        rows.append(t)
+        want.append(_ref_apply(RT, frames, src, win, (H, W), flip, ops_, mean, std))
+    table = np.concatenate(rows)
+    want = torch.stack(want)                                                                   # [clips, T, 3, H, W]
+    got = A.augment_ingest(frames, table, len(clips), 3, H, W, mean, std).permute(0, 2, 1, 3, 4)
+    err = float((got - want).abs().max())
+    print('augment explicit rows: oracle-vs-reference', err)
+    assert err < 2e-6, err
+    rec['A/table'], rec['A/want'] = table.view(np.uint8).reshape(-1, 64), want.numpy()
+    # (B) seeded pipelines
+    for tag, sized, consistent in (('crop', False, False), ('sized', True, False), ('sized_consistent', True, True)):
+        outs = []
+        for seed in (1, 2, 3, 4):
+            random.seed(seed)
+            np.random.seed(seed)
+            src = [(seed + k) % 12 for k in range(4)]
+            vid = RT.to_normalized_float_tensor(torch.from_numpy(frames[src]))
+            vid = (RT.RandomSizedCrop((H, W)) if sized else RT.RandomCrop((H, W)))(vid)
+            vid = RT.RandomHorizontalFlip()(vid)
+            vid = RT.random_adjust_saturation(vid, [0.2, 1.8], consistent, 1, 0)
+            vid = RT.random_adjust_brightness(vid, [0.2, 1.8], consistent, 1)
+            vid = RT.random_adjust_contrast(vid, [0.2, 1.8], consistent, 1, 0)
+            outs.append(RT.normalize(vid, mean, std, channel=0).permute(1, 0, 2, 3).float())
+        rec['B/%s' % tag] = torch.stack(outs).numpy()                                          # [4 seeds, T=4, 3, H, W]
+    np.savez_compressed(os.path.join(GOLD, 'augment.npz'), **rec)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['backbones', 'models', 'losses', 'eval', 'clf', 'extra']
+    which = sys.argv[1:] or ['backbones', 'models', 'losses', 'eval', 'clf', 'extra', 'augment']
     if 'losses' in which:
         case_losses()
     ref = harness.load_reference()
@@ -378,6 +475,8 @@ def main():
         case_classifier_train(ref)
     if 'extra' in which:
         case_backbones_extra(ref)
+    if 'augment' in which:
+        case_augment(ref)
     if 'models' in which:
         case_models(ref)
 

@@ -51,6 +51,7 @@ def load_reference():
     import backbone.resnet_2d3d as R
     import utils.utils as U
     import model.classifier as CL
+    import utils.transforms as RT                                         # tensor-side transforms (functions need no torchvision)
     S.SimCLR_TimeSeriesV4.calc_contrast_loss = S.SimCLR_TimeSeriesV4.calc_clip_contrast_loss   # D1
     M.MoCo_TimeSeriesV4.calc_contrast_loss = M.MoCo_TimeSeriesV4.calc_clip_contrast_loss       # D1
 
@@ -68,4 +69,4 @@ def load_reference():
         return CL.LinearClassifier(network=network, **kw)
 
     return types.SimpleNamespace(simclr=S, moco=M, select_backbone=select_backbone, utils=U, r50=r50,
-                                 linear_classifier=linear_classifier)
+                                 linear_classifier=linear_classifier, transforms=RT)

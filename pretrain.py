@@ -8,7 +8,9 @@ the per-head loss / top-1 meters.  One process per GPU (torch.distributed, backe
 
 What differs, deliberately:
   * data: `--dataset synthetic` (the metric's workload; the JPEG/LMDB loaders of dataset/local_dataset.py and the
-    PIL augmentations are the CPU data pipeline, out of scope -- SURVEY.md 2.1 rows 13-14);
+    PIL augmentations are the CPU data pipeline, out of scope -- SURVEY.md 2.1 rows 13-14); `--dataset
+    synthetic-frames` feeds decoded uint8 128x171 frames and augments them ON THE GPU inside the ingest kernel
+    (crop / flip / colour jitter / grayscale of utils/transforms.py, dualvar_amd.utils.transforms.FrameBatch);
   * Normalize (utils/transforms.py) is fused into the ingest kernel instead of a separate GPU pass;
   * SyncBatchNorm / DDP are the engine's own collectives (dualvar_amd/parallel.py), not module wrappers;
   * accuracy meters read the positive's rank emitted by the loss kernels (no topk launch, no extra sync):
@@ -127,6 +129,33 @@ class SyntheticClips(torch.utils.data.Dataset):
         return {'seq': torch.rand(self.shape, generator=g)}
 
 
+class SyntheticFrames(torch.utils.data.Dataset):
+    """batch['frames']: what a video decoder hands over -- uint8 [seq_len, 128, 171, 3] (A.Scale((128, 171)) of
+    pretrain.py:494); every view of the sample is cut from these frames by the augmenting ingest."""
+
+    def __init__(self, args, length):
+        self.shape, self.length, self.seed = (args.seq_len, 128, 171, 3), length, args.seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        return {'frames': torch.randint(0, 256, self.shape, generator=g, dtype=torch.uint8)}
+
+
+def gpu_transform(args):
+    """the base transform of pretrain.py:500-509 in its tensor-side form (utils/transforms.py): random crop, optional
+    flip, colour jitter 0.8 / 0.8 / 0.8 with p = 0.8 (temporally consistent under --aug_temp_consist); hue and the PIL
+    Gaussian blur have no tensor-side definition in the reference and are not applied"""
+    from dualvar_amd.utils import transforms as T
+    steps = [T.RandomCrop((args.img_dim, args.img_dim))]
+    if args.rand_flip:
+        steps.append(T.RandomHorizontalFlip())
+    steps.append(T.ColorJitter(0.8, 0.8, 0.8, consistent=args.aug_temp_consist, p=0.8 * 0.8))
+    return T.Compose(steps)
+
+
 def main(args):
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
@@ -180,7 +209,8 @@ def main_worker(gpu, ngpus_per_node, args):
     optimizer = SGD(params, lr=args.lr, weight_decay=args.wd, momentum=0.9, stores=model.stores(), grad_sync=gsync)
 
     per_rank = max(args.epoch_size // max(args.world_size, 1), args.batch_size)
-    dataset = SyntheticClips(args, per_rank * max(args.world_size, 1))
+    dataset = (SyntheticFrames if args.dataset == 'synthetic-frames' else SyntheticClips)(args, per_rank * max(args.world_size, 1))
+    args.gpu_transform = gpu_transform(args) if args.dataset == 'synthetic-frames' else None
     sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=True) if args.distributed else None
     loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
                                          num_workers=min(args.workers, 4), pin_memory=True, drop_last=True)
@@ -240,7 +270,14 @@ def train_one_epoch(data_loader, model, optimizer, scheduler, transforms_cuda, e
     clips = 0
     for idx, batch in enumerate(data_loader):
         data_time.update(time.time() - end)
-        input_seq = tr(batch['seq'].cuda(args.gpu, non_blocking=True))
+        if 'frames' in batch:        # decoded frames: every view is augmented inside the ingest kernel
+            from dualvar_amd.utils.transforms import FrameBatch
+            fr = batch['frames'].cuda(args.gpu, non_blocking=True)                       # [B, L, Hs, Ws, 3] uint8
+            L_ = fr.size(1)
+            input_seq = FrameBatch.build(fr.view(-1, *fr.shape[2:]), [list(range(b * L_, b * L_ + args.seq_len)) for b in range(fr.size(0))],
+                                         args.gpu_transform, (args.img_dim, args.img_dim), views=nv)
+        else:
+            input_seq = tr(batch['seq'].cuda(args.gpu, non_blocking=True))
         B = input_seq.size(0)
         ret = model(input_seq)
         loss = 0

@@ -263,6 +263,61 @@ def test_multi_clip_test_against_reference_fixture(gpu):
         E.clips_from_sequence(seq, 3, T)
 
 
+def test_frame_batch_through_backbone_and_model(gpu):
+    """uint8 frames + augmentation table in place of the float clip tensor: the backbone and
+    SimCLR_Naked give what they give on the oracle-augmented float clips"""
+    import random
+    from dualvar_amd.backbone import select_backbone
+    from dualvar_amd.model import SimCLR_Naked
+    from dualvar_amd.utils import transforms as T
+    from oracle import augment_ref as A
+    P = _P()
+    r = np.random.RandomState(5)
+    frames = r.randint(0, 256, size=(16, 72, 96, 3)).astype(np.uint8)
+    random.seed(3)
+    np.random.seed(3)
+    tr = T.Compose([T.RandomSizedCrop((64, 64)), T.RandomHorizontalFlip(), T.ColorJitter(0.8, 0.8, 0.8, p=0.8), T.RandomGray(0.2)])
+    clips = [[0, 1, 2, 3, 4, 5, 6, 7], [8, 9, 10, 11, 12, 13, 14, 15], [4, 5, 6, 7, 8, 9, 10, 11], [1, 3, 5, 7, 9, 11, 13, 15]]
+    fb = T.FrameBatch.build(torch.from_numpy(frames), clips, tr, (64, 64), views=2, device=gpu)
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    table = np.frombuffer(fb.table.cpu().numpy().tobytes(), dtype=A.ROW)
+    block = A.augment_ingest(frames, table, 8, 8, 64, 64, mean, std).view(4, 2, 3, 8, 64, 64).to(gpu)
+    m, _ = select_backbone('s3dg')
+    P.procedural_init(m)
+    m.set_compute_dtype('fp32').train().to(gpu)
+    m.set_input_normalization(mean, std)
+    with torch.no_grad():
+        a = m.forward_pooled(fb.reshape(-1, 3, 8, 64, 64))
+    m.set_input_normalization(None, None)
+    with torch.no_grad():
+        b = m.forward_pooled(block.view(-1, 3, 8, 64, 64))
+    e = rel_err(a.cpu().numpy(), b.cpu().numpy())
+    print(f'frame batch vs float clips through s3dg: rel err {e:.2e}')
+    assert e < 2e-4
+    # the whole objective, with gradients: against float clips holding exactly the kernel's output (the stem input is
+    # then bit-identical, so only the order of the fp32 atomics in the weight gradients differs)
+    from dualvar_amd import ops
+    from dualvar_amd.ops import DV_F32
+    act = ops.new_act(8, 8, 64, 64, 3, DV_F32, gpu, cpitch=4, zero=True)
+    ops.call('dv_augment_ingest', DV_F32, fb.frames, 16, 72, 96, fb.table, 8, 8, 64, 64, act, 4, 0, torch.tensor(mean).to(gpu),
+             (1 / torch.tensor(std)).to(gpu), None, 0, torch.empty(64, device=gpu))
+    block = ops.act_to_ncdhw(act).view(4, 2, 3, 8, 64, 64).contiguous()
+    losses = []
+    for inp, norm in ((fb, (mean, std)), (block, (None, None))):
+        torch.manual_seed(0)
+        sm = SimCLR_Naked('s3dg', 128, 0.07, False)
+        P.procedural_init(sm)
+        sm.set_compute_dtype('fp32').train().to(gpu)
+        sm.encoder_q[0].set_input_normalization(*norm)
+        ret = sm(inp)
+        loss = total_loss(ret)
+        loss.backward()
+        losses.append((float(loss), grad_summary(sm, P)))
+    assert abs(losses[0][0] - losses[1][0]) < 1e-6 * abs(losses[1][0]), losses
+    for k in losses[0][1]:
+        assert abs(losses[0][1][k][0] - losses[1][1][k][0]) <= 1e-4 * abs(losses[1][1][k][0]) + 1e-7, k
+
+
 @pytest.mark.parametrize('mode,kw', [('ft', dict(use_dropout=False)),
                                      ('last', dict(use_dropout=True, use_l2_norm=True, use_final_bn=True))])
 def test_classifier_finetune_steps_against_reference_fixture(gpu, mode, kw):

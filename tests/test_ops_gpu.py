@@ -172,6 +172,77 @@ def test_ingest(gpu, dtype):
     close(ops.act_to_ncdhw(a2), q(ref2, dtype), dtype, 'ingest perm', factor=0.5 if dtype == DV_BF16 else 1)
 
 
+def _augment(gpu, dtype, frames, table, N, T, H, W, mean, std, perm=None, pad=0):
+    from dualvar_amd.utils.transforms import AUG_ROW
+    assert table.dtype == AUG_ROW
+    a = ops.new_act(N, T, H + 2 * pad, W + 2 * pad, 3, dtype, gpu, cpitch=4, zero=True)
+    fr = torch.from_numpy(np.ascontiguousarray(frames)).to(gpu)
+    tb = torch.from_numpy(table.view(np.uint8).copy()).to(gpu)
+    scratch = torch.full((N * T,), float('nan'), device=gpu)
+    ops.call('dv_augment_ingest', dtype, fr, fr.shape[0], fr.shape[1], fr.shape[2], tb, N, T, H, W, a, 4, pad,
+             torch.tensor(mean).to(gpu), (1 / torch.tensor(std)).to(gpu), None if perm is None else perm.to(gpu),
+             0 if perm is None else perm.shape[1], scratch)
+    y = ops.act_to_ncdhw(a)                                                        # [N, 3, T, H + 2 pad, W + 2 pad]
+    if pad:
+        inner = y[:, :, :, pad:-pad, pad:-pad]
+        assert float(y.abs().sum() - inner.abs().sum()) == 0.0                     # the border stays zero
+        y = inner
+    assert float(a.buf[:, 3].abs().max()) == 0.0
+    return y
+
+
+@pytest.mark.parametrize('dtype,pad', [(DV_F32, 0), (DV_F32, 3), (DV_BF16, 3)])
+def test_augment_ingest_against_reference_fixture(gpu, dtype, pad):
+    """dv_augment_ingest == the reference's utils/transforms.py functions on the fixture rows (every op, order, resize,
+    flip; tests/golden/augment.npz): crop / hflip / resize / adjust_* / rgb_to_grayscale / normalize"""
+    from tests.util import gold
+    from dualvar_amd.utils.transforms import AUG_ROW
+    g = gold('augment')
+    H, W = (int(v) for v in g['HW'])
+    table = np.ascontiguousarray(g['A/table']).view(AUG_ROW).reshape(-1)
+    want = torch.from_numpy(g['A/want']).permute(0, 2, 1, 3, 4)                    # [clips, 3, T, H, W]
+    got = _augment(gpu, dtype, g['frames'], table, want.shape[0], want.shape[2], H, W, g['mean'].tolist(), g['std'].tolist(),
+                   pad=pad).cpu()
+    err = float((got - want).abs().max())
+    print(f'augment ingest vs reference: max abs err {err:.2e} (values up to {float(want.abs().max()):.2f})')
+    assert err < (2e-5 if dtype == DV_F32 else 2e-2)
+
+
+def test_augment_ingest_full_size_rows_against_oracle(gpu):
+    """128x171 decoded frames -> 112x112 windows (plain and resized crops, flips, all colour-op orders, segment
+    shuffle) at the bench's frame size, against oracle/augment_ref.py"""
+    from oracle import augment_ref as A
+    r = np.random.RandomState(11)
+    n_src, Hs, Ws, N, T, H, W = 10, 128, 171, 3, 8, 112, 112
+    yy, xx = np.mgrid[0:Hs, 0:Ws]
+    frames = (((np.sin(yy / 9.0)[..., None] * np.cos(xx / 7.0)[..., None] * 0.4 + 0.5)[None] * r.uniform(0.4, 1, (n_src, 1, 1, 3))
+               + r.uniform(-0.2, 0.2, (n_src, Hs, Ws, 3))).clip(0, 1) * 255).round().astype(np.uint8)
+    table = np.zeros(N * T, dtype=A.ROW)
+    for f in range(N * T):
+        row = table[f]
+        row['src'] = r.randint(n_src)
+        if f % 3 == 0:
+            row['crop_h'], row['crop_w'] = H, W
+        else:
+            row['crop_h'], row['crop_w'] = r.randint(60, Hs + 1), r.randint(80, Ws + 1)
+        row['crop_i'], row['crop_j'] = r.randint(0, Hs - row['crop_h'] + 1), r.randint(0, Ws - row['crop_w'] + 1)
+        row['flip'] = r.randint(2)
+        codes = list(r.permutation([A.BRIGHTNESS, A.CONTRAST, A.SATURATION, A.GRAY]))[:r.randint(0, 5)]
+        for k, c in enumerate(codes):
+            row['op'][k], row['factor'][k] = c, 1.0 if c == A.GRAY else r.uniform(0.2, 1.8)
+    perm = torch.tensor([[1, 0], [0, 1], [1, 0]], dtype=torch.int32)
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    got = _augment(gpu, DV_F32, frames, table, N, T, H, W, mean, std, perm=perm, pad=3).cpu()
+    want = A.augment_ingest(frames, table, N, T, H, W, mean, std, perm=perm.numpy())
+    err = float((got - want).abs().max())
+    print(f'augment ingest 112x112 vs oracle: max abs err {err:.2e}')
+    assert err < 3e-5
+    # an out-of-range row is clamped into the source instead of faulting
+    bad = table.copy()
+    bad['src'][0], bad['crop_i'][1], bad['crop_h'][2] = 10 ** 6, -5, 10 ** 6
+    assert torch.isfinite(_augment(gpu, DV_F32, frames, bad, N, T, H, W, mean, std)).all()
+
+
 @pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
 @pytest.mark.parametrize('kt,st,pt', [(1, 1, 0), (3, 1, 1)])
 def test_rgb_stem_as_pixel_pair_conv(gpu, dtype, kt, st, pt):

@@ -130,3 +130,69 @@ def test_oracle_equals_live_reference():
         x = P.procedural_clips(2, 1, 8, 64, 64)[:, 0]
         with torch.no_grad():
             assert torch.equal(a(x), b(x))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# augmenting ingest: oracle/augment_ref.py and the build's parameter classes against the outputs of
+# the reference's own utils/transforms.py functions (tests/golden/augment.npz, oracle/gen_golden.py:case_augment)
+def test_augment_oracle_matches_reference_fixture():
+    from oracle import augment_ref as A
+    g = gold('augment')
+    H, W = (int(v) for v in g['HW'])
+    table = np.ascontiguousarray(g['A/table']).view(A.ROW).reshape(-1)
+    want = torch.from_numpy(g['A/want'])                                        # [clips, T, 3, H, W]
+    got = A.augment_ingest(g['frames'], table, want.shape[0], want.shape[1], H, W, g['mean'].tolist(), g['std'].tolist())
+    assert float((got.permute(0, 2, 1, 3, 4) - want).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize('tag,sized,consistent', [('crop', False, False), ('sized', True, False), ('sized_consistent', True, True)])
+def test_augment_parameter_classes_follow_reference_rng(tag, sized, consistent):
+    """same seeds -> same crops / flips / factors as the reference's RandomCrop, RandomSizedCrop, RandomHorizontalFlip and
+    random_adjust_* (which draw from `random` and `numpy.random`): the rows the build's classes fill, rendered by the
+    oracle, equal the reference's output tensors"""
+    import random
+    from dualvar_amd.utils import transforms as T
+    from oracle import augment_ref as A
+    assert T.AUG_ROW == A.ROW
+    g = gold('augment')
+    H, W = (int(v) for v in g['HW'])
+    frames = g['frames']
+    for k, seed in enumerate((1, 2, 3, 4)):
+        random.seed(seed)
+        np.random.seed(seed)
+        st = T.ClipState([(seed + i) % 12 for i in range(4)], frames.shape[1], frames.shape[2])
+        st = (T.RandomSizedCrop((H, W)) if sized else T.RandomCrop((H, W)))(st)
+        st = T.RandomHorizontalFlip()(st)
+        cj = T.ColorJitter(0.8, 0.8, 0.8, consistent=consistent)
+        for code, rng in ((T.AUG_SATURATION, cj.saturation), (T.AUG_BRIGHTNESS, cj.brightness), (T.AUG_CONTRAST, cj.contrast)):
+            st.ops.append((code, cj._draw(rng, st.N).astype(np.float32)))
+        got = A.augment_ingest(frames, st.rows(H, W), 1, 4, H, W, g['mean'].tolist(), g['std'].tolist())[0].permute(1, 0, 2, 3)
+        err = float((got - torch.from_numpy(g['B/' + tag][k])).abs().max())
+        assert err < 5e-6, (tag, seed, err)
+
+
+def test_color_jitter_and_frame_batch_host_logic():
+    import random
+    from dualvar_amd.utils import transforms as T
+    random.seed(7)
+    np.random.seed(7)
+    tr = T.Compose([T.RandomSizedCrop((16, 16)), T.RandomHorizontalFlip(), T.ColorJitter(0.8, 0.8, 0.8, p=1.0), T.RandomGray(0.5)])
+    fr = torch.zeros(12, 24, 32, 3, dtype=torch.uint8)
+    fb = T.FrameBatch.build(fr, [[0, 1, 2, 3], [4, 5, 6, 7]], tr, (16, 16), views=2)
+    assert tuple(fb.shape) == (2, 2, 3, 4, 16, 16) and fb.dim() == 6
+    flat = fb.reshape(-1, *fb.shape[2:])
+    assert tuple(flat.shape) == (4, 3, 4, 16, 16) and flat.table.data_ptr() == fb.table.data_ptr()
+    rows = np.frombuffer(fb.table.numpy().tobytes(), dtype=T.AUG_ROW)
+    assert rows.shape == (16,) and list(rows['src'][:8]) == [0, 1, 2, 3, 0, 1, 2, 3]
+    for r in rows:
+        ops_ = [int(o) for o in r['op'] if o]
+        assert sorted(o for o in ops_ if o != T.AUG_GRAY) == [1, 2, 3]          # every jitter op once, in a shuffled order
+        assert all(0.2 <= f <= 1.8 for o, f in zip(r['op'], r['factor']) if o in (1, 2, 3))
+        assert 0 <= r['crop_i'] and r['crop_i'] + r['crop_h'] <= 24 and r['crop_j'] + r['crop_w'] <= 32
+    v1 = fb[:, 1]
+    assert tuple(v1.shape) == (2, 3, 4, 16, 16)
+    assert np.array_equal(np.frombuffer(v1.table.numpy().tobytes(), dtype=T.AUG_ROW), np.concatenate([rows[4:8], rows[12:16]]))
+    with pytest.raises(ValueError):
+        T.Compose([T.ColorJitter(0.5, 0, 0), T.RandomCrop((8, 8))])(T.ClipState([0], 24, 32))
+    with pytest.raises(ValueError):
+        T.ClipState([0], 24, 32).rows(16, 16)
