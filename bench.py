@@ -284,7 +284,7 @@ def main():
             'roofline': roof,
             'kernel_time_ms_per_step': {k: round(v[1], 3) for k, v in sorted(csum.items(), key=lambda kv: -kv[1][1])[:12]},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the host-core baseline is reported at N=1 only
             out['cpu_baseline'] = cpu_baseline(args, V)
         print(json.dumps(out))
     if distributed:
