@@ -158,11 +158,13 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    distributed = world > 1
+    # DUALVAR_FORCE_EXCHANGE=1: rehearse the multi-GPU step (every RCCL collective issued) with one rank on a 1-GPU box
+    distributed = world > 1 or os.environ.get('DUALVAR_FORCE_EXCHANGE') == '1'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from dualvar_amd.optim import SGD

@@ -296,8 +296,13 @@ class Comm:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # `exchange`: take the multi-rank code path.  DUALVAR_FORCE_EXCHANGE=1 takes it with ONE rank too: the only way
+        # to run the RCCL calls (stream semantics, flat gather, async handles) on a single-GPU box, where two ranks
+        # cannot share the device (tests/test_distributed_gpu.py::test_rccl_single_rank_rehearsal)
+        self.exchange = self.world > 1 or (os.environ.get('DUALVAR_FORCE_EXCHANGE') == '1' and dist.is_available()
+                                           and dist.is_initialized())
         # RCCL gathers straight into one flat tensor; gloo (the CPU / single-GPU tests) only has the list form
-        self.flat_gather = self.world > 1 and dist.get_backend(group) == 'nccl'
+        self.flat_gather = self.exchange and dist.get_backend(group) == 'nccl'
 
 
 class Launch:
@@ -679,7 +684,7 @@ class BNGroupOp(Op):
         R = plan.comm.world
         self.width = sum(m.width for m in self.members)
         self.local = plan.f32(self.width)
-        self.gathered = plan.f32(R, self.width) if R > 1 else self.local
+        self.gathered = plan.f32(R, self.width) if plan.comm.exchange else self.local
         off = 0
         for m in self.members:
             m.loff = off
@@ -733,7 +738,7 @@ class BNGroupOp(Op):
 
         def tot(lst, attr):
             return sum(getattr(l, attr) for l in lst)
-        f_red = [Launch('bn_stats_multi', 'bn_stats_multi', lib.dv_bn_stats_multi, (tab, n, 1 if R == 1 else 0, ends[0]),
+        f_red = [Launch('bn_stats_multi', 'bn_stats_multi', lib.dv_bn_stats_multi, (tab, n, 0 if p.comm.exchange else 1, ends[0]),
                         tot(f_red, 'bytes'))]
         f_app = [Launch('bn_apply_multi', 'bn_apply_multi<%s>' % dt, lib.dv_bn_apply_multi, (p.dtype, tab, n, ends[1]),
                         tot(f_app, 'bytes'))]
@@ -785,7 +790,7 @@ class BNGroupOp(Op):
             coff = x.off - m.conv.y.off
             spitch = m.conv.slot.Cout
             sptr = m.conv.stats.data_ptr() + 4 * coff * m.conv.tiles        # partials are [2][Cout][tiles]
-            if R == 1:
+            if not p.comm.exchange:
                 f_red.append(Launch('bn_stats_finalize', 'bn_reduce_stats', lib.dv_bn_stats_finalize,
                                     (sptr, m.conv.tiles, m.conv.tile_rows, spitch, M, Cn, local, st.w_master(gs), st.w_master(bs),
                                      eps, mom, rm, rv) + outs, m.conv.tiles * 2 * Cn * 4))
@@ -826,7 +831,7 @@ class BNGroupOp(Op):
                 f_red, f_app = f1, a1        # a lone (large) layer keeps the single-tensor forward kernels (1024-thread stats)
         f = list(f_red)
         b = list(b_red)
-        if R > 1:
+        if p.comm.exchange:
             local, gathered, group = self.local, self.gathered, p.comm.group
             if p.comm.flat_gather:
                 f.append(HostStep('syncbn_allgather', lambda: dist.all_gather_into_tensor(gathered, local, group=group)))

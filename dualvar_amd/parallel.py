@@ -13,6 +13,8 @@ SURVEY 2.2 C1-C6) is here:
   * C5/C6 feature gather   -> utils.GatherLayer
 The host logic is device-agnostic so the world_size-2 tests run it on gloo/CPU tensors.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -51,13 +53,16 @@ class GradSync:
         self.group = group
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.rank, self.world = world_info(group)
+        # one rank + DUALVAR_FORCE_EXCHANGE=1: still issue the collectives (RCCL rehearsal on a single-GPU box, see engine.Comm)
+        self.exchange = self.world > 1 or (os.environ.get('DUALVAR_FORCE_EXCHANGE') == '1' and dist.is_available()
+                                           and dist.is_initialized())
         self.side_stream = side_stream
         self._stream = None
         self._works = {}             # id(flat) -> {bucket start: work handle} for the step in flight
 
     # ---- overlap with backward
     def attach(self, model):
-        if self.world == 1 or not getattr(model, 'single_backward_pass', False):
+        if not self.exchange or not getattr(model, 'single_backward_pass', False):
             return False
         for m in model.modules():
             if hasattr(m, '_plans') and hasattr(m, 'grad_ready'):
@@ -93,7 +98,7 @@ class GradSync:
 
     # ---- the reduction proper (optimizer step)
     def reduce_flat(self, flat):
-        if self.world == 1:
+        if not self.exchange:
             return 1.0
         works = self._works.pop(id(flat), {})
         with self._comm_stream(flat):

@@ -142,3 +142,106 @@ def test_two_ranks_equal_one_process(gpu, kind):
         # single-process run; at B=4 the BatchNorm backward amplifies that to ~1e-3..1e-2 in individual tensors
         # (identical tile shapes gave 6.5e-6).  The exact identities are the two asserts inside the loop.
         assert worst < 3e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# RCCL rehearsal: two ranks cannot share the one GPU of the test box under RCCL, so the backend="nccl" code path (flat
+# all_gather_into_tensor, async all-reduce handles, collectives enqueued from the side stream) is run with ONE rank and
+# DUALVAR_FORCE_EXCHANGE=1, which makes the engine and GradSync issue every collective of the multi-GPU step anyway.
+# With one rank the exchanged statistics equal the local ones, so the step must reproduce the plain single-process step.
+def _rccl_worker(port, kind, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DUALVAR_FORCE_EXCHANGE='1')
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda:0')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        from dualvar_amd import model as M
+        from dualvar_amd.optim import SGD
+        from dualvar_amd.parallel import GradSync
+        from oracle import procedural as P
+        m = getattr(M, kind)(NET, 128, 0.07, True)
+        P.procedural_init(m)
+        m.set_compute_dtype('fp32').train().to(dev)
+        sync = GradSync(bucket_mb=1)
+        attached = sync.attach(m)
+        assert attached == kind.endswith('Naked')
+        opt = SGD([p for p in m.parameters() if p.requires_grad], lr=0.01, momentum=0.9, weight_decay=1e-4, stores=m.stores(),
+                  grad_sync=sync)
+        V = 2 if kind.endswith('Naked') else 3
+        block = P.procedural_clips(B, V, T, H, H).to(dev)
+        losses = []
+        for _ in range(2):
+            np.random.seed(1234)
+            ret = m(block)
+            loss = ret['clip_contrast_loss']
+            for k in ret:
+                if 'loss' in k and 'clip' not in k:
+                    loss = loss + ret[k]
+            opt.zero_grad()
+            loss.backward()
+            early = len(sync._works.get(id(m.store.grad), {}))
+            opt.step()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        from dualvar_amd.engine import Comm
+        assert Comm().exchange and Comm().flat_gather
+        q.put((losses, early, {k: v.detach().float().cpu().numpy() for k, v in m.state_dict().items() if v.dtype.is_floating_point}))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind', ['SimCLR_Naked', 'SimCLR_TimeSeriesV4'])
+def test_rccl_single_rank_rehearsal(gpu, kind):
+    from dualvar_amd import model as M
+    from dualvar_amd.optim import SGD
+    from oracle import procedural as P
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    proc = ctx.Process(target=_rccl_worker, args=(29911 + (os.getpid() % 200), kind, q))
+    proc.start()
+    import queue
+    import time
+    deadline, got = time.time() + 300, None
+    while got is None:
+        try:
+            got = q.get(timeout=2)
+        except queue.Empty:
+            if proc.exitcode not in (None, 0) or time.time() > deadline:
+                if proc.is_alive():
+                    proc.kill()
+                pytest.fail('RCCL rehearsal process died or timed out (exit code %s)' % proc.exitcode)
+    proc.join(timeout=120)
+    assert proc.exitcode == 0
+    losses, early, params = got
+    if kind.endswith('Naked'):
+        assert early >= 2, 'no gradient bucket was all-reduced from inside the backward pass'
+
+    m = getattr(M, kind)(NET, 128, 0.07, False)
+    P.procedural_init(m)
+    m.set_compute_dtype('fp32').train().to(gpu)
+    opt = SGD([p for p in m.parameters() if p.requires_grad], lr=0.01, momentum=0.9, weight_decay=1e-4, stores=m.stores())
+    V = 2 if kind.endswith('Naked') else 3
+    block = P.procedural_clips(B, V, T, H, H).to(gpu)
+    want = []
+    for _ in range(2):
+        np.random.seed(1234)
+        ret = m(block)
+        loss = ret['clip_contrast_loss']
+        for k in ret:
+            if 'loss' in k and 'clip' not in k:
+                loss = loss + ret[k]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        want.append(float(loss))
+    print('RCCL single-rank rehearsal losses', losses, 'plain', want)
+    assert abs(losses[0] - want[0]) < 1e-5 * abs(want[0])
+    assert abs(losses[1] - want[1]) < 2e-3 * abs(want[1])              # after one SGD step (fp32-atomic order in the wgrads)
+    worst = 0.0
+    for k, v in m.state_dict().items():
+        if v.dtype.is_floating_point and 'num_batches' not in k:
+            ref = v.detach().float().cpu().numpy()
+            worst = max(worst, float(np.abs(params[k] - ref).max() / (np.abs(ref).max() + 1e-12)))
+    print('parameters after 2 steps: worst rel diff', worst)
+    assert worst < 2e-3
