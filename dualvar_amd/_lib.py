@@ -83,6 +83,7 @@ SIGNATURES = {
     'dv_bn_apply': [I32, P, I32, P, P, P, I32, P, I32, I64, I32, I32, P],
     'dv_bn_stats_multi': [P, I32, I32, I32, P],
     'dv_bn_apply_multi': [I32, P, I32, I32, P],
+    'dv_bn_finalize_multi': [P, I32, I32, P, P, I32, I32, P],
     'dv_bn_bwd_reduce_multi': [I32, P, I32, I32, P],
     'dv_bn_bwd_apply_multi': [I32, P, I32, I32, I32, P],
     'dv_bn_bwd_blocks': [I64, I32],

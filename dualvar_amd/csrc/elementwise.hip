@@ -161,6 +161,39 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int R, int s
   }
 }
 
+// the members of a group in ONE launch: item i's rows sit in the gathered [R][stride] table at the offset its
+// local_stats has inside the group's local row; 128 channels per block, blocks of item i follow those of item i-1
+__global__ void bn_finalize_multi_kernel(const dv_bn_item* __restrict__ items, int n, const float* __restrict__ local_base,
+                                         const float* __restrict__ gathered, int R, int stride) {
+  int bid = blockIdx.x, i = 0;
+  while (i < n - 1 && bid >= (items[i].C + 127) / 128) { bid -= (items[i].C + 127) / 128; ++i; }
+  const dv_bn_item& it = items[i];
+  const int c = bid * 128 + threadIdx.x, C = it.C;
+  if (c >= C) return;
+  const float* stats = gathered + (it.local_stats - local_base);
+  float cnt = 0.f, S = 0.f;
+  for (int r = 0; r < R; ++r) { cnt += stats[r * stride + 2 * C]; S += stats[r * stride + c]; }
+  const float mean = S / cnt;
+  float M2 = 0.f;
+  for (int r = 0; r < R; ++r) {
+    float n_r = stats[r * stride + 2 * C];
+    float d = stats[r * stride + c] / n_r - mean;
+    M2 += stats[r * stride + C + c] + n_r * d * d;
+  }
+  const float var = M2 / cnt;
+  const float invstd = rsqrtf(var + it.eps);
+  it.mean[c] = mean;
+  it.invstd[c] = invstd;
+  const float sc = it.gamma[c] * invstd;
+  it.scale[c] = sc;
+  it.shift[c] = it.beta[c] - mean * sc;
+  if (it.running_mean) {
+    it.running_mean[c] = (1.f - it.momentum) * it.running_mean[c] + it.momentum * mean;
+    const float unbiased = cnt > 1.f ? M2 / (cnt - 1.f) : var;
+    it.running_var[c] = (1.f - it.momentum) * it.running_var[c] + it.momentum * unbiased;
+  }
+}
+
 // ------------------------------------------------------------------ BN apply (+residual) (+ReLU)
 // i (vector index) -> (row, first channel) with one mulhi; parameters as 16-byte vector loads (the per-channel
 // arrays are padded to a multiple of 8 floats)
@@ -1008,6 +1041,13 @@ extern "C" int dv_bn_stats_finalize(const float* partials, int32_t n_tiles, int3
 extern "C" int dv_bn_stats_multi(const dv_bn_item* items, int32_t n, int32_t finalize, int32_t total_blocks, void* stream) {
   if (!items || n <= 0 || total_blocks <= 0) return DV_EINVAL;
   hipLaunchKernelGGL(bn_stats_multi_kernel, dim3(total_blocks), dim3(kThreads), 0, ST(stream), items, n, finalize);
+  return dv_launch_status();
+}
+extern "C" int dv_bn_finalize_multi(const dv_bn_item* items, int32_t n, int32_t total_blocks, const float* local_base,
+                                    const float* gathered, int32_t R, int32_t stride, void* stream) {
+  if (!items || n <= 0 || total_blocks <= 0 || !local_base || !gathered || R <= 0 || stride <= 0) return DV_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3(total_blocks), dim3(128), 0, ST(stream), items, n, local_base, gathered, R,
+                     stride);
   return dv_launch_status();
 }
 extern "C" int dv_bn_apply_multi(int32_t dtype, const dv_bn_item* items, int32_t n, int32_t total_blocks, void* stream) {

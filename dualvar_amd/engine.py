@@ -742,6 +742,10 @@ class BNGroupOp(Op):
                         tot(f_red, 'bytes'))]
         f_app = [Launch('bn_apply_multi', 'bn_apply_multi<%s>' % dt, lib.dv_bn_apply_multi, (p.dtype, tab, n, ends[1]),
                         tot(f_app, 'bytes'))]
+        # multi-rank step: ONE finalize launch for the group after the all-gather (instead of one per member)
+        self._fin_multi = Launch('bn_finalize_multi', 'bn_finalize_multi', lib.dv_bn_finalize_multi,
+                                 (tab, n, sum((m.C + 127) // 128 for m in self.members), self.local.data_ptr(),
+                                  self.gathered.data_ptr(), R, self.width))
         if p.with_grad:
             b_red = [Launch('bn_bwd_reduce_multi', 'bn_bwd_reduce_multi<%s>' % dt, lib.dv_bn_bwd_reduce_multi,
                             (p.dtype, tab, n, ends[2]), tot(b_red, 'bytes'))]
@@ -829,6 +833,8 @@ class BNGroupOp(Op):
             f_red, f_app, b_red, b_app = self._multi(R, f_red, f_app, b_red, b_app)
             if len(self.members) == 1:
                 f_red, f_app = f1, a1        # a lone (large) layer keeps the single-tensor forward kernels (1024-thread stats)
+            else:
+                f_fin = [self._fin_multi]
         f = list(f_red)
         b = list(b_red)
         if p.comm.exchange:

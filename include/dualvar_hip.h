@@ -223,6 +223,10 @@ typedef struct dv_bn_item {
   int32_t blk_stats, blk_apply, blk_red, blk_bapply;
 } dv_bn_item;
 int dv_bn_stats_multi(const dv_bn_item* items, int32_t n, int32_t finalize, int32_t total_blocks, void* stream);
+/* dv_bn_finalize for every member of the group in one launch (multi-rank step, after the all-gather): item i's rows of the
+ * gathered [R][stride] table start at the offset (items[i].local_stats - local_base); total_blocks = sum ceil(C_i / 128) */
+int dv_bn_finalize_multi(const dv_bn_item* items, int32_t n, int32_t total_blocks, const float* local_base,
+                         const float* gathered, int32_t R, int32_t stride, void* stream);
 int dv_bn_apply_multi(int32_t dtype, const dv_bn_item* items, int32_t n, int32_t total_blocks, void* stream);
 int dv_bn_bwd_reduce_multi(int32_t dtype, const dv_bn_item* items, int32_t n, int32_t total_blocks, void* stream);
 int dv_bn_bwd_apply_multi(int32_t dtype, const dv_bn_item* items, int32_t n, int32_t total_blocks, int32_t max_c,
