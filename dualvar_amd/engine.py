@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from . import rccl
 from . import ops
 from ._lib import DV_MASK_FROM_X
 from .ops import DV_ACCUM, DV_BF16, DV_BIAS, DV_F32, DV_NO_RELU_MASK, DV_RELU, DV_SIGMOID, DV_STATS, Act, cp8
@@ -303,6 +304,15 @@ class Comm:
                                            and dist.is_initialized())
         # RCCL gathers straight into one flat tensor; gloo (the CPU / single-GPU tests) only has the list form
         self.flat_gather = self.exchange and dist.get_backend(group) == 'nccl'
+        # RCCL enqueued directly on the step's own streams (dualvar_amd/rccl.py); None: torch.distributed calls
+        self.rccl = rccl.get('bn', group) if self.flat_gather else None
+        self._xstream = None
+
+    def xstream(self, device):
+        """the stream the backward sum exchanges run on, next to the main chain"""
+        if self._xstream is None:
+            self._xstream = torch.cuda.Stream(device=device)
+        return self._xstream
 
 
 class Launch:
@@ -317,6 +327,17 @@ class Launch:
         rc = self.fn(*self.args, stream)
         if rc:
             L.check(rc, self.name)
+
+
+class StreamStep:
+    """A host-side step that needs the stream it is issued on (event hops around a direct RCCL call)."""
+    __slots__ = ('name', 'kname', 'call', 'bytes', 'flops')
+
+    def __init__(self, name, call):
+        self.name, self.kname, self.call, self.bytes, self.flops = name, 'host:' + name, call, 0, 0
+
+    def __call__(self, stream):
+        self.call(stream)
 
 
 class HostStep:
@@ -839,7 +860,11 @@ class BNGroupOp(Op):
         b = list(b_red)
         if p.comm.exchange:
             local, gathered, group = self.local, self.gathered, p.comm.group
-            if p.comm.flat_gather:
+            rc = p.comm.rccl
+            if rc is not None:       # in-stream: ordered with the reduce kernels before and the finalize after, no hop
+                f.append(Launch('syncbn_allgather', 'rccl:all_gather', rc.all_gather,
+                                (local.data_ptr(), gathered.data_ptr(), self.width), 4 * self.width * (R + 1)))
+            elif p.comm.flat_gather:
                 f.append(HostStep('syncbn_allgather', lambda: dist.all_gather_into_tensor(gathered, local, group=group)))
             else:
                 f.append(HostStep('syncbn_allgather', lambda: dist.all_gather(list(gathered.unbind(0)), local, group=group)))
@@ -857,8 +882,31 @@ class BNGroupOp(Op):
 
                 def _wait():
                     pending.pop().wait()
-                b.append(HostStep('syncbn_allreduce_start', _start))
-                b.append(HostStep('syncbn_allreduce_wait', _wait))
+                if rc is not None and os.environ.get('DUALVAR_BN_BWD_ASYNC') != '1':
+                    # in-stream between the group's reduce and apply kernels.  Measured (one rank, every collective issued):
+                    # the two event hops of the overlapped form cost ~24 us per exchange, more than a small RCCL
+                    # all-reduce inside a node takes -- step 11.71 ms overlapped vs 10.95 ms in-stream (10.74 without exchange)
+                    b.append(Launch('syncbn_allreduce', 'rccl:all_reduce', lambda stream: rc.all_reduce(p.zero_ptr(lo), n, stream), (),
+                                    8 * n))
+                elif rc is not None:
+                    # same overlap with RCCL called directly: main --event--> exchange stream: all-reduce --event--> main
+                    ev_a, ev_b = torch.cuda.Event(), torch.cuda.Event()
+                    dev = p.device
+
+                    def _start_direct(stream):
+                        xs = p.comm.xstream(dev)
+                        ev_a.record(torch.cuda.current_stream(dev))
+                        xs.wait_event(ev_a)
+                        L.check(rc.all_reduce(p.zero_ptr(lo), n, xs.cuda_stream), 'ncclAllReduce')
+                        ev_b.record(xs)
+
+                    def _wait_direct(stream):
+                        torch.cuda.current_stream(dev).wait_event(ev_b)
+                    b.append(StreamStep('syncbn_allreduce_start', _start_direct))
+                    b.append(StreamStep('syncbn_allreduce_wait', _wait_direct))
+                else:
+                    b.append(HostStep('syncbn_allreduce_start', _start))
+                    b.append(HostStep('syncbn_allreduce_wait', _wait))
         for m in self.members:               # conv bias in front of the BN: only the running mean sees it
             if m.conv_bias is not None and m.bn.running_mean is not None:
                 assert len(self.members) == 1

@@ -59,6 +59,10 @@ class GradSync:
         self.side_stream = side_stream
         self._stream = None
         self._works = {}             # id(flat) -> {bucket start: work handle} for the step in flight
+        # a communicator of its own, called directly (dualvar_amd/rccl.py): the buckets do not queue behind the SyncBN
+        # exchanges of c10d's / the engine's communicator.  None (gloo, DUALVAR_RCCL=c10d): torch.distributed calls.
+        from . import rccl
+        self._rccl = rccl.get('grad', group) if self.exchange else None
 
     # ---- overlap with backward
     def attach(self, model):
@@ -85,6 +89,15 @@ class GradSync:
                 self._stream.wait_stream(s_)
         return torch.cuda.stream(self._stream)
 
+    def _all_reduce(self, flat, a, b):
+        """sum-all-reduce flat[a:b] on the current stream; -> work handle (torch.distributed) or None (enqueued in-stream)"""
+        if self._rccl is not None and flat.is_cuda:
+            rc = self._rccl.all_reduce(flat.data_ptr() + 4 * a, b - a, torch.cuda.current_stream(flat.device).cuda_stream)
+            if rc:
+                raise RuntimeError('ncclAllReduce failed with %d' % rc)
+            return None
+        return dist.all_reduce(flat[a:b], group=self.group, async_op=True)
+
     def _on_ready(self, plan, lo):
         """gradient-arena elements [lo, total) are final: start the buckets that lie in there"""
         flat = plan.store.grad
@@ -94,7 +107,7 @@ class GradSync:
             return
         with self._comm_stream(flat, getattr(plan, '_side', None)):
             for a, b in todo:
-                works[a] = dist.all_reduce(flat[a:b], group=self.group, async_op=True)
+                works[a] = self._all_reduce(flat, a, b)
 
     # ---- the reduction proper (optimizer step)
     def reduce_flat(self, flat):
@@ -104,9 +117,10 @@ class GradSync:
         with self._comm_stream(flat):
             for a, b in bucket_ranges(flat.numel(), self.bucket_elems):
                 if a not in works:
-                    works[a] = dist.all_reduce(flat[a:b], group=self.group, async_op=True)
+                    works[a] = self._all_reduce(flat, a, b)
             for w in works.values():
-                w.wait()
+                if w is not None:
+                    w.wait()
         if self.side_stream and flat.is_cuda:
             torch.cuda.current_stream(flat.device).wait_stream(self._stream)
         return 1.0 / self.world

@@ -1,0 +1,128 @@
+"""RCCL called directly, in-stream (one process per GPU, xGMI inside the node).
+
+The data-parallel step issues ~70 tiny collectives (SyncBatchNorm statistics: one all-gather per BatchNorm group forward,
+one all-reduce backward) plus the gradient buckets.  Through torch.distributed each of them costs 30-50 us of host time
+and two cross-stream event hops (c10d runs collectives on a stream of its own); enqueued with `ncclAllGather` /
+`ncclAllReduce` on the stream the producing and consuming kernels run on, a collective costs what a kernel launch costs
+and needs no hop at all.  This module binds the handful of RCCL entry points with ctypes (the library torch already
+loaded) and builds communicators of its own: rank 0 draws the unique id, torch.distributed broadcasts it (plumbing),
+every rank calls ncclCommInitRank.
+
+Operations on ONE communicator are serialised by RCCL whatever stream they are enqueued on, so the engine uses two:
+`get('bn')` for the SyncBatchNorm exchanges (main / exchange stream) and `get('grad')` for the gradient buckets (comm
+stream), which may then overlap.  Every rank issues every collective in the same program order.
+
+`DUALVAR_RCCL=c10d` keeps everything on torch.distributed (also the path taken with the gloo backend of the CPU tests).
+"""
+import ctypes as C
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+NCCL_FLOAT32, NCCL_SUM = 7, 0          # ncclDataType_t / ncclRedOp_t (rccl.h)
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [('internal', C.c_byte * 128)]
+
+
+_lib = None
+_comms = {}
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        lib = C.CDLL(path if os.path.exists(path) else 'librccl.so')
+        lib.ncclGetErrorString.restype = C.c_char_p
+        lib.ncclGetErrorString.argtypes = [C.c_int]
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        for f in ('ncclGetUniqueId', 'ncclCommInitRank', 'ncclCommDestroy', 'ncclAllGather', 'ncclAllReduce'):
+            getattr(lib, f).restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+class RcclError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RcclError('%s failed: %s' % (what, _load().ncclGetErrorString(rc).decode()))
+
+
+class RcclComm:
+    """fp32 all-gather / in-place sum all-reduce on device pointers, enqueued on the HIP stream handed in"""
+
+    def __init__(self, group=None):
+        lib = _load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        uid = _UniqueId()
+        if self.rank == 0:
+            _check(lib.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId')
+        dev = torch.device('cuda', torch.cuda.current_device())
+        t = torch.tensor(list(bytes(uid)), dtype=torch.uint8).to(dev)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        C.memmove(C.byref(uid), bytes(t.cpu().tolist()), 128)
+        self._comm = C.c_void_p()
+        _check(lib.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank), 'ncclCommInitRank')
+        self._ag, self._ar = lib.ncclAllGather, lib.ncclAllReduce
+
+    def all_gather(self, send_ptr, recv_ptr, count, stream):
+        """recv[r * count : (r + 1) * count] = rank r's send[0 : count]; returns the ncclResult (0 = ok)"""
+        return self._ag(send_ptr, recv_ptr, count, NCCL_FLOAT32, self._comm, stream)
+
+    def all_reduce(self, ptr, count, stream):
+        """in place: ptr[0 : count] = sum over ranks"""
+        return self._ar(ptr, ptr, count, NCCL_FLOAT32, NCCL_SUM, self._comm, stream)
+
+    def destroy(self):
+        if self._comm:
+            _load().ncclCommDestroy(self._comm)
+            self._comm = C.c_void_p()
+
+
+def enabled(group=None):
+    return (os.environ.get('DUALVAR_RCCL', 'direct') != 'c10d' and dist.is_available() and dist.is_initialized()
+            and dist.get_backend(group) == 'nccl' and torch.cuda.is_available())
+
+
+def get(name, group=None):
+    """the process-wide communicator `name` ('bn' / 'grad'), or None when the step stays on torch.distributed.  Creation is
+    collective: every rank reaches it at the same point of the program (model construction / first GradSync)."""
+    if not enabled(group):
+        return None
+    key = (name, id(group))
+    if key not in _comms:
+        comm, err = None, None
+        try:
+            comm = RcclComm(group)
+        except (RcclError, OSError, AttributeError) as e:
+            err = e
+        # all ranks take the same path: one failed initialisation sends everybody to c10d's communicator (also RCCL)
+        ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=torch.device('cuda', torch.cuda.current_device()))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.destroy()
+                comm = None
+            if dist.get_rank(group) == 0:
+                print('[dualvar_amd.rccl] direct communicator %r unavailable (%s): using torch.distributed' % (name, err),
+                      file=sys.stderr, flush=True)
+        _comms[key] = comm
+    return _comms[key]
+
+
+def destroy_all():
+    for c in _comms.values():
+        if c is not None:
+            c.destroy()
+    _comms.clear()

@@ -149,8 +149,8 @@ def test_two_ranks_equal_one_process(gpu, kind):
 # all_gather_into_tensor, async all-reduce handles, collectives enqueued from the side stream) is run with ONE rank and
 # DUALVAR_FORCE_EXCHANGE=1, which makes the engine and GradSync issue every collective of the multi-GPU step anyway.
 # With one rank the exchanged statistics equal the local ones, so the step must reproduce the plain single-process step.
-def _rccl_worker(port, kind, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DUALVAR_FORCE_EXCHANGE='1')
+def _rccl_worker(port, kind, transport, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DUALVAR_FORCE_EXCHANGE='1', DUALVAR_RCCL=transport)
     torch.cuda.set_device(0)
     dev = torch.device('cuda:0')
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
@@ -185,20 +185,22 @@ def _rccl_worker(port, kind, q):
         torch.cuda.synchronize()
         from dualvar_amd.engine import Comm
         assert Comm().exchange and Comm().flat_gather
+        # 'direct': ncclAllGather / ncclAllReduce enqueued on the step's own streams (dualvar_amd/rccl.py); 'c10d': torch.distributed
+        assert (Comm().rccl is not None) == (transport == 'direct') and (sync._rccl is not None) == (transport == 'direct')
         q.put((losses, early, {k: v.detach().float().cpu().numpy() for k, v in m.state_dict().items() if v.dtype.is_floating_point}))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('kind', ['SimCLR_Naked', 'SimCLR_TimeSeriesV4'])
-def test_rccl_single_rank_rehearsal(gpu, kind):
+@pytest.mark.parametrize('kind,transport', [('SimCLR_Naked', 'direct'), ('SimCLR_TimeSeriesV4', 'direct'), ('SimCLR_Naked', 'c10d')])
+def test_rccl_single_rank_rehearsal(gpu, kind, transport):
     from dualvar_amd import model as M
     from dualvar_amd.optim import SGD
     from oracle import procedural as P
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    proc = ctx.Process(target=_rccl_worker, args=(29911 + (os.getpid() % 200), kind, q))
+    proc = ctx.Process(target=_rccl_worker, args=(29911 + (os.getpid() % 200), kind, transport, q))
     proc.start()
     import queue
     import time
