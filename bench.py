@@ -291,6 +291,9 @@ def main():
         print(json.dumps(out))
     if distributed:
         dist.barrier()
+        torch.cuda.synchronize()
+        from dualvar_amd import rccl
+        rccl.destroy_all()
         dist.destroy_process_group()
 
 

@@ -249,6 +249,9 @@ def main_worker(gpu, ngpus_per_node, args):
                             keep_all=True)
     args.logger.info('Training from ep %d to ep %d finished' % (args.start_epoch, args.epochs))
     if args.distributed:
+        torch.cuda.synchronize()
+        from dualvar_amd import rccl
+        rccl.destroy_all()
         dist.destroy_process_group()
 
 
