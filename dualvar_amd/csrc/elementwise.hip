@@ -114,12 +114,23 @@ __global__ void bn_reduce_stats_kernel(const float* __restrict__ part, int n_til
 }
 
 // locate the item a block of a multi-tensor launch belongs to: `end` is the running block-count prefix
+// (the first eight prefixes are fetched with independent loads: a `while` over them is a chain of dependent global
+// loads, ~1 us each, in front of every block of these latency-bound launches)
 template <typename GetEnd>
 __device__ __forceinline__ int find_item(int n, uint32_t& bid, uint32_t& nblk, GetEnd end) {
+  uint32_t e[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = k < n ? (uint32_t)end(k) : 0xffffffffu;
   int i = 0;
-  uint32_t start = 0;
-  while (i < n - 1 && bid >= (uint32_t)end(i)) { start = (uint32_t)end(i); ++i; }
-  nblk = (uint32_t)end(i) - start;
+  uint32_t start = 0, endv = e[0];
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+    if (k < n - 1 && bid >= e[k]) { start = e[k]; i = k + 1; endv = e[k + 1]; }
+  if (n > 8 && i == 7) {
+    while (i < n - 1 && bid >= (uint32_t)end(i)) { start = (uint32_t)end(i); ++i; }
+    endv = (uint32_t)end(i);
+  }
+  nblk = endv - start;
   bid -= start;
   return i;
 }

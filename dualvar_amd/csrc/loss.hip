@@ -67,11 +67,19 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const dv_gemm_des
   __shared__ float red[3][16][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int tile = blockIdx.x;
-  int gi = 0;
-  while (gi < n_groups && tile >= descs[gi].tile_end) ++gi;
+  int gi = 0, tstart = 0;
+  {  // independent loads of the first eight prefixes instead of a chain of dependent ones
+    int e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = k < n_groups ? descs[k].tile_end : 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < n_groups && tile >= e[k]) { gi = k + 1; tstart = e[k]; }
+    while (gi >= 8 && gi < n_groups && tile >= descs[gi].tile_end) { tstart = descs[gi].tile_end; ++gi; }
+  }
   if (gi >= n_groups) return;
   const dv_gemm_desc d = descs[gi];
-  tile -= (gi == 0 ? 0 : descs[gi - 1].tile_end);
+  tile -= tstart;
   const int tiles_n = (d.N + 31) / 32;
   const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
   const int l31 = lane & 31, h = lane >> 5;
@@ -84,9 +92,11 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const dv_gemm_des
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int kc = wave * 16; kc < d.K; kc += 64) {
+  // U chunks per round: all loads of a round are issued before its MFMAs, so a wave pays the load latency K/(64 U)
+  // times instead of K/64 times (the loop is latency bound: 13 dependent rounds at K = 832 were 12-16 us per launch)
+  constexpr int U = 4;
+  auto load_chunk = [&](int kc, float (&a)[8], float (&b)[8]) {
     const int kb = kc + 8 * h;
-    float a[8], b[8];
     if (kc + 16 <= d.K) {
       if (avec) {
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(ap + kb), v1 = *reinterpret_cast<const f32x4*>(ap + kb + 4);
@@ -105,14 +115,24 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const dv_gemm_des
     } else {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const bool kok = kb + u < d.K;
+        const bool kok = kb + u < d.K;                  // also covers kc >= K: the whole chunk is zero
         a[u] = kok ? ap[(int64_t)(kb + u) * d.sak] : 0.f;
         b[u] = kok ? bp[(int64_t)(kb + u) * d.sbk] : 0.f;
       }
     }
+  };
+  for (int kc = wave * 16; kc < d.K; kc += 64 * U) {
+    float a[U][8], b[U][8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mok ? a[u] : 0.f, nok ? b[u] : 0.f, acc, 0, 0, 0);
+    for (int q = 0; q < U; ++q) load_chunk(kc + 64 * q, a[q], b[q]);
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      if (kc + 64 * q < d.K) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mok ? a[q][u] : 0.f, nok ? b[q][u] : 0.f, acc, 0, 0, 0);
+      }
+    }
   }
   if (wave > 0) {
 #pragma unroll
