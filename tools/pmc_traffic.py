@@ -20,9 +20,9 @@ import sys
 def short(name):
     """map a (mangled or rocprof-demangled) kernel name to the label dualvar_amd.engine gives the launch"""
     n = name
-    m = re.search(r'conv_wgrad_dma_kernelILi(\d+)ELi(\d+)E', n) or re.search(r'conv_wgrad_dma_kernel<(\d+), (\d+)>', n)
+    m = re.search(r'conv_wgrad_dma_kernelILi(\d+)ELi(\d+)E', n) or re.search(r'conv_wgrad_dma_kernel<(\d+), (\d+)(?:, \d+)?>', n)
     if m:
-        return 'conv_wgrad<bf16,16,%s,%s>' % m.groups()
+        return 'conv_wgrad<bf16,16,%s,%s>' % m.groups()[:2]
     m = re.search(r'conv_wgrad_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)E', n)
     if m:
         return 'conv_wgrad<%s,%s,%s,%s>' % ((('bf16' if m.group(1) == 'DF16b' else 'f32'),) + m.groups()[1:])
