@@ -80,6 +80,28 @@ __device__ __forceinline__ Rgb colour_ops(Rgb p, const dv_aug_frame& q, int to, 
         p.r = p.g = p.b = l;
         break;
       }
+      case DV_AUG_HUE: {                                        // utils/augmentation.py:26-106 (_rgb2hsv_np, _hsv2rgb_np)
+        const float maxc = fmaxf(p.r, fmaxf(p.g, p.b)), minc = fminf(p.r, fminf(p.g, p.b));
+        const bool eqc = maxc == minc;
+        const float cr = maxc - minc;
+        const float s = cr / (eqc ? 1.f : maxc);
+        const float cd = eqc ? 1.f : cr;
+        const float rc = (maxc - p.r) / cd, gc = (maxc - p.g) / cd, bc = (maxc - p.b) / cd;
+        const float hr = (maxc == p.r) ? (bc - gc) : 0.f;
+        const float hg = (maxc == p.g && maxc != p.r) ? (2.0f + rc - bc) : 0.f;
+        const float hb = (maxc != p.g && maxc != p.r) ? (4.0f + gc - rc) : 0.f;
+        float hh = fmodf((hr + hg + hb) / 6.0f + 1.0f, 1.0f);
+        hh = hh + f;
+        hh = hh - floorf(hh);                                   // numpy's float `% 1.0`
+        const float h6 = hh * 6.0f, fi = floorf(h6), ff = h6 - fi;
+        const float v = maxc;
+        const float pp = clamp01(v * (1.0f - s)), qq = clamp01(v * (1.0f - s * ff)), tt = clamp01(v * (1.0f - s * (1.0f - ff)));
+        const int i = ((int)fi) % 6;
+        p.r = i == 0 ? v : i == 1 ? qq : i == 2 ? pp : i == 3 ? pp : i == 4 ? tt : v;
+        p.g = i == 0 ? tt : i == 1 ? v : i == 2 ? v : i == 3 ? qq : i == 4 ? pp : pp;
+        p.b = i == 0 ? pp : i == 1 ? pp : i == 2 ? tt : i == 3 ? v : i == 4 ? v : qq;
+        break;
+      }
       default: break;
     }
   }
@@ -87,7 +109,7 @@ __device__ __forceinline__ Rgb colour_ops(Rgb p, const dv_aug_frame& q, int to, 
 }
 
 __device__ __forceinline__ int contrast_pos(const dv_aug_frame& q) {
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < DV_AUG_MAX_OPS; ++k)
     if (q.op[k] == DV_AUG_CONTRAST) return k;
   return -1;
 }
@@ -123,7 +145,7 @@ __global__ void __launch_bounds__(kThreads) aug_apply_kernel(AugArgs a, T* __res
     const int hw = (int)(i - (int64_t)f * px);
     const int hh = hw / a.W, ww = hw - hh * a.W;
     const dv_aug_frame q = a.tab[table_row(a, f)];
-    Rgb p = colour_ops(sample(a, q, hh, ww), q, 4, contrast_pos(q) >= 0 ? a.cmean[f] : 0.f);
+    Rgb p = colour_ops(sample(a, q, hh, ww), q, DV_AUG_MAX_OPS, contrast_pos(q) >= 0 ? a.cmean[f] : 0.f);
     if (a.mean3) {
       p.r = (p.r - a.mean3[0]) * a.istd3[0];
       p.g = (p.g - a.mean3[1]) * a.istd3[1];

@@ -32,9 +32,10 @@ import random
 
 import numpy as np
 
-AUG_NONE, AUG_BRIGHTNESS, AUG_CONTRAST, AUG_SATURATION, AUG_GRAY = 0, 1, 2, 3, 4
+AUG_NONE, AUG_BRIGHTNESS, AUG_CONTRAST, AUG_SATURATION, AUG_GRAY, AUG_HUE = 0, 1, 2, 3, 4, 5
+AUG_MAX_OPS = 5
 AUG_ROW = np.dtype([('src', '<i4'), ('crop_i', '<i4'), ('crop_j', '<i4'), ('crop_h', '<i4'), ('crop_w', '<i4'), ('flip', '<i4'),
-                    ('op', '<i4', (4,)), ('factor', '<f4', (4,)), ('_pad', '<i4', (2,))])          # include/dualvar_hip.h
+                    ('op', '<i4', (AUG_MAX_OPS,)), ('factor', '<f4', (AUG_MAX_OPS,))])                   # include/dualvar_hip.h
 
 
 class ClipState:
@@ -70,8 +71,8 @@ class ClipState:
         oh, ow = self.size()
         if (oh, ow) != (H, W):
             raise ValueError('pipeline produces %dx%d frames, the plan wants %dx%d' % (oh, ow, H, W))
-        if len(self.ops) > 4 or sum(1 for c, _ in self.ops if c == AUG_CONTRAST) > 1:
-            raise ValueError('at most four colour ops and one contrast per frame')
+        if len(self.ops) > AUG_MAX_OPS or sum(1 for c, _ in self.ops if c == AUG_CONTRAST) > 1:
+            raise ValueError('at most %d colour ops and one contrast per frame' % AUG_MAX_OPS)
         t = np.zeros(self.N, dtype=AUG_ROW)
         t['src'], t['crop_i'], t['crop_j'], t['crop_h'], t['crop_w'] = self.src, self.i, self.j, self.h, self.w
         t['flip'] = int(self.flip)
@@ -181,10 +182,15 @@ class RandomGray(object):                                   # transforms.py:80-8
 
 
 class ColorJitter(object):                                  # transforms.py:313-373
-    def __init__(self, brightness=0, contrast=0, saturation=0, consistent=False, p=1.0, n_channel=1, gray_channel=0):
+    """`hue` is an extension: the reference's tensor-side ColorJitter has none, its PIL one (utils/augmentation.py:429-508,
+    the `ColorJitter(0.8, 0.8, 0.8, 0.2)` of pretrain.py:503) draws a shift in [-hue, hue] turns; here it joins the shuffled
+    list like the other three and runs as DV_AUG_HUE (`adjust_hue_np`'s arithmetic)."""
+
+    def __init__(self, brightness=0, contrast=0, saturation=0, consistent=False, p=1.0, n_channel=1, gray_channel=0, hue=0):
         self.brightness = self._check_input(brightness, 'brightness')
         self.contrast = self._check_input(contrast, 'contrast')
         self.saturation = self._check_input(saturation, 'saturation')
+        self.hue = self._check_input(hue, 'hue', center=0, bound=(-0.5, 0.5))
         self.consistent, self.p = consistent, p
 
     @staticmethod
@@ -216,6 +222,8 @@ class ColorJitter(object):                                  # transforms.py:313-
                 todo.append((AUG_CONTRAST, self.contrast))
             if self.saturation is not None:
                 todo.append((AUG_SATURATION, self.saturation))
+            if self.hue is not None:
+                todo.append((AUG_HUE, self.hue))
             random.shuffle(todo)
             for code, rng in todo:
                 st.ops.append((code, self._draw(rng, st.N).astype(np.float32)))

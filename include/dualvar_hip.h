@@ -136,22 +136,23 @@ int dv_fill_cols_f32(float* p, int64_t rows, int32_t pitch, int32_t col0, int32_
 /* Augmenting ingest (replaces the CPU PIL/DataLoader pipeline of pretrain.py:491-564 with the
  * reference's own tensor-side definitions, utils/transforms.py:13-63,66-78,90-163,201-312): decoded uint8 frames
  * [n_src][Hs][Ws][3] -> for every output frame f = n*T + t one table row: source frame, crop window (resized to H x W
- * with bilinear / align_corners=False when its size differs), horizontal flip, then up to four colour ops in table
+ * with bilinear / align_corners=False when its size differs), horizontal flip, then up to five colour ops in table
  * order on [0,1] floats -- brightness / contrast / saturation `clamp(f*x + (1-f)*ref)` with ref = 0 / mean luma of the
- * frame at that point / luma of the pixel, or grayscale (x = luma) -- then Normalize, and the NDHWC store of
+ * frame at that point / luma of the pixel, grayscale (x = luma), or the hue rotation RGB -> HSV -> h = (h + f) mod 1
+ * -> RGB of utils/augmentation.py:26-106 (`adjust_hue_np`, without its uint8 re-quantisation) -- then Normalize, and the NDHWC store of
  * dv_ingest_ncdhw_pad (4th channel zero, optional zero border, optional segment shuffle of table rows).
  * `table` and `perm` are DEVICE arrays; indices and windows are clamped into the source, so a bad row cannot fault.
  * At most one contrast op per frame.  scratch: N*T floats (mean luma in front of the contrast op).  Two launches. */
-enum { DV_AUG_NONE = 0, DV_AUG_BRIGHTNESS = 1, DV_AUG_CONTRAST = 2, DV_AUG_SATURATION = 3, DV_AUG_GRAY = 4 };
+enum { DV_AUG_NONE = 0, DV_AUG_BRIGHTNESS = 1, DV_AUG_CONTRAST = 2, DV_AUG_SATURATION = 3, DV_AUG_GRAY = 4, DV_AUG_HUE = 5 };
+#define DV_AUG_MAX_OPS 5
 typedef struct dv_aug_frame {
   int32_t src;                     /* index of the source frame */
   int32_t crop_i, crop_j;          /* top-left corner of the window in the source frame */
   int32_t crop_h, crop_w;          /* its size; == (H, W): plain crop, else bilinear resize to H x W */
   int32_t flip;                    /* 1: horizontal flip of the window */
-  int32_t op[4];                   /* DV_AUG_*, applied in this order */
-  float factor[4];                 /* blend ratio of op[k] (unused for DV_AUG_GRAY / DV_AUG_NONE) */
-  int32_t _pad[2];                 /* 64 bytes per row */
-} dv_aug_frame;
+  int32_t op[DV_AUG_MAX_OPS];      /* DV_AUG_*, applied in this order */
+  float factor[DV_AUG_MAX_OPS];    /* blend ratio of op[k]; hue shift in turns for DV_AUG_HUE; unused for GRAY / NONE */
+} dv_aug_frame;                    /* 64 bytes per row */
 int dv_augment_ingest(int32_t dtype, const uint8_t* frames, int32_t n_src, int32_t Hs, int32_t Ws,
                       const dv_aug_frame* table, int32_t N, int32_t T, int32_t H, int32_t W, void* y, int32_t ldy,
                       int32_t pad, const float* mean3, const float* istd3, const int32_t* perm, int32_t n_seg,

@@ -10,11 +10,12 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-NONE, BRIGHTNESS, CONTRAST, SATURATION, GRAY = 0, 1, 2, 3, 4
+NONE, BRIGHTNESS, CONTRAST, SATURATION, GRAY, HUE = 0, 1, 2, 3, 4, 5
+MAX_OPS = 5
 
 # numpy mirror of `dv_aug_frame` (64 bytes per row)
 ROW = np.dtype([('src', '<i4'), ('crop_i', '<i4'), ('crop_j', '<i4'), ('crop_h', '<i4'), ('crop_w', '<i4'), ('flip', '<i4'),
-                ('op', '<i4', (4,)), ('factor', '<f4', (4,)), ('_pad', '<i4', (2,))])
+                ('op', '<i4', (MAX_OPS,)), ('factor', '<f4', (MAX_OPS,))])
 assert ROW.itemsize == 64
 
 
@@ -27,6 +28,33 @@ def _blend(a, b, ratio):
     return (r * a + (1 - r) * b).clamp(0, 1)
 
 
+def _hue(x, factor):
+    """utils/augmentation.py:26-106 (`_rgb2hsv_np`, `_hsv2rgb_np`, `adjust_hue_np`) on a [0, 1] float frame [3, H, W], without the
+    uint8 re-quantisation of `adjust_hue_np` (the tensor-side pipeline stays in floats)"""
+    r, g, b = x[0], x[1], x[2]
+    maxc, minc = x.max(0).values, x.min(0).values
+    eqc = maxc == minc
+    cr = maxc - minc
+    ones = torch.ones_like(maxc)
+    s = cr / torch.where(eqc, ones, maxc)
+    cd = torch.where(eqc, ones, cr)
+    rc, gc, bc = (maxc - r) / cd, (maxc - g) / cd, (maxc - b) / cd
+    hr = (maxc == r) * (bc - gc)
+    hg = ((maxc == g) & (maxc != r)) * (2.0 + rc - bc)
+    hb = ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+    h = torch.fmod((hr + hg + hb) / 6.0 + 1.0, 1.0)
+    h = torch.remainder(h + torch.tensor(factor, dtype=torch.float32), 1.0)
+    i = torch.floor(h * 6.0)
+    f = h * 6.0 - i
+    i = i.to(torch.int64) % 6
+    v = maxc
+    p = (v * (1.0 - s)).clamp(0, 1)
+    q = (v * (1.0 - s * f)).clamp(0, 1)
+    t = (v * (1.0 - s * (1.0 - f))).clamp(0, 1)
+    pick = lambda opts: torch.stack(opts, 0).gather(0, i[None])[0]          # noqa: E731
+    return torch.stack((pick([v, q, p, p, t, v]), pick([t, v, v, q, p, p]), pick([p, p, t, v, v, q])), 0)
+
+
 def augment_frame(frames, row, H, W):
     """one output frame [3, H, W] fp32 in [0, 1] (before Normalize)"""
     fr = torch.from_numpy(np.ascontiguousarray(frames[int(row['src'])]))               # [Hs, Ws, 3] uint8
@@ -37,7 +65,7 @@ def augment_frame(frames, row, H, W):
         x = F.interpolate(x[None], size=(H, W), mode='bilinear', align_corners=False)[0]
     if int(row['flip']):
         x = x.flip(dims=(-1,))
-    for k in range(4):
+    for k in range(MAX_OPS):
         op, f = int(row['op'][k]), float(row['factor'][k])
         if op == BRIGHTNESS:
             x = _blend(x, 0, f)
@@ -47,6 +75,8 @@ def augment_frame(frames, row, H, W):
             x = _blend(x, _luma(x)[None], f)
         elif op == GRAY:
             x = _luma(x)[None].expand(3, -1, -1)
+        elif op == HUE:
+            x = _hue(x, f)
     return x.contiguous()
 
 

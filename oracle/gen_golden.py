@@ -457,6 +457,24 @@ def case_augment(ref):
             vid = RT.random_adjust_contrast(vid, [0.2, 1.8], consistent, 1, 0)
             outs.append(RT.normalize(vid, mean, std, channel=0).permute(1, 0, 2, 3).float())
         rec['B/%s' % tag] = torch.stack(outs).numpy()                                          # [4 seeds, T=4, 3, H, W]
+    # (C) hue: the reference's only hue definition is utils/augmentation.py:adjust_hue_np (uint8 in, uint8 out: float HSV
+    # round trip, then truncation to uint8).  The build applies the same arithmetic on floats and does not re-quantise; the
+    # fixture keeps the reference's uint8 result, the tests compare floor(255 * x) with it.
+    RA = ref.augmentation
+    hue_src, hue_fac = [0, 3, 5, 7, 9, 11], [-0.2, -0.07, 0.03, 0.11, 0.2, 0.45]
+    t = np.zeros(len(hue_src), dtype=A.ROW)
+    t['src'], t['crop_i'], t['crop_j'], t['crop_h'], t['crop_w'] = hue_src, 2, 5, H, W
+    t['op'][:, 0], t['factor'][:, 0] = A.HUE, hue_fac
+    want_u8 = np.stack([RA.adjust_hue_np(frames[s_][2:2 + H, 5:5 + W], f_) for s_, f_ in zip(hue_src, hue_fac)])   # [6, H, W, 3]
+    got = A.augment_ingest(frames, t, len(hue_src), 1, H, W)[:, :, 0].permute(0, 2, 3, 1)                     # [6, H, W, 3] floats
+    # a float that lands within rounding of an integer may truncate either way: compare both neighbours
+    q = (got * 255.0).numpy()
+    diff = np.abs(np.floor(q) - want_u8.astype(np.float64))
+    near = np.abs(q - np.round(q)) < 2e-3
+    bad = (diff > 0) & ~((diff <= 1) & near)
+    print('augment hue: mismatching pixels', int(bad.sum()), 'of', bad.size, '; boundary cases', int(((diff > 0) & near).sum()))
+    assert bad.sum() == 0
+    rec['C/table'], rec['C/want_u8'] = t.view(np.uint8).reshape(-1, 64), want_u8
     np.savez_compressed(os.path.join(GOLD, 'augment.npz'), **rec)
 
 

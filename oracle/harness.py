@@ -52,6 +52,7 @@ def load_reference():
     import utils.utils as U
     import model.classifier as CL
     import utils.transforms as RT                                         # tensor-side transforms (functions need no torchvision)
+    import utils.augmentation as RA                                       # PIL pipeline: only its numpy colour helpers are callable here
     S.SimCLR_TimeSeriesV4.calc_contrast_loss = S.SimCLR_TimeSeriesV4.calc_clip_contrast_loss   # D1
     M.MoCo_TimeSeriesV4.calc_contrast_loss = M.MoCo_TimeSeriesV4.calc_clip_contrast_loss       # D1
 
@@ -69,4 +70,4 @@ def load_reference():
         return CL.LinearClassifier(network=network, **kw)
 
     return types.SimpleNamespace(simclr=S, moco=M, select_backbone=select_backbone, utils=U, r50=r50,
-                                 linear_classifier=linear_classifier, transforms=RT)
+                                 linear_classifier=linear_classifier, transforms=RT, augmentation=RA)

@@ -146,13 +146,13 @@ class SyntheticFrames(torch.utils.data.Dataset):
 
 def gpu_transform(args):
     """the base transform of pretrain.py:500-509 in its tensor-side form (utils/transforms.py): random crop, optional
-    flip, colour jitter 0.8 / 0.8 / 0.8 with p = 0.8 (temporally consistent under --aug_temp_consist); hue and the PIL
-    Gaussian blur have no tensor-side definition in the reference and are not applied"""
+    flip, colour jitter 0.8 / 0.8 / 0.8 / hue 0.2 with p = 0.8 (temporally consistent under --aug_temp_consist; hue by
+    utils/augmentation.py:adjust_hue_np's arithmetic); the PIL Gaussian blur is not applied"""
     from dualvar_amd.utils import transforms as T
     steps = [T.RandomCrop((args.img_dim, args.img_dim))]
     if args.rand_flip:
         steps.append(T.RandomHorizontalFlip())
-    steps.append(T.ColorJitter(0.8, 0.8, 0.8, consistent=args.aug_temp_consist, p=0.8 * 0.8))
+    steps.append(T.ColorJitter(0.8, 0.8, 0.8, consistent=args.aug_temp_consist, p=0.8 * 0.8, hue=0.2))
     return T.Compose(steps)
 
 

@@ -208,6 +208,25 @@ def test_augment_ingest_against_reference_fixture(gpu, dtype, pad):
     assert err < (2e-5 if dtype == DV_F32 else 2e-2)
 
 
+def test_augment_hue_against_reference_fixture(gpu):
+    """DV_AUG_HUE on the GPU == the reference's adjust_hue_np (uint8 result in tests/golden/augment.npz, part C)"""
+    from tests.util import gold
+    from tests.test_oracle_golden import _hue_matches
+    from dualvar_amd.utils.transforms import AUG_ROW
+    g = gold('augment')
+    H, W = (int(v) for v in g['HW'])
+    t = np.ascontiguousarray(g['C/table']).view(AUG_ROW).reshape(-1)
+    a = ops.new_act(len(t), 1, H, W, 3, DV_F32, gpu, cpitch=4, zero=True)
+    fr = torch.from_numpy(np.ascontiguousarray(g['frames'])).to(gpu)
+    tb = torch.from_numpy(t.view(np.uint8).copy()).to(gpu)
+    ops.call('dv_augment_ingest', DV_F32, fr, fr.shape[0], fr.shape[1], fr.shape[2], tb, len(t), 1, H, W, a, 4, 0, None, None, None, 0,
+             torch.empty(len(t), device=gpu))
+    got = ops.act_to_ncdhw(a)[:, :, 0].permute(0, 2, 3, 1).cpu().numpy()
+    bad, boundary = _hue_matches(got.astype(np.float64) * 255.0, g['C/want_u8'])
+    print(f'hue vs adjust_hue_np: {bad} mismatching pixels, {boundary} truncation-boundary cases of {got.size}')
+    assert bad == 0 and boundary <= 10
+
+
 def test_augment_ingest_full_size_rows_against_oracle(gpu):
     """128x171 decoded frames -> 112x112 windows (plain and resized crops, flips, all colour-op orders, segment
     shuffle) at the bench's frame size, against oracle/augment_ref.py"""
@@ -227,9 +246,9 @@ def test_augment_ingest_full_size_rows_against_oracle(gpu):
             row['crop_h'], row['crop_w'] = r.randint(60, Hs + 1), r.randint(80, Ws + 1)
         row['crop_i'], row['crop_j'] = r.randint(0, Hs - row['crop_h'] + 1), r.randint(0, Ws - row['crop_w'] + 1)
         row['flip'] = r.randint(2)
-        codes = list(r.permutation([A.BRIGHTNESS, A.CONTRAST, A.SATURATION, A.GRAY]))[:r.randint(0, 5)]
+        codes = list(r.permutation([A.BRIGHTNESS, A.CONTRAST, A.SATURATION, A.GRAY, A.HUE]))[:r.randint(0, 6)]
         for k, c in enumerate(codes):
-            row['op'][k], row['factor'][k] = c, 1.0 if c == A.GRAY else r.uniform(0.2, 1.8)
+            row['op'][k], row['factor'][k] = c, 1.0 if c == A.GRAY else r.uniform(-0.3, 0.3) if c == A.HUE else r.uniform(0.2, 1.8)
     perm = torch.tensor([[1, 0], [0, 1], [1, 0]], dtype=torch.int32)
     mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
     got = _augment(gpu, DV_F32, frames, table, N, T, H, W, mean, std, perm=perm, pad=3).cpu()

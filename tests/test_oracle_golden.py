@@ -145,6 +145,25 @@ def test_augment_oracle_matches_reference_fixture():
     assert float((got.permute(0, 2, 1, 3, 4) - want).abs().max()) < 2e-6
 
 
+def _hue_matches(q, want_u8):
+    """floor(255 * x) == the reference's uint8 result; a float within rounding of an integer may truncate either way"""
+    diff = np.abs(np.floor(q) - want_u8.astype(np.float64))
+    near = np.abs(q - np.round(q)) < 2e-3
+    return int(((diff > 0) & ~((diff <= 1) & near)).sum()), int(((diff > 0) & near).sum())
+
+
+def test_augment_hue_oracle_matches_reference_fixture():
+    """DV_AUG_HUE == utils/augmentation.py:adjust_hue_np (the reference's uint8 result is in the fixture)"""
+    from oracle import augment_ref as A
+    g = gold('augment')
+    H, W = (int(v) for v in g['HW'])
+    t = np.ascontiguousarray(g['C/table']).view(A.ROW).reshape(-1)
+    got = A.augment_ingest(g['frames'], t, len(t), 1, H, W)[:, :, 0].permute(0, 2, 3, 1)
+    bad, boundary = _hue_matches((got * 255.0).numpy(), g['C/want_u8'])
+    assert bad == 0 and boundary <= 5
+    assert float((got.numpy() * 255 - g['C/want_u8']).max()) < 1.0 + 1e-3            # truncation only ever rounds down
+
+
 @pytest.mark.parametrize('tag,sized,consistent', [('crop', False, False), ('sized', True, False), ('sized_consistent', True, True)])
 def test_augment_parameter_classes_follow_reference_rng(tag, sized, consistent):
     """same seeds -> same crops / flips / factors as the reference's RandomCrop, RandomSizedCrop, RandomHorizontalFlip and
@@ -176,7 +195,7 @@ def test_color_jitter_and_frame_batch_host_logic():
     from dualvar_amd.utils import transforms as T
     random.seed(7)
     np.random.seed(7)
-    tr = T.Compose([T.RandomSizedCrop((16, 16)), T.RandomHorizontalFlip(), T.ColorJitter(0.8, 0.8, 0.8, p=1.0), T.RandomGray(0.5)])
+    tr = T.Compose([T.RandomSizedCrop((16, 16)), T.RandomHorizontalFlip(), T.ColorJitter(0.8, 0.8, 0.8, p=1.0, hue=0.2), T.RandomGray(0.5)])
     fr = torch.zeros(12, 24, 32, 3, dtype=torch.uint8)
     fb = T.FrameBatch.build(fr, [[0, 1, 2, 3], [4, 5, 6, 7]], tr, (16, 16), views=2)
     assert tuple(fb.shape) == (2, 2, 3, 4, 16, 16) and fb.dim() == 6
@@ -186,8 +205,9 @@ def test_color_jitter_and_frame_batch_host_logic():
     assert rows.shape == (16,) and list(rows['src'][:8]) == [0, 1, 2, 3, 0, 1, 2, 3]
     for r in rows:
         ops_ = [int(o) for o in r['op'] if o]
-        assert sorted(o for o in ops_ if o != T.AUG_GRAY) == [1, 2, 3]          # every jitter op once, in a shuffled order
+        assert sorted(o for o in ops_ if o != T.AUG_GRAY) == [1, 2, 3, 5]       # every jitter op once, in a shuffled order
         assert all(0.2 <= f <= 1.8 for o, f in zip(r['op'], r['factor']) if o in (1, 2, 3))
+        assert all(-0.2 <= f <= 0.2 for o, f in zip(r['op'], r['factor']) if o == T.AUG_HUE)
         assert 0 <= r['crop_i'] and r['crop_i'] + r['crop_h'] <= 24 and r['crop_j'] + r['crop_w'] <= 32
     v1 = fb[:, 1]
     assert tuple(v1.shape) == (2, 3, 4, 16, 16)
