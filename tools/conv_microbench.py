@@ -53,6 +53,7 @@ def main():
     ap.add_argument('--layers', default='big')
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--passes', default='fwd,dgrad,wgrad')
+    ap.add_argument('--no-stats', action='store_true', help='forward without the fused BatchNorm partials')
     args = ap.parse_args()
     L.require_device()
     dev = torch.device('cuda:0')
@@ -70,7 +71,7 @@ def main():
         w = torch.randn(Co, taps * x.cpitch, device=dev).bfloat16()
         wd = torch.randn(Ci, taps * y.cpitch, device=dev).bfloat16()
         dw = torch.zeros(Co, taps * x.cpitch, device=dev)
-        d = ops.conv_desc(L.DV_BF16, x, y, k, s, p, flags=L.DV_STATS)
+        d = ops.conv_desc(L.DV_BF16, x, y, k, s, p, flags=0 if args.no_stats else L.DV_STATS)
         stats = torch.zeros(ops.stat_tiles(d) * 2 * Co, device=dev)
         dd = ops.conv_desc(L.DV_BF16, x, y, k, s, p)
         flops = 2.0 * y.rows * Co * Ci * taps
