@@ -156,10 +156,76 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const dv_gemm_des
   }
 }
 
+// Few output tiles, long K (MoCo's dq = dlogits . queue^T: 32 x 128 outputs over K = 65 536 -- four tiles, i.e. four waves
+// walking 4 096 dependent load rounds each: 4 ms): the K range is cut into `splits` slices, one workgroup per (tile,
+// slice), its four waves interleave 16-deep chunks of the slice, reduce through LDS and add alpha * partial to C with
+// fp32 atomics (C zeroed first unless accumulating).
+__global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(int M, int N, int K, const float* __restrict__ A, int64_t sam,
+                                                               int64_t sak, const float* __restrict__ B, int64_t sbk,
+                                                               int64_t sbn, float* __restrict__ C, int64_t ldc, float alpha,
+                                                               int tiles_n, int tiles, int kslice) {
+  __shared__ float red[3][16][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = blockIdx.x % tiles, slice = blockIdx.x / tiles;
+  const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int m = m0 + l31, n = n0 + l31;
+  const bool mok = m < M, nok = n < N;
+  const float* ap = A + (int64_t)(mok ? m : 0) * sam;
+  const float* bp = B + (int64_t)(nok ? n : 0) * sbn;
+  const int k_begin = slice * kslice, k_end = min(K, k_begin + kslice);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int kc = k_begin + wave * 16; kc < k_end; kc += 64) {
+    const int kb = kc + 8 * h;
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool kok = kb + u < k_end;
+      a[u] = (kok && mok) ? ap[(int64_t)(kb + u) * sak] : 0.f;
+      b[u] = (kok && nok) ? bp[(int64_t)(kb + u) * sbk] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0 && nok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < M) atomicAdd(C + (int64_t)row * ldc + n, alpha * (((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane]));
+    }
+  }
+}
+
+__global__ void zero_matrix_kernel(float* __restrict__ C, int64_t ldc, int M, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M * N) C[(int64_t)(i / N) * ldc + i % N] = 0.f;
+}
+
 static int launch_gemm_f32(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
                            int64_t sbn, float* C, int64_t ldc, float alpha, int accumulate, hipStream_t s) {
   const int tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32;
   const int tiles = tiles_m * tiles_n;
+  if (tiles <= 64 && K >= 4096) {
+    int splits = 1024 / tiles;
+    if (splits > K / 256) splits = K / 256;
+    const int kslice = (((K + splits - 1) / splits) + 63) / 64 * 64;
+    splits = (K + kslice - 1) / kslice;
+    if (!accumulate) {
+      hipLaunchKernelGGL(zero_matrix_kernel, dim3((M * N + 255) / 256), dim3(256), 0, s, C, ldc, M, N);
+      int rc = dv_launch_status();
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(gemm_f32_splitk_kernel, dim3(tiles * splits), dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc,
+                       alpha, tiles_n, tiles, kslice);
+    return dv_launch_status();
+  }
   hipLaunchKernelGGL(gemm_f32_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc,
                      alpha, accumulate, tiles_n);
   return dv_launch_status();

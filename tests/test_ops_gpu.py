@@ -589,8 +589,10 @@ def test_losses_against_oracle(gpu):
         close(df.reshape(N, 2, 2, 64).permute(0, 2, 1, 3), rk.grad, DV_F32, 'rank grad', factor=50)
 
 
-def test_infonce_against_oracle(gpu):
-    B, D, K = 5, 128, 96
+@pytest.mark.parametrize('B,K', [(5, 96), (32, 65536), (40, 4096)])
+def test_infonce_against_oracle(gpu, B, K):
+    """K = 65 536 is MoCo's queue (moco.py:79-81): dq = dlogits . queue^T then takes the split-K path of dv_gemm_f32"""
+    D = 128
     qf = F.normalize(rnd(B, D, seed=22), dim=1).requires_grad_(True)
     kf = F.normalize(rnd(B, D, seed=23), dim=1)
     queue = F.normalize(rnd(D, K, seed=24), dim=0)
