@@ -91,6 +91,9 @@ SIGNATURES = {
     'dv_bn_bwd_apply': [I32, P, I32, P, I32, P, I32, P, P, P, P, I32, F, F, P, P, P, I32, P, I32, I64, I32, I32, P],
     'dv_maxpool3d_fwd': [PD, P, P, P, P],
     'dv_maxpool3d_bwd': [PD, P, P, P, I32, P],
+    'dv_bn_apply_maxpool': [PD, P, P, P, P, P, P],
+    'dv_bn_bwd_reduce_maxpool': [PD, P, P, P, P, P, P, P, P, I32, P],
+    'dv_bn_bwd_apply_maxpool': [PD, P, P, P, P, P, P, P, P, P, I32, F, F, P, P, P, I32, P],
     'dv_spatial_mean': [I32, P, I32, I32, I32, I32, P, P],
     'dv_spatial_mean_bwd': [I32, P, I32, I32, I32, P, I32, I32, P],
     'dv_gate_scale': [I32, P, I32, P, I32, I32, I32, P, I32, P],

@@ -232,7 +232,7 @@ class ResNet2d3d(HipBackbone):
     def emit(self, plan, x):
         x = emit_conv_bn(plan, self.conv1, self.bn1, x)
         mp = self.maxpool
-        x = plan.maxpool(x, _t3(mp.kernel_size), _t3(mp.stride), _t3(mp.padding))
+        x = plan.maxpool(x, _t3(mp.kernel_size), _t3(mp.stride), _t3(mp.padding), sole_consumer=True)   # fused with bn1 + ReLU
         layers = (self.layer1, self.layer2, self.layer3, self.layer4)
         for li, layer in enumerate(layers):
             for bi, b in enumerate(layer):
@@ -312,7 +312,7 @@ class ResNet2d3dFull(HipBackbone):
     def emit(self, plan, x):
         x = emit_conv_bn(plan, self.conv1, self.bn1, x)
         mp = self.maxpool
-        x = plan.maxpool(x, _t3(mp.kernel_size), _t3(mp.stride), _t3(mp.padding))
+        x = plan.maxpool(x, _t3(mp.kernel_size), _t3(mp.stride), _t3(mp.padding), sole_consumer=True)   # fused with bn1 + ReLU
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for b in layer:
                 x = b.emit(plan, x)

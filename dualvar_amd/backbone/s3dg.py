@@ -192,7 +192,9 @@ class S3D(HipBackbone):
             return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
         for m in self._sequence():
             if isinstance(m, nn.MaxPool3d):
-                x = plan.maxpool(x, t3(m.kernel_size), t3(m.stride), t3(m.padding))
+                # the network is a chain here: the pool is the only reader of what precedes it (after a conv + BN + ReLU
+                # -- MaxPool_2a, MaxPool_3a -- the engine then fuses the three)
+                x = plan.maxpool(x, t3(m.kernel_size), t3(m.stride), t3(m.padding), sole_consumer=True)
             else:
                 x = m.emit(plan, x)
         return x

@@ -611,6 +611,193 @@ __global__ void maxpool_bwd_kernel(PoolArgs a, const T* __restrict__ dy, const u
   }
 }
 
+// ------------------------------------------------------------------ BatchNorm + ReLU + MaxPool3d as one pass each way
+// A pool that is the ONLY consumer of y = relu(x*scale + shift) (the stems: s3dg.py:138-151, resnet_2d3d.py:128-131) never
+// needs y in memory: the backward of that BatchNorm rebuilds the ReLU mask from x (DV_MASK_FROM_X) and the pool's own
+// backward only needs the tap indices.  Forward: the window elements are normalised, rectified and rounded to the storage
+// type on the fly, exactly the values bn_apply would have stored (same expression, same rounding), so pooled values and
+// indices are bit-identical to the two-pass form.  Backward: g = dL/dy of an input element is the gather of the pooled
+// gradients through idx (maxpool_bwd's inner loop), evaluated inside the reduce and the apply pass of the BatchNorm
+// backward instead of being written and read back twice.  Saved per stem pool: one write + one read of y forward, one
+// write + two reads of dL/dy backward, two launches.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(PoolArgs a, const T* __restrict__ x, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, T* __restrict__ y,
+                                                               uint8_t* __restrict__ idx) {
+  constexpr int V = DT<T>::VEC;
+  const uint32_t CV = a.fcv.d;
+  const uint32_t total = (uint32_t)a.N * a.To * a.Ho * a.Wo * CV;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    uint32_t m, cvi, q, wo_, ho_, to_, n_;
+    fd_divmod(i, a.fcv, m, cvi);
+    const int c0 = (int)cvi * V;
+    fd_divmod(m, a.fWo, q, wo_);
+    fd_divmod(q, a.fHo, q, ho_);
+    fd_divmod(q, a.fTo, n_, to_);
+    const int wo = (int)wo_, ho = (int)ho_, to = (int)to_, n = (int)n_;
+    float sc[V], sh[V];
+    load_params<V>(scale, c0, sc);
+    load_params<V>(shift, c0, sh);
+    float best[V]; int bi[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    bool first = true;
+    int tap = 0;
+    for (int dt = 0; dt < a.kt; ++dt) {
+      const int t = to * a.st - a.pt + dt;
+      for (int dh = 0; dh < a.kh; ++dh) {
+        const int hh = ho * a.sh - a.ph + dh;
+        for (int dw = 0; dw < a.kw; ++dw, ++tap) {
+          const int w = wo * a.sw - a.pw + dw;
+          if ((unsigned)t >= (unsigned)a.Ti || (unsigned)hh >= (unsigned)a.Hi || (unsigned)w >= (unsigned)a.Wi) continue;
+          float v[V];
+          Pack16<T>::load(x + ((int64_t)((n * a.Ti + t) * a.Hi + hh) * a.Wi + w) * a.ldx + c0, v);
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const float yv = DT<T>::to_f(DT<T>::from_f(fmaxf(v[e] * sc[e] + sh[e], 0.f)));     // what bn_apply stores
+            if (first || yv > best[e] || yv != yv) { best[e] = yv; bi[e] = tap; }
+          }
+          first = false;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) if (c0 + e >= a.C) best[e] = 0.f;
+    Pack16<T>::store(y + (size_t)m * a.ldy + c0, best);
+    uint8_t* ip = idx + (size_t)m * a.CP + c0;
+#pragma unroll
+    for (int e = 0; e < V; ++e) ip[e] = (uint8_t)bi[e];
+  }
+}
+
+// g[e] = dL/dy of input element (row m_in, channels c0..c0+V) = sum of the pooled gradients of the windows that chose it
+template <typename T>
+__device__ __forceinline__ void pool_gather(const PoolArgs& a, const T* __restrict__ dyp, const uint8_t* __restrict__ idx,
+                                            uint32_t m_in, int c0, float (&g)[DT<T>::VEC]) {
+  constexpr int V = DT<T>::VEC;
+  uint32_t q, wi_, hi_, ti_, n_;
+  fd_divmod(m_in, a.fWi, q, wi_);
+  fd_divmod(q, a.fHi, q, hi_);
+  fd_divmod(q, a.fTi, n_, ti_);
+  const int wi = (int)wi_, hi = (int)hi_, ti = (int)ti_, n = (int)n_;
+#pragma unroll
+  for (int e = 0; e < V; ++e) g[e] = 0.f;
+  int tap = 0;
+  for (int dt = 0; dt < a.kt; ++dt) {
+    const int tn = ti + a.pt - dt;
+    for (int dh = 0; dh < a.kh; ++dh) {
+      const int hn = hi + a.ph - dh;
+      for (int dw = 0; dw < a.kw; ++dw, ++tap) {
+        const int wn = wi + a.pw - dw;
+        if ((tn | hn | wn) < 0) continue;
+        if ((tn & (a.st - 1)) | (hn & (a.sh - 1)) | (wn & (a.sw - 1))) continue;       // strides are 1 or 2
+        const int to = tn >> (a.st - 1), ho = hn >> (a.sh - 1), wo = wn >> (a.sw - 1);
+        if (to >= a.To || ho >= a.Ho || wo >= a.Wo) continue;
+        const int64_t mo = (int64_t)((n * a.To + to) * a.Ho + ho) * a.Wo + wo;
+        float d[V];
+        Pack16<T>::load(dyp + mo * a.ldy + c0, d);
+        const uint8_t* ip = idx + mo * a.CP + c0;
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (ip[e] == tap) g[e] += d[e];
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void bn_bwd_reduce_maxpool_kernel(PoolArgs a, const T* __restrict__ dyp, const uint8_t* __restrict__ idx,
+                                             const T* __restrict__ x, const float* __restrict__ mean,
+                                             const float* __restrict__ invstd, const float* __restrict__ scale,
+                                             const float* __restrict__ shift, int64_t M, int C, int CP, int64_t rows_per_block,
+                                             float* __restrict__ sums_all, int n_rep) {
+  constexpr int V = DT<T>::VEC;
+  float* sums = sums_all + (size_t)(blockIdx.x % n_rep) * 2 * CP;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(M, r0 + rows_per_block);
+  float mu[V], is[V], sc[V], sh[V];
+  column_reduce<V, 2>(
+      r0, r1, CP,
+      [&](int64_t r, int c0, float(&acc)[2][V]) {
+        float g[V], xx[V];
+        pool_gather<T>(a, dyp, idx, (uint32_t)r, c0, g);
+        Pack16<T>::load(x + r * a.ldx + c0, xx);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float act = xx[e] * sc[e] + sh[e];
+          const float gg = !(act > 0.f) ? 0.f : g[e];
+          acc[0][e] += gg;
+          acc[1][e] += gg * (xx[e] - mu[e]) * is[e];
+        }
+      },
+      [&](int c0, float(&acc)[2][V]) {
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (c0 + e < C) { atomicAdd(sums + c0 + e, acc[0][e]); atomicAdd(sums + CP + c0 + e, acc[1][e]); }
+      },
+      [&](int c0) {
+        load_params<V>(mean, c0, mu);
+        load_params<V>(invstd, c0, is);
+        load_params<V>(scale, c0, sc);
+        load_params<V>(shift, c0, sh);
+      });
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_maxpool_kernel(PoolArgs a, const T* __restrict__ dyp, const uint8_t* __restrict__ idx,
+                                            const T* __restrict__ x, const float* __restrict__ mean,
+                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                            const float* __restrict__ sums_g, int rep_g, float inv_count, float dscale,
+                                            float* dgamma, float* dbeta, T* __restrict__ dx, int lddx, uint32_t total, int C,
+                                            int CP) {
+  constexpr int V = DT<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) float coef[];      // [5][CP]: k1, k2, k3, scale, shift
+  if (blockIdx.x == 0 && dgamma) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float sb = 0.f, sg = 0.f;
+      for (int r = 0; r < rep_g; ++r) { sb += sums_g[(size_t)r * 2 * CP + c]; sg += sums_g[(size_t)r * 2 * CP + CP + c]; }
+      dbeta[c] += dscale * sb;
+      dgamma[c] += dscale * sg;
+    }
+  }
+  for (int c = threadIdx.x; c < CP; c += blockDim.x) {
+    float k1 = 0.f, k2 = 0.f, k3 = 0.f;
+    if (c < C) {
+      float sg = 0.f, sgx = 0.f;
+      for (int r = 0; r < rep_g; ++r) { sg += sums_g[(size_t)r * 2 * CP + c]; sgx += sums_g[(size_t)r * 2 * CP + CP + c]; }
+      k1 = gamma[c] * invstd[c];
+      k2 = -k1 * invstd[c] * sgx * inv_count;
+      k3 = -k1 * sg * inv_count - k2 * mean[c];
+    }
+    coef[c] = k1; coef[CP + c] = k2; coef[2 * CP + c] = k3;
+    coef[3 * CP + c] = c < C ? scale[c] : 0.f; coef[4 * CP + c] = c < C ? shift[c] : 0.f;
+  }
+  __syncthreads();
+  const uint32_t CV = a.fcv.d;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    uint32_t row, cvi;
+    fd_divmod(i, a.fcv, row, cvi);
+    const int c0 = (int)cvi * V;
+    float g[V], xx[V], o[V], k1[V], k2[V], k3[V], sc[V], sh[V];
+    pool_gather<T>(a, dyp, idx, row, c0, g);
+    Pack16<T>::load(x + (size_t)row * a.ldx + c0, xx);
+    load_params<V>(coef, c0, k1);
+    load_params<V>(coef + CP, c0, k2);
+    load_params<V>(coef + 2 * CP, c0, k3);
+    load_params<V>(coef + 3 * CP, c0, sc);
+    load_params<V>(coef + 4 * CP, c0, sh);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float act = xx[e] * sc[e] + sh[e];
+      const float gg = !(act > 0.f) ? 0.f : g[e];
+      o[e] = k1[e] * gg + k2[e] * xx[e] + k3[e];
+    }
+    Pack16<T>::store(dx + (size_t)row * lddx + c0, o);
+  }
+  (void)CV;
+}
+
 // ------------------------------------------------------------------ MaxPool3d 3x3x3, stride 1, padding 1, bf16
 // (the pool branch of every Inception block, s3dg.py:105).  The generic kernels above spend ~6 VALU instructions per
 // tap and element on convert / compare / select-value / select-index and are VALU bound (~1 TB/s).  Here a thread
@@ -1221,6 +1408,60 @@ extern "C" int dv_maxpool3d_bwd(const dv_pool_desc* d, const void* dy, const uin
     const int64_t total = (int64_t)a.N * a.Ti * a.Hi * a.Wi * (a.CP / DT<T>::VEC);
     hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total, 16384)), dim3(kThreads), 0, ST(stream), a, (const T*)dy,
                        idx, (T*)dx, (flags & DV_ACCUM) ? 1 : 0);
+  });
+  return dv_launch_status();
+}
+
+extern "C" int dv_bn_apply_maxpool(const dv_pool_desc* d, const void* x, const float* scale, const float* shift, void* y,
+                                   uint8_t* idx, void* stream) {
+  PoolArgs a;
+  int rc = pool_args(d, a);
+  if (rc) return rc;
+  if (!x || !scale || !shift || !y || !idx) return DV_EINVAL;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(scale) || !aligned16(shift) || (reinterpret_cast<uintptr_t>(idx) & 7)) return DV_EALIGN;
+  DISPATCH_T(d->dtype, {
+    const int64_t total = (int64_t)a.N * a.To * a.Ho * a.Wo * (a.CP / DT<T>::VEC);
+    hipLaunchKernelGGL((bn_apply_maxpool_kernel<T>), dim3(grid_for(total, 16384)), dim3(kThreads), 0, ST(stream), a, (const T*)x,
+                       scale, shift, (T*)y, idx);
+  });
+  return dv_launch_status();
+}
+
+extern "C" int dv_bn_bwd_reduce_maxpool(const dv_pool_desc* d, const void* dy_pool, const uint8_t* idx, const void* x,
+                                        const float* mean, const float* invstd, const float* scale, const float* shift,
+                                        float* sums, int32_t n_rep, void* stream) {
+  PoolArgs a;
+  int rc = pool_args(d, a);
+  if (rc) return rc;
+  if (!dy_pool || !idx || !x || !mean || !invstd || !scale || !shift || !sums || n_rep <= 0) return DV_EINVAL;
+  if (!aligned16(dy_pool) || !aligned16(x) || !aligned16(mean) || !aligned16(invstd) || !aligned16(scale) || !aligned16(shift)) return DV_EALIGN;
+  const int64_t M = (int64_t)a.N * a.Ti * a.Hi * a.Wi;
+  const int blocks = dv_bn_bwd_blocks(M, a.C);
+  const int64_t rpb = (M + blocks - 1) / blocks;
+  DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_reduce_maxpool_kernel<T>), dim3(blocks), dim3(kThreads), 0, ST(stream), a,
+                                          (const T*)dy_pool, idx, (const T*)x, mean, invstd, scale, shift, M, a.C, a.CP, rpb,
+                                          sums, n_rep));
+  return dv_launch_status();
+}
+
+extern "C" int dv_bn_bwd_apply_maxpool(const dv_pool_desc* d, const void* dy_pool, const uint8_t* idx, const void* x,
+                                       const float* mean, const float* invstd, const float* gamma, const float* scale,
+                                       const float* shift, const float* sums_global, int32_t rep_global, float inv_count,
+                                       float dparam_scale, float* dgamma, float* dbeta, void* dx, int32_t lddx, void* stream) {
+  PoolArgs a;
+  int rc = pool_args(d, a);
+  if (rc) return rc;
+  if (!dy_pool || !idx || !x || !mean || !invstd || !gamma || !scale || !shift || !sums_global || !dx || rep_global <= 0) return DV_EINVAL;
+  if ((dgamma == nullptr) != (dbeta == nullptr) || lddx < a.CP) return DV_EINVAL;
+  if (!aligned16(dy_pool) || !aligned16(x) || !aligned16(dx)) return DV_EALIGN;
+  if (5 * a.CP * 4 > 60 * 1024) return DV_EUNSUPPORTED;
+  DISPATCH_T(d->dtype, {
+    constexpr int V = DT<T>::VEC;
+    if (lddx % V) return DV_EALIGN;
+    const int64_t total = (int64_t)a.N * a.Ti * a.Hi * a.Wi * (a.CP / V);
+    hipLaunchKernelGGL((bn_bwd_apply_maxpool_kernel<T>), dim3(grid_for(total, 2048)), dim3(kThreads), 5 * a.CP * sizeof(float),
+                       ST(stream), a, (const T*)dy_pool, idx, (const T*)x, mean, invstd, gamma, scale, shift, sums_global,
+                       rep_global, inv_count, dparam_scale, dgamma, dbeta, (T*)dx, lddx, (uint32_t)total, a.C, a.CP);
   });
   return dv_launch_status();
 }

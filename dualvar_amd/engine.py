@@ -38,6 +38,8 @@ WGRAD_SIDE_STREAM = os.environ.get('DUALVAR_WGRAD_STREAM', '1') != '0'
 SIDE_LAUNCHES = ('conv_wgrad', 'gate_db')
 # side launches issued per main-stream event (the event marker costs the main stream a few microseconds each)
 WGRAD_BATCH = int(os.environ.get('DUALVAR_WGRAD_BATCH', '4'))
+# BatchNorm + ReLU whose only consumer is a max-pool (the stems) run fused with it; '0' keeps the separate passes
+FUSE_BN_POOL = os.environ.get('DUALVAR_FUSE_BN_POOL', '1') != '0'
 
 
 class Slot:
@@ -442,6 +444,8 @@ class Plan:
         """specs: [(bn_module, raw_conv_output, relu, residual_or_None, out_or_None), ...] of mutually independent
         layers -> their outputs.  One statistics exchange for the whole group."""
         op = self._push(BNGroupOp(self, specs))
+        for m in op.members:
+            m.y.bn_member = (op, m)
         return [m.y for m in op.members]
 
     def bn(self, bn_mod, x, relu=True, residual=None, out=None, conv_bias=None):
@@ -452,8 +456,16 @@ class Plan:
         self.ops[-1].members[0].conv_bias = conv_bias
         return ys[0]
 
-    def maxpool(self, x, k, s, p):
-        return self._push(PoolOp(self, x, k, s, p)).y
+    def maxpool(self, x, k, s, p, sole_consumer=False):
+        """sole_consumer: the caller guarantees that nothing else reads x.  If x is then the output of a lone
+        BatchNorm + ReLU, the pair runs fused (dv_bn_apply_maxpool / dv_bn_bwd_*_maxpool): x is never materialised."""
+        member = None
+        if sole_consumer and FUSE_BN_POOL and getattr(x, 'bn_member', None) is not None:
+            op, m = x.bn_member
+            if (len(op.members) == 1 and m.relu and m.res is None and m.conv_bias is None and m.fused_pool is None
+                    and m.y is x and x.off == 0 and (not self.with_grad or m.mask_from_x)):
+                member = m
+        return self._push(PoolOp(self, x, k, s, p, bn_member=member)).y
 
     def gate_group(self, fcs, cat):
         """in-place self gating of a concat buffer: fcs = [(nn.Linear, channel offset, width), ...]"""
@@ -464,11 +476,22 @@ class Plan:
         return self._push(MeanOp(self, x)).out
 
     def finalize(self):
+        for op in self.ops:          # a BatchNorm output fused into its pool does not exist in memory: nobody else may read it
+            if isinstance(op, PoolOp) and op.bn_member is not None:
+                gone = op.bn_member.y
+                for other in self.ops:
+                    if other is op:
+                        continue
+                    readers = [getattr(other, a, None) for a in ('x', 'cat')]
+                    readers += [t for m in getattr(other, 'members', ()) for t in (m.x, m.res)]
+                    assert all(r is None or r.buf is not gone.buf for r in readers), \
+                        'maxpool(sole_consumer=True) on an activation that %s also reads' % type(other).__name__
         # the last consumer (forward order) of an activation is the first writer of its gradient
         seen = set()
         for op in reversed(self.ops):
             for name, a in op.grad_targets():
-                key = (a.buf.data_ptr(), a.off)
+                g = a.grad if a.grad is not None else a      # (an activation fused away has no buffer of its own: key on the gradient)
+                key = (g.buf.data_ptr(), g.off)
                 op.acc[name] = key in seen
                 seen.add(key)
         if self.with_grad and self._zero_words:
@@ -687,6 +710,7 @@ class BNMember:
         # y = relu(x*scale + shift) with nothing added: the backward recomputes the ReLU mask from x (which it reads for
         # xhat anyway) with the forward's expression and never touches y -- 5 tensor passes per BatchNorm instead of 7
         self.conv_bias = None        # Plan.bn(conv_bias=...)
+        self.fused_pool = None       # the PoolOp that consumes y on the fly (Plan.maxpool(sole_consumer=True))
         self.mask_from_x = bool(relu) and residual is None
         self.sums_off = plan.reserve_zero(BN_REPLICAS * 2 * self.CP) if plan.with_grad else 0
         self.sums_len = BN_REPLICAS * 2 * self.CP
@@ -791,6 +815,8 @@ class BNGroupOp(Op):
             if m.conv_bias is not None:          # y = scale*(conv + b) + shift
                 f.append(Launch('bn_bias_shift', 'addcmul', lib.dv_addcmul_f32,
                                 (m.shift.data_ptr(), m.scale.data_ptr(), st.w_master(st.slot(m.conv_bias)), 1.0, m.C)))
+            if m.fused_pool is not None:
+                continue                     # applied by the pool op while it reads its windows
             f.append(Launch('bn_apply', 'bn_apply<%s>' % dt, lib.dv_bn_apply,
                             (p.dtype, x.ptr, x.ld, m.scale.data_ptr(), m.shift.data_ptr(),
                              res.ptr if res is not None else 0, res.ld if res is not None else 0, y.ptr, y.ld, m.M, m.C,
@@ -856,6 +882,10 @@ class BNGroupOp(Op):
                 f_red, f_app = f1, a1        # a lone (large) layer keeps the single-tensor forward kernels (1024-thread stats)
             else:
                 f_fin = [self._fin_multi]
+        if self.members[0].fused_pool is not None:
+            # y = relu(bn(x)) only feeds a max-pool: the pool op applies the BatchNorm while it reads its windows (its
+            # backward writes dL/dy as before; the BatchNorm backward takes the ReLU mask from x, so y itself is never needed)
+            f_app = []
         f = list(f_red)
         b = list(b_red)
         if p.comm.exchange:
@@ -919,8 +949,9 @@ class BNGroupOp(Op):
 
 
 class PoolOp(Op):
-    def __init__(self, plan, x, k, s, p):
+    def __init__(self, plan, x, k, s, p, bn_member=None):
         super().__init__(plan)
+        self.bn_member = bn_member
         self.x = x
         To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
         self.y = plan.act(x.N, To, Ho, Wo, x.C)
@@ -928,6 +959,13 @@ class PoolOp(Op):
         plan.bytes += self.idx.numel()
         self.d = ops.pool_desc(plan.dtype, x, self.y, k, s, p)
         self.need_dx = plan.with_grad and x.grad is not None
+        if bn_member is not None:
+            # forward fused with the BatchNorm + ReLU that produces x: the windows are read from the conv output and
+            # normalised on the fly, x itself is never written (its gradient still is: the BatchNorm backward reads it)
+            bn_member.fused_pool = self
+            self.d_fused = ops.pool_desc(plan.dtype, bn_member.x, self.y, k, s, p)
+            plan.bytes -= x.buf.numel() * x.buf.element_size()
+            x.buf = x.buf.new_empty(0)
 
     def grad_targets(self):
         return [('x', self.x)] if self.need_dx else []
@@ -935,8 +973,14 @@ class PoolOp(Op):
     def launches(self):
         p, lib, x, y = self.plan, self.plan.lib, self.x, self.y
         dt = _dt(p.dtype)
-        f = [Launch('maxpool_fwd', 'maxpool_fwd<%s>' % dt, lib.dv_maxpool3d_fwd,
-                    (C.byref(self.d), x.ptr, y.ptr, self.idx.data_ptr()), _abytes(x) + _abytes(y) + y.rows * x.C)]
+        if self.bn_member is not None:
+            m = self.bn_member
+            f = [Launch('bn_apply_maxpool', 'bn_apply_maxpool<%s>' % dt, lib.dv_bn_apply_maxpool,
+                        (C.byref(self.d_fused), m.x.ptr, m.scale.data_ptr(), m.shift.data_ptr(), y.ptr, self.idx.data_ptr()),
+                        _abytes(x) + _abytes(y) + y.rows * x.C)]
+        else:
+            f = [Launch('maxpool_fwd', 'maxpool_fwd<%s>' % dt, lib.dv_maxpool3d_fwd,
+                        (C.byref(self.d), x.ptr, y.ptr, self.idx.data_ptr()), _abytes(x) + _abytes(y) + y.rows * x.C)]
         b = []
         if self.need_dx:
             acc = bool(self.acc.get('x'))

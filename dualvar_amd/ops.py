@@ -23,7 +23,7 @@ def stream_ptr():
 
 class Act:
     """[N,T,H,W,C] view with row pitch `ld` starting at channel `off` of `buf` ([rows, ld_total])."""
-    __slots__ = ('buf', 'N', 'T', 'H', 'W', 'C', 'ld', 'off', 'dtype', 'grad', 'cpitch', 'producer', 'hw_pad')
+    __slots__ = ('buf', 'N', 'T', 'H', 'W', 'C', 'ld', 'off', 'dtype', 'grad', 'cpitch', 'producer', 'hw_pad', 'bn_member')
 
     def __init__(self, buf, N, T, H, W, C, ld, off, dtype, cpitch=None):
         self.buf, self.N, self.T, self.H, self.W, self.C, self.ld, self.off, self.dtype = buf, N, T, H, W, C, ld, off, dtype
@@ -31,6 +31,7 @@ class Act:
         self.grad = None
         self.producer = None
         self.hw_pad = 0              # zero border (pixels) materialised around H and W (the ingest frames)
+        self.bn_member = None        # (BNGroupOp, BNMember) when this is the output of a BatchNorm (engine.Plan.bn_group)
 
     @property
     def rows(self):

@@ -258,6 +258,21 @@ int dv_maxpool3d_fwd(const dv_pool_desc* d, const void* x, void* y, uint8_t* idx
 /* dx (+)= scatter of dy through idx (gather formulation, deterministic); flags: DV_ACCUM */
 int dv_maxpool3d_bwd(const dv_pool_desc* d, const void* dy, const uint8_t* idx, void* dx, int32_t flags,
                      void* stream);
+/* BatchNorm + ReLU + MaxPool3d in one pass each way, for a pool that is the only consumer of y = relu(x*scale + shift)
+ * (the stems: s3dg.py:138-151, resnet_2d3d.py:128-131): y is never materialised.  d describes the pool (d->ldx = pitch of
+ * the conv output x that the BatchNorm normalises, d->ldy = pitch of the pooled tensor).  Forward: pooled values and tap
+ * indices bit-identical to dv_bn_apply (DV_RELU) followed by dv_maxpool3d_fwd.  Backward: the two passes of the BatchNorm
+ * backward (dv_bn_bwd_reduce / dv_bn_bwd_apply with DV_MASK_FROM_X) with dL/dy gathered from the pooled gradient through
+ * idx on the fly. */
+int dv_bn_apply_maxpool(const dv_pool_desc* d, const void* x, const float* scale, const float* shift, void* y, uint8_t* idx,
+                        void* stream);
+int dv_bn_bwd_reduce_maxpool(const dv_pool_desc* d, const void* dy_pool, const uint8_t* idx, const void* x, const float* mean,
+                             const float* invstd, const float* scale, const float* shift, float* sums, int32_t n_rep,
+                             void* stream);
+int dv_bn_bwd_apply_maxpool(const dv_pool_desc* d, const void* dy_pool, const uint8_t* idx, const void* x, const float* mean,
+                            const float* invstd, const float* gamma, const float* scale, const float* shift,
+                            const float* sums_global, int32_t rep_global, float inv_count, float dparam_scale, float* dgamma,
+                            float* dbeta, void* dx, int32_t lddx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Spatio-temporal mean and broadcast scaling: nn.AdaptiveAvgPool3d((1,1,1)) (simclr.py:44,166,

@@ -376,6 +376,68 @@ def test_batchnorm_fwd_bwd(gpu, dtype, C_, residual, relu):
         close(ops.act_to_ncdhw(dra), rr.grad, dtype, 'dres')
 
 
+@pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
+@pytest.mark.parametrize('k,s,p,shape', [((1, 3, 3), (1, 2, 2), (0, 1, 1), (3, 2, 14, 10)), ((3, 3, 3), (2, 2, 2), (1, 1, 1), (2, 5, 9, 8)),
+                                        ((1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 3, 9, 7))])
+def test_batchnorm_relu_maxpool_fused(gpu, dtype, k, s, p, shape):
+    """dv_bn_apply_maxpool / dv_bn_bwd_*_maxpool == the two-pass form they replace (dv_bn_apply + dv_maxpool3d_fwd;
+    dv_maxpool3d_bwd + dv_bn_bwd_reduce / apply with the mask from x): forward bit for bit, backward up to the order of
+    the fp32 atomics"""
+    from dualvar_amd._lib import DV_MASK_FROM_X
+    N, T, H, W = shape
+    C_ = 72
+    x = q(rnd(N, C_, T, H, W, seed=31) * 2 + 0.3, dtype)
+    M = N * T * H * W
+    CP = ops.cp8(C_)
+    xa = ops.act_from_ncdhw(x.to(gpu), dtype)
+    xs = xa.buf[:, :C_].float()
+    mean_t, var_t = xs.mean(0), xs.var(0, unbiased=False)
+    gamma, beta = 1 + 0.2 * rnd(C_, seed=32).to(gpu), 0.1 * rnd(C_, seed=33).to(gpu)
+
+    def padded(t):
+        o = torch.zeros(CP, device=gpu)
+        o[:C_] = t
+        return o
+    invstd_t = torch.rsqrt(var_t + 1e-5)
+    mean, invstd, gam = padded(mean_t), padded(invstd_t), padded(gamma)
+    scale, shift = padded(gamma * invstd_t), padded(beta - mean_t * gamma * invstd_t)
+    # --- two passes
+    ya = ops.new_act(N, T, H, W, C_, dtype, gpu)
+    ops.call('dv_bn_apply', dtype, xa, xa.ld, scale, shift, None, 0, ya, ya.ld, M, C_, ops.DV_RELU)
+    To, Ho, Wo = ops.conv_out_dims(ya, k, s, p)
+    pa = ops.new_act(N, To, Ho, Wo, C_, dtype, gpu)
+    d = ops.pool_desc(dtype, ya, pa, k, s, p)
+    idx = torch.zeros(pa.rows, CP, dtype=torch.uint8, device=gpu)
+    ops.call('dv_maxpool3d_fwd', d, ya, pa, idx)
+    # --- fused
+    pb = ops.new_act(N, To, Ho, Wo, C_, dtype, gpu)
+    idx2 = torch.zeros_like(idx)
+    d2 = ops.pool_desc(dtype, xa, pb, k, s, p)
+    ops.call('dv_bn_apply_maxpool', d2, xa, scale, shift, pb, idx2)
+    assert torch.equal(pa.buf, pb.buf) and torch.equal(idx[:, :C_], idx2[:, :C_])
+    # --- backward
+    gp = ops.act_from_ncdhw(q(rnd(N, C_, To, Ho, Wo, seed=34), dtype).to(gpu), dtype)
+    dya = ops.new_act(N, T, H, W, C_, dtype, gpu)
+    ops.call('dv_maxpool3d_bwd', d, gp, idx, dya, 0)
+    sums = torch.zeros(4, 2, CP, device=gpu)
+    ops.call('dv_bn_bwd_reduce', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, M, C_, 0, sums, 4)
+    dg, db = torch.zeros(C_, device=gpu), torch.zeros(C_, device=gpu)
+    dxa = ops.new_act(N, T, H, W, C_, dtype, gpu)
+    ops.call('dv_bn_bwd_apply', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, gam, sums, 4, 1.0 / M, 1.0, dg, db,
+             dxa, dxa.ld, None, 0, M, C_, 0)
+    sums2 = torch.zeros(4, 2, CP, device=gpu)
+    ops.call('dv_bn_bwd_reduce_maxpool', d2, gp, idx2, xa, mean, invstd, scale, shift, sums2, 4)
+    dg2, db2 = torch.zeros(C_, device=gpu), torch.zeros(C_, device=gpu)
+    dxb = ops.new_act(N, T, H, W, C_, dtype, gpu)
+    ops.call('dv_bn_bwd_apply_maxpool', d2, gp, idx2, xa, mean, invstd, gam, scale, shift, sums2, 4, 1.0 / M, 1.0, dg2, db2,
+             dxb, dxb.ld)
+    # (bf16: the two-pass form rounds dL/dy to bf16 between the pool and the BatchNorm backward, the fused one does not)
+    close(sums2.sum(0), sums.sum(0), dtype, 'fused bn+pool sums', factor=1 if dtype == DV_BF16 else 5)
+    close(dxb.buf.float(), dxa.buf.float(), dtype, 'fused bn+pool dx', factor=1 if dtype == DV_BF16 else 5)
+    close(dg2, dg, dtype, 'fused bn+pool dgamma', factor=1 if dtype == DV_BF16 else 5)
+    close(db2, db, dtype, 'fused bn+pool dbeta', factor=1 if dtype == DV_BF16 else 5)
+
+
 def test_bn_two_rank_combine(gpu):
     C_, M = 40, 600
     x = rnd(M, C_, seed=11) * 3 + 1
