@@ -86,46 +86,48 @@ class ClipState:
         return t
 
 
-class RandomCrop(object):                                   # transforms.py:201-219
+def _corner(h, w, th, tw):
+    """top-left corner of a th x tw window, rows first: the two `random.randint` draws of the reference's get_params"""
+    top = random.randint(0, h - th)
+    return top, random.randint(0, w - tw)
+
+
+class RandomCrop(object):
+    """transforms.py:201-219: no draw at all when the window already has the requested size"""
+
     def __init__(self, size):
         self.size = size
 
     @staticmethod
     def get_params(hw, output_size):
-        h, w = hw
-        th, tw = output_size
-        if w == tw and h == th:
+        (h, w), (th, tw) = hw, output_size
+        if (h, w) == (th, tw):
             return 0, 0, h, w
-        i = random.randint(0, h - th)
-        j = random.randint(0, w - tw)
-        return i, j, th, tw
+        return _corner(h, w, th, tw) + (th, tw)
 
     def __call__(self, st):
         st.crop(*self.get_params(st.size(), self.size))
         return st
 
 
-class RandomSizedCrop(object):                              # transforms.py:221-247
+class RandomSizedCrop(object):
+    """transforms.py:221-247: up to ten (area fraction in [0.5, 1], aspect in [3/4, 4/3]) proposals -- two uniform draws
+    each, then the corner -- and a plain random crop of the output size when none fits; resized to `size`"""
+
     def __init__(self, size):
         self.size = size
 
     @staticmethod
     def get_params(hw, output_size):
         h, w = hw
-        for attempt in range(10):
-            area = h * w
-            target_area = random.uniform(0.5, 1) * area
-            aspect_ratio = random.uniform(3. / 4, 4. / 3)
-            tw = int(round(math.sqrt(target_area * aspect_ratio)))
-            th = int(round(math.sqrt(target_area / aspect_ratio)))
-            if tw <= w and th <= h:
-                i = random.randint(0, h - th)
-                j = random.randint(0, w - tw)
-                return i, j, th, tw
+        for _ in range(10):
+            target = random.uniform(0.5, 1) * (h * w)
+            aspect = random.uniform(3. / 4, 4. / 3)
+            tw, th = int(round(math.sqrt(target * aspect))), int(round(math.sqrt(target / aspect)))
+            if th <= h and tw <= w:
+                return _corner(h, w, th, tw) + (th, tw)
         th, tw = output_size
-        i = random.randint(0, h - th)
-        j = random.randint(0, w - tw)
-        return i, j, th, tw
+        return _corner(h, w, th, tw) + (th, tw)
 
     def __call__(self, st):
         st.crop(*self.get_params(st.size(), self.size))
@@ -195,18 +197,18 @@ class ColorJitter(object):                                  # transforms.py:313-
 
     @staticmethod
     def _check_input(value, name, center=1, bound=(0, float('inf'))):
+        """a number v means [center - v, center + v]; a pair is taken as is; the identity range means "off" (None)"""
         if isinstance(value, (int, float)):
             if value < 0:
-                raise ValueError('If {} is a single number, it must be non negative.'.format(name))
-            value = [center - value, center + value]
+                raise ValueError('%s: a single number must not be negative' % name)
+            lo, hi = center - value, center + value
         elif isinstance(value, (tuple, list)) and len(value) == 2:
-            if not bound[0] <= value[0] <= value[1] <= bound[1]:
-                raise ValueError('{} values should be between {}'.format(name, bound))
+            lo, hi = value
+            if not bound[0] <= lo <= hi <= bound[1]:
+                raise ValueError('%s range must lie in %s' % (name, (bound,)))
         else:
-            raise TypeError('{} should be a single number or a list/tuple with lenght 2.'.format(name))
-        if value[0] == value[1] == center:
-            value = None
-        return value
+            raise TypeError('%s: a number or a (low, high) pair' % name)
+        return None if lo == hi == center else [lo, hi]
 
     def _draw(self, rng, N):                                # random_adjust_*: transforms.py:165-190
         if self.consistent:
