@@ -149,7 +149,7 @@ def test_two_ranks_equal_one_process(gpu, kind):
 # all_gather_into_tensor, async all-reduce handles, collectives enqueued from the side stream) is run with ONE rank and
 # DUALVAR_FORCE_EXCHANGE=1, which makes the engine and GradSync issue every collective of the multi-GPU step anyway.
 # With one rank the exchanged statistics equal the local ones, so the step must reproduce the plain single-process step.
-def _rccl_worker(port, kind, transport, q):
+def _rccl_worker(port, kind, transport, net, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DUALVAR_FORCE_EXCHANGE='1', DUALVAR_RCCL=transport)
     torch.cuda.set_device(0)
     dev = torch.device('cuda:0')
@@ -159,7 +159,7 @@ def _rccl_worker(port, kind, transport, q):
         from dualvar_amd.optim import SGD
         from dualvar_amd.parallel import GradSync
         from oracle import procedural as P
-        m = getattr(M, kind)(NET, 128, 0.07, True)
+        m = getattr(M, kind)(net, 128, 0.07, True)
         P.procedural_init(m)
         m.set_compute_dtype('fp32').train().to(dev)
         sync = GradSync(bucket_mb=1)
@@ -193,14 +193,15 @@ def _rccl_worker(port, kind, transport, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('kind,transport', [('SimCLR_Naked', 'direct'), ('SimCLR_TimeSeriesV4', 'direct'), ('SimCLR_Naked', 'c10d')])
-def test_rccl_single_rank_rehearsal(gpu, kind, transport):
+@pytest.mark.parametrize('kind,transport,net', [('SimCLR_Naked', 'direct', 'r3d'), ('SimCLR_TimeSeriesV4', 'direct', 'r3d'),
+                                                 ('SimCLR_Naked', 'c10d', 'r3d'), ('SimCLR_Naked', 'direct', 's3dg')])
+def test_rccl_single_rank_rehearsal(gpu, kind, transport, net):
     from dualvar_amd import model as M
     from dualvar_amd.optim import SGD
     from oracle import procedural as P
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    proc = ctx.Process(target=_rccl_worker, args=(29911 + (os.getpid() % 200), kind, transport, q))
+    proc = ctx.Process(target=_rccl_worker, args=(29911 + (os.getpid() % 200), kind, transport, net, q))
     proc.start()
     import queue
     import time
@@ -219,7 +220,7 @@ def test_rccl_single_rank_rehearsal(gpu, kind, transport):
     if kind.endswith('Naked'):
         assert early >= 2, 'no gradient bucket was all-reduced from inside the backward pass'
 
-    m = getattr(M, kind)(NET, 128, 0.07, False)
+    m = getattr(M, kind)(net, 128, 0.07, False)
     P.procedural_init(m)
     m.set_compute_dtype('fp32').train().to(gpu)
     opt = SGD([p for p in m.parameters() if p.requires_grad], lr=0.01, momentum=0.9, weight_decay=1e-4, stores=m.stores())
@@ -246,4 +247,6 @@ def test_rccl_single_rank_rehearsal(gpu, kind, transport):
             ref = v.detach().float().cpu().numpy()
             worst = max(worst, float(np.abs(params[k] - ref).max() / (np.abs(ref).max() + 1e-12)))
     print('parameters after 2 steps: worst rel diff', worst)
-    assert worst < 2e-3
+    # s3dg: plain-vs-plain runs of this B=4 step already differ by several per cent in single gradient tensors (fp32 atomics in
+    # the weight gradients and the self-gating reductions, amplified by the B=4 BatchNorms); the exact check is the first loss
+    assert worst < (2e-2 if net == 's3dg' else 2e-3)
