@@ -14,6 +14,7 @@
 // MFMA: v_mfma_f32_32x32x16_bf16 (bf16 storage) / v_mfma_f32_32x32x2_f32 (f32 parity mode);
 // both share the 32x32 C/D layout  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -1130,10 +1131,24 @@ static void launch_gemm_ns(int bm, int bn, const ConvArgs& a, int grid, hipStrea
   else hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 128, 2, 2, GM, NS>), dim3(grid), dim3(256), 0, s, a);
 }
 
-// Two LDS stages everywhere: with the DMA overlapping the MFMA phase, three to six stages measured equal or slower on
-// every S3D-G layer (they cost resident workgroups, and the K loop is issue bound, not latency bound).
+// Two LDS stages where the grid fills the chip several times over: there three to six stages measured equal or slower
+// (they cost resident workgroups, and the K loop is issue bound).  Launches of at most ~2 workgroups per CU (64-row tiles
+// of the 12 544- and 1 152-row layers) are latency bound instead -- one workgroup per CU waits out every DMA round trip --
+// and get four stages: those layers 252 -> 200 us (1 152 rows) and 581 -> 541 us (12 544 rows) per pass, step 10.53 ->
+// 10.35 ms.  Six stages on the smallest grids add nothing.  DUALVAR_CONV_NS_SMALL / _SMALL_GRID / _TINY_GRID: tuning knobs.
 template <typename T, int MODE, int GVB, int GM>
 static void launch_gemm_gm(int bm, int bn, const ConvArgs& a, int grid, hipStream_t s) {
+  if constexpr (GVB == 16 && sizeof(T) == 2) {
+    static const int ns_small = getenv("DUALVAR_CONV_NS_SMALL") ? atoi(getenv("DUALVAR_CONV_NS_SMALL")) : 4;
+    static const int small_grid = getenv("DUALVAR_CONV_SMALL_GRID") ? atoi(getenv("DUALVAR_CONV_SMALL_GRID")) : 512;
+    if (bm == 64 && grid <= small_grid && ns_small != 2) {
+      static const int tiny_grid = getenv("DUALVAR_CONV_TINY_GRID") ? atoi(getenv("DUALVAR_CONV_TINY_GRID")) : 0;
+      if (grid <= tiny_grid) launch_gemm_ns<T, MODE, GVB, GM, 6>(bm, bn, a, grid, s);
+      else if (ns_small == 3) launch_gemm_ns<T, MODE, GVB, GM, 3>(bm, bn, a, grid, s);
+      else launch_gemm_ns<T, MODE, GVB, GM, 4>(bm, bn, a, grid, s);
+      return;
+    }
+  }
   launch_gemm_ns<T, MODE, GVB, GM, 2>(bm, bn, a, grid, s);
 }
 
@@ -1325,6 +1340,7 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
       aa.w = a; aa.x_bytes = (int)xb; aa.dy_bytes = (int)yb;
       // three stages below 50k rows (fewer resident workgroups there anyway: 690 -> 628 us over the 12 544-row layers of
       // the S3D-G step), two above (1351 vs 1335 / 1392 us with three / four)
+      // (four stages on the 1 152- / 12 544-row layers: no change)
       const int ns = a.M < 50000 ? 3 : 2;
 #define WGD(NS_)                                                                                               \
   do {                                                                                                         \
