@@ -109,6 +109,7 @@ SIGNATURES = {
     'dv_rank_margin': [P, I32, I32, I32, F, F, F, P, P, P, P, P],
     'dv_gemm_f32': [I32, I32, I32, P, I64, I64, P, I64, I64, P, I64, F, I32, P],
     'dv_gemm_f32_grouped': [P, I32, I32, P],
+    'dv_gemm_f32_ex': [P, P],
     'dv_group_mean_f32': [P, I32, I32, I32, P, P],
     'dv_group_mean_bwd_f32': [P, I32, I32, I32, P, P],
     'dv_sgd_momentum': [P, P, P, I64, F, F, F, F, I32, P, P],

@@ -63,23 +63,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
 // reduce through LDS.  A K-contiguous operand is read as two float4 per lane and chunk instead of eight strided
 // dwords.  Within a chunk lane half h multiplies k = chunk + 8h + u (u = 0..7): any pairing works as long as A and B
 // agree, this one makes each lane's eight values contiguous.
-__global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const dv_gemm_desc* __restrict__ descs, int n_groups) {
-  __shared__ float red[3][16][64];
+__device__ __forceinline__ void gemm_tile4_body(const dv_gemm_desc& d, int tile, float (&red)[3][16][64]) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int tile = blockIdx.x;
-  int gi = 0, tstart = 0;
-  {  // independent loads of the first eight prefixes instead of a chain of dependent ones
-    int e[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) e[k] = k < n_groups ? descs[k].tile_end : 0x7fffffff;
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (k < n_groups && tile >= e[k]) { gi = k + 1; tstart = e[k]; }
-    while (gi >= 8 && gi < n_groups && tile >= descs[gi].tile_end) { tstart = descs[gi].tile_end; ++gi; }
-  }
-  if (gi >= n_groups) return;
-  const dv_gemm_desc d = descs[gi];
-  tile -= tstart;
   const int tiles_n = (d.N + 31) / 32;
   const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
   const int l31 = lane & 31, h = lane >> 5;
@@ -156,6 +141,31 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const dv_gemm_des
   }
 }
 
+__global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const dv_gemm_desc* __restrict__ descs, int n_groups) {
+  __shared__ float red[3][16][64];
+  int tile = blockIdx.x;
+  int gi = 0, tstart = 0;
+  {  // independent loads of the first eight prefixes instead of a chain of dependent ones
+    int e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = k < n_groups ? descs[k].tile_end : 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < n_groups && tile >= e[k]) { gi = k + 1; tstart = e[k]; }
+    while (gi >= 8 && gi < n_groups && tile >= descs[gi].tile_end) { tstart = descs[gi].tile_end; ++gi; }
+  }
+  if (gi >= n_groups) return;
+  const dv_gemm_desc d = descs[gi];
+  gemm_tile4_body(d, tile - tstart, red);
+}
+
+// one GEMM, descriptor in the kernel arguments: the same workgroup-per-tile, K-over-four-waves scheme for the single
+// products of the heads and losses (128 x 1024 x 1024: 32 workgroups of one wave per tile walking K = 1024 took 65-70 us)
+__global__ __launch_bounds__(256) void gemm_f32_tile4_kernel(dv_gemm_desc d) {
+  __shared__ float red[3][16][64];
+  gemm_tile4_body(d, (int)blockIdx.x, red);
+}
+
 // Few output tiles, long K (MoCo's dq = dlogits . queue^T: 32 x 128 outputs over K = 65 536 -- four tiles, i.e. four waves
 // walking 4 096 dependent load rounds each: 4 ms): the K range is cut into `splits` slices, one workgroup per (tile,
 // slice), its four waves interleave 16-deep chunks of the slice, reduce through LDS and add alpha * partial to C with
@@ -224,6 +234,14 @@ static int launch_gemm_f32(int M, int N, int K, const float* A, int64_t sam, int
     }
     hipLaunchKernelGGL(gemm_f32_splitk_kernel, dim3(tiles * splits), dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc,
                        alpha, tiles_n, tiles, kslice);
+    return dv_launch_status();
+  }
+  if (tiles <= 1024 && K >= 64) {          // few tiles: one workgroup per tile, K over its four waves
+    dv_gemm_desc d;
+    d.A = A; d.B = B; d.C = C; d.bias = nullptr;
+    d.sam = sam; d.sak = sak; d.sbk = sbk; d.sbn = sbn; d.ldc = ldc;
+    d.M = M; d.N = N; d.K = K; d.flags = accumulate ? DV_ACCUM : 0; d.tile_end = tiles; d.alpha = alpha;
+    hipLaunchKernelGGL(gemm_f32_tile4_kernel, dim3(tiles), dim3(256), 0, s, d);
     return dv_launch_status();
   }
   hipLaunchKernelGGL(gemm_f32_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc,
@@ -425,6 +443,17 @@ extern "C" int dv_gemm_f32(int32_t M, int32_t N, int32_t K, const float* A, int6
                            void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return DV_EINVAL;
   return launch_gemm_f32(M, N, K, A, sam, sak, B, sbk, sbn, C, ldc, alpha, accumulate, ST(stream));
+}
+
+extern "C" int dv_gemm_f32_ex(const dv_gemm_desc* desc_host, void* stream) {
+  if (!desc_host || !desc_host->A || !desc_host->B || !desc_host->C || desc_host->M <= 0 || desc_host->N <= 0 || desc_host->K <= 0)
+    return DV_EINVAL;
+  dv_gemm_desc d = *desc_host;
+  const int64_t tiles = (int64_t)((d.M + 31) / 32) * ((d.N + 31) / 32);
+  if (tiles > 0x7fffffff) return DV_EINVAL;
+  d.tile_end = (int32_t)tiles;
+  hipLaunchKernelGGL(gemm_f32_tile4_kernel, dim3((unsigned)tiles), dim3(256), 0, ST(stream), d);
+  return dv_launch_status();
 }
 
 extern "C" int dv_gemm_f32_grouped(const dv_gemm_desc* descs_dev, int32_t n_groups, int32_t total_tiles, void* stream) {

@@ -52,12 +52,8 @@ class ProjectionHead:
         ws, bs = st.slot(conv.weight), st.slot(conv.bias)
         n, fin, fout = x.shape[0], ws.Cin, ws.Cout
         y = torch.empty(n, fout, dtype=torch.float32, device=x.device)
-        ax = Act(x, n, 1, 1, 1, fin, fin, 0, DV_F32, ws.cin_pitch)
-        ay = Act(y, n, 1, 1, 1, fout, fout, 0, DV_F32, fout)
         assert fin == ws.cin_pitch and fout % 8 == 0, 'head widths must be multiples of 8'
-        d = ops.conv_desc(DV_F32, ax, ay, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=flags | DV_BIAS)
-        _chk(lib.dv_conv3d_fwd(C.byref(d), x.data_ptr(), st.w_master(ws), st.w_master(bs), y.data_ptr(), 0,
-                               ops.stream_ptr()), 'head linear')
+        _linear_fwd(x, st.w_master(ws), ws.cin_pitch, st.w_master(bs), y, n, fin, fout, fout, bool(flags & DV_RELU))
         return y
 
     def _linear_bwd(self, dy, x, conv, need_dx=True):
@@ -286,6 +282,16 @@ def rank_margin(feats_vm, n_series, theta, clip, weight):
 
 # ---------------------------------------------------------------------------------------------------------------
 # downstream classifier head (model/classifier.py:10-70, trained by classifier.py:422-498)
+def _linear_fwd(x, w_ptr, w_pitch, b_ptr, y, n, fin, fout, ldy, relu):
+    """y[n][:fout] = act(x[n][:fin] @ W^T + b), W stored [fout][w_pitch] in the arena: one fp32 MFMA GEMM (a workgroup per 32x32
+    tile, K over its four waves) with bias and ReLU in the epilogue"""
+    d = L.GemmDesc()
+    d.A, d.B, d.C, d.bias = x.data_ptr(), w_ptr, y.data_ptr(), b_ptr
+    d.sam, d.sak, d.sbk, d.sbn, d.ldc = fin, 1, 1, w_pitch, ldy
+    d.M, d.N, d.K, d.flags, d.alpha = n, fout, fin, (DV_RELU if relu else 0), 1.0
+    _chk(_lib().dv_gemm_f32_ex(C.byref(d), ops.stream_ptr()), 'linear fwd')
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x @ W^T + b (+ReLU) with W, b in a ParamStore arena; dW, db accumulate into the gradient arena"""
 
@@ -298,11 +304,9 @@ class _LinearFn(torch.autograd.Function):
         assert fin == ws.cin_pitch, 'linear input widths must be multiples of 8'
         fp = (fout + 7) // 8 * 8
         y = torch.empty(n, fp, dtype=torch.float32, device=x.device)
-        ax = Act(xc, n, 1, 1, 1, fin, fin, 0, DV_F32, fin)
-        ay = Act(y, n, 1, 1, 1, fout, fp, 0, DV_F32, fp)
-        d = ops.conv_desc(DV_F32, ax, ay, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=DV_BIAS | (DV_RELU if relu else 0))
-        _chk(_lib().dv_conv3d_fwd(C.byref(d), xc.data_ptr(), store.w_master(ws), store.w_master(bs), y.data_ptr(), 0,
-                                  ops.stream_ptr()), 'linear fwd')
+        if fp != fout:
+            y[:, fout:].zero_()
+        _linear_fwd(xc, store.w_master(ws), ws.cin_pitch, store.w_master(bs), y, n, fin, fout, fp, relu)
         ctx.store, ctx.lin, ctx.relu = store, lin, relu
         ctx.save_for_backward(xc, y)
         return y[:, :fout]

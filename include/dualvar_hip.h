@@ -362,6 +362,9 @@ typedef struct dv_gemm_desc {
   float alpha;
 } dv_gemm_desc;
 int dv_gemm_f32_grouped(const dv_gemm_desc* descs /*device*/, int32_t n_groups, int32_t total_tiles, void* stream);
+/* ONE such GEMM with its descriptor in HOST memory (passed to the kernel by value; tile_end is ignored): the heads'
+ * Linear / 1x1x1-conv forward with bias and ReLU in the epilogue (simclr.py:45-50,167-180; model/classifier.py:49-62) */
+int dv_gemm_f32_ex(const dv_gemm_desc* desc /*host*/, void* stream);
 /* y[r][d] = mean_g x[r][g][d]  (series-mean vectors of the tc head, simclr.py:297-304 ==
  * <mean_i row_i, mean_j col_j>);  bwd: dx[r][g][d] = dy[r][d]/G */
 int dv_group_mean_f32(const float* x, int32_t R, int32_t G, int32_t D, float* y, void* stream);
