@@ -671,6 +671,33 @@ def test_infonce_against_oracle(gpu, B, K):
     close(dq, qf.grad, DV_F32, 'infonce dq', factor=20)
 
 
+@pytest.mark.parametrize('M,N,K,relu', [(5, 40, 100, True), (128, 1024, 1024, True), (33, 65, 7, False), (128, 128, 1024, False)])
+def test_gemm_ex_bias_relu(gpu, M, N, K, relu):
+    """dv_gemm_f32_ex (descriptor by value: the heads' Linear / 1x1x1 conv forward) == x @ W^T + b (+ReLU) in fp64, with W
+    stored at a wider pitch and C written into a wider buffer"""
+    import ctypes as C
+    from dualvar_amd import _lib as L
+    x, w, b = rnd(M, K, seed=41), rnd(N, K + 8, seed=42), rnd(N, seed=43)
+    want = x.double() @ w[:, :K].double().t() + b.double()
+    if relu:
+        want = want.clamp_min(0)
+    xg, wg, bg = x.to(gpu), w.to(gpu), b.to(gpu)
+    y = torch.full((M, N + 3), 7.0, device=gpu)
+    d = L.GemmDesc()
+    d.A, d.B, d.C, d.bias = xg.data_ptr(), wg.data_ptr(), y.data_ptr(), bg.data_ptr()
+    d.sam, d.sak, d.sbk, d.sbn, d.ldc = K, 1, 1, K + 8, N + 3
+    d.M, d.N, d.K, d.flags, d.alpha = M, N, K, (ops.DV_RELU if relu else 0), 1.0
+    L.check(L.load().dv_gemm_f32_ex(C.byref(d), ops.stream_ptr()), 'dv_gemm_f32_ex')
+    got = y.cpu()
+    assert float((got[:, :N].double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
+    assert float((got[:, N:] - 7.0).abs().max()) == 0.0                        # nothing written beyond N
+    # the plain entry point takes the same kernel for products with few tiles: A^T B form, accumulate
+    acc = torch.ones(K, N, device=gpu)
+    ops.call('dv_gemm_f32', K, N, M, xg, 1, K, (xg @ wg[:, :K].t()).contiguous(), N, 1, acc, N, 0.5, 1)
+    ref = 1.0 + 0.5 * (x.double().t() @ (x.double() @ w[:, :K].double().t()))
+    assert float((acc.cpu().double() - ref).abs().max()) <= 5e-5 * float(ref.abs().max()) + 1e-6
+
+
 def test_sgd_and_ema(gpu):
     n = 1003
     p0, g = rnd(n, seed=25), rnd(n, seed=26)
