@@ -12,6 +12,8 @@ One "step" = ingest + forward + NT-Xent + backward + (gradient all-reduce) + SGD
   cpu_baseline : the CPU oracle (oracle/torch_ref.py, validated == the reference) timed on this host on a bounded
                  sample of the same workload.
 """
+import os as _os
+_os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')   # kernel arguments in device memory: -4 % step time (read when HIP loads)
 import argparse
 import json
 import os

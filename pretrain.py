@@ -16,6 +16,8 @@ What differs, deliberately:
   * accuracy meters read the positive's rank emitted by the loss kernels (no topk launch, no extra sync):
     all scalars of a step come back in ONE device->host copy.
 """
+import os as _os
+_os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')   # kernel arguments in device memory: -4 % step time (read when HIP loads)
 import argparse
 import os
 import random
