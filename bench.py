@@ -162,12 +162,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     # DUALVAR_FORCE_EXCHANGE=1: rehearse the multi-GPU step (every RCCL collective issued) with one rank on a 1-GPU box
     distributed = world > 1 or os.environ.get('DUALVAR_FORCE_EXCHANGE') == '1'
+    if os.environ.get('DUALVAR_BENCH_BACKEND'):      # rehearsal of the N > 1 flow on a 1-GPU box: ranks share the device (gloo)
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get('DUALVAR_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from dualvar_amd.optim import SGD
     from dualvar_amd.parallel import GradSync
