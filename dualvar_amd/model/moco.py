@@ -19,6 +19,7 @@ from .. import functional as DF
 from .. import ops
 from ..backbone.select_backbone import select_backbone
 from ..engine import ParamStore
+from ..utils.transforms import FrameBatch
 from ..utils.utils import concat_all_gather
 from .simclr import _Objective, _proj_modules
 
@@ -226,7 +227,7 @@ class MoCo_TimeSeriesV4(_MoCoBase):
         perm = np.array([np.random.permutation(s) for _ in range(B)])              # moco.py:544-546
         # one backbone pass over [aug_x1 ; shuffled aug_x1] (2B clips), exactly as the reference batches it
         aug = block[:, 2]
-        dual = torch.cat([aug, aug], dim=0)
+        dual = FrameBatch.cat([aug, aug]) if isinstance(aug, FrameBatch) else torch.cat([aug, aug], dim=0)
         ident = np.tile(np.arange(s), (B, 1))
         dp = bq.forward_pooled(dual, perm=np.concatenate([ident, perm], axis=0))
         dsf = DF.l2_normalize(self._series_q(dp).view(2 * B, s, sd))

@@ -49,12 +49,61 @@ class SGD(torch.optim.Optimizer):
                          lr, mu, wd, scale, st.dtype, (copy.data_ptr() + es * a) if copy is not None else None)
             st.mark_dirty(cast_done=True)
 
+    def _momentum_views(self):
+        """[(index in torch's flat parameter order, momentum view shaped like the parameter)] for every parameter that
+        lives in one of the arenas"""
+        where = {}
+        for st in self.stores:
+            if st.master is None:
+                continue
+            buf = self._momentum_buf(st)
+            for s in st.slots:
+                where[id(s.tensor)] = st._view(buf, s)
+        out, i = [], 0
+        for g in self.param_groups:
+            for p in g['params']:
+                if id(p) in where:
+                    out.append((i, where[id(p)]))
+                i += 1
+        return out
+
     def state_dict(self):
-        return {'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups],
-                'momentum_arenas': [self._momentum_buf(st).detach().cpu() for st in self.stores if st.master is not None]}
+        """torch.optim.SGD's format (pretrain.py:343-349 stores it in the checkpoint; `--resume` feeds it back):
+        param_groups with flat parameter indices, state[i]['momentum_buffer'] shaped like parameter i."""
+        groups, i = [], 0
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != 'params'}
+            d['params'] = list(range(i, i + len(g['params'])))
+            i += len(g['params'])
+            groups.append(d)
+        state = {i: {'momentum_buffer': v.detach().cpu().clone()} for i, v in self._momentum_views()}
+        return {'state': state, 'param_groups': groups}
 
     def load_state_dict(self, sd):
+        """Accepts torch.optim.SGD state (the reference's checkpoints) and this class's own; returns the number of
+        momentum buffers restored and warns when some are missing (a silent cold restart of the momentum is a
+        different training run)."""
+        import warnings
         for g, s in zip(self.param_groups, sd['param_groups']):
-            g.update(s)
-        for st, b in zip([s for s in self.stores if s.master is not None], sd.get('momentum_arenas', [])):
-            self._momentum_buf(st).copy_(b)
+            g.update({k: v for k, v in s.items() if k != 'params'})
+        restored, views = 0, self._momentum_views()
+        if 'momentum_arenas' in sd:                         # round-1 format: one flat arena per store
+            for st, b in zip([s for s in self.stores if s.master is not None], sd['momentum_arenas']):
+                self._momentum_buf(st).copy_(b)
+            return len(views)
+        state = sd.get('state', {})
+        with torch.no_grad():
+            for i, v in views:
+                e = state.get(i, state.get(str(i)))
+                mb = None if e is None else e.get('momentum_buffer')
+                if mb is None:
+                    v.zero_()
+                    continue
+                if tuple(mb.shape) != tuple(v.shape):
+                    raise ValueError('momentum_buffer %d has shape %s, parameter has %s' % (i, tuple(mb.shape), tuple(v.shape)))
+                v.copy_(mb.to(device=v.device, dtype=v.dtype))
+                restored += 1
+        if restored != len(views):
+            warnings.warn('optimizer state: %d of %d momentum buffers restored, the rest start at zero'
+                          % (restored, len(views)))
+        return restored

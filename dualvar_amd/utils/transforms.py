@@ -304,6 +304,20 @@ class FrameBatch(object):
 
     view = reshape
 
+    @staticmethod
+    def cat(batches, dim=0):
+        """torch.cat(..., dim=0) for frame batches over the SAME decoded frames: the augmentation tables are
+        concatenated, no pixel is copied (MoCo_TimeSeriesV4 feeds [aug_x1 ; aug_x1] through one backbone pass,
+        moco.py:551-556)."""
+        if dim != 0:
+            raise NotImplementedError('FrameBatch.cat joins the leading dimension only')
+        first = batches[0]
+        for b in batches[1:]:
+            if b.frames.data_ptr() != first.frames.data_ptr() or tuple(b.shape[1:]) != tuple(first.shape[1:]):
+                raise ValueError('FrameBatch.cat: batches must share their frames and per-sample shape')
+        table = torch.cat([b.table.view(-1) for b in batches])
+        return FrameBatch(first.frames, table, (sum(b.shape[0] for b in batches),) + tuple(first.shape[1:]))
+
     def __getitem__(self, idx):
         # block[:, v]: one view of every sample
         if isinstance(idx, tuple) and len(idx) == 2 and idx[0] == slice(None) and isinstance(idx[1], int) and self.dim() == 6:

@@ -193,7 +193,7 @@ def main_worker(gpu, ngpus_per_node, args):
     else:
         args.rank, args.gpu = 0, (args.gpu if args.gpu is not None else 0)
         torch.cuda.set_device(args.gpu)
-    args.print = args.gpu == 0 if not args.distributed else args.rank == 0
+    args.print = is_printing_rank(args.distributed, args.rank)
     args.img_path, args.model_path, args.exp_path = set_path(args)
     args.logger = DistLogger(os.path.join(args.exp_path, 'log.txt'), args.print)
     args.iteration = 1
@@ -217,16 +217,18 @@ def main_worker(gpu, ngpus_per_node, args):
     loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
                                          num_workers=min(args.workers, 4), pin_memory=True, drop_last=True)
 
+    best_acc = 0
     if args.resume and os.path.isfile(args.resume):
         ck = torch.load(args.resume, map_location='cpu', weights_only=True)
-        args.start_epoch, args.iteration = ck['epoch'], ck.get('iteration', 1)
+        args.start_epoch, args.iteration, best_acc = resume_position(ck)
         try:
             model.load_state_dict(ck['state_dict'])
         except Exception:
             neq_load_customized(model, ck['state_dict'], verbose=True, args=args)
         if 'optimizer' in ck:
             try:
-                optimizer.load_state_dict(ck['optimizer'])
+                n = optimizer.load_state_dict(ck['optimizer'])
+                args.logger.info('optimizer state restored (%d momentum buffers)' % n)
             except Exception as e:
                 args.logger.info('optimizer state not restored: %s' % e)
     elif args.pretrain and os.path.isfile(args.pretrain):
@@ -235,7 +237,6 @@ def main_worker(gpu, ngpus_per_node, args):
 
     scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=args.schedule, gamma=0.1,
                                                      last_epoch=args.start_epoch - 1)
-    best_acc = 0
     for epoch in range(args.start_epoch, args.epochs):
         if sampler is not None:
             sampler.set_epoch(epoch)
@@ -245,7 +246,7 @@ def main_worker(gpu, ngpus_per_node, args):
         if (epoch % args.save_freq == 0 or epoch == args.epochs - 1) and args.print:
             is_best = train_acc > best_acc
             best_acc = max(train_acc, best_acc)
-            save_checkpoint({'epoch': epoch + 1, 'state_dict': model.state_dict(), 'best_acc': best_acc,
+            save_checkpoint({'epoch': epoch, 'state_dict': model.state_dict(), 'best_acc': best_acc,
                              'optimizer': optimizer.state_dict(), 'iteration': args.iteration}, is_best,
                             gap=args.save_freq, filename=os.path.join(args.model_path, 'epoch%d.pth.tar' % epoch),
                             keep_all=True)
@@ -255,6 +256,17 @@ def main_worker(gpu, ngpus_per_node, args):
         from dualvar_amd import rccl
         rccl.destroy_all()
         dist.destroy_process_group()
+
+
+def is_printing_rank(distributed, rank):
+    """pretrain.py:225 (`args.print = args.gpu == 0 or not args.distributed`): the process that logs and saves
+    checkpoints -- rank 0 of a distributed job; a single-process run always, whatever --gpu it was given."""
+    return (rank == 0) if distributed else True
+
+
+def resume_position(ck):
+    """pretrain.py:290-292,343: a checkpoint's 'epoch' is the LAST FINISHED epoch -> (start_epoch, iteration, best_acc)"""
+    return int(ck['epoch']) + 1, ck.get('iteration', 1), float(ck.get('best_acc', 0))
 
 
 def train_one_epoch(data_loader, model, optimizer, scheduler, transforms_cuda, epoch, args,

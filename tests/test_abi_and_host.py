@@ -179,6 +179,63 @@ def test_checkpoint_interchange_with_reference_format(tmp_path):
     neq_load_customized(M.SimCLR_TimeSeriesV4('s3dg', 128, 0.07, False), sub, verbose=False)
 
 
+def test_pretrain_host_flags_follow_the_reference():
+    """pretrain.py:225 / :290-292,343 -- who logs and saves, and where a resumed run starts"""
+    import importlib
+    pt = importlib.import_module('pretrain')
+    assert pt.is_printing_rank(False, 0) and pt.is_printing_rank(True, 0) and not pt.is_printing_rank(True, 3)
+    # a single-process run on --gpu 1 still logs and saves its checkpoints (args.rank is 0 there, but so would any rank be)
+    assert pt.is_printing_rank(False, 5)
+    # the reference saves 'epoch' = the epoch just finished and resumes at the next one
+    assert pt.resume_position({'epoch': 4, 'iteration': 77, 'best_acc': 0.5}) == (5, 77, 0.5)
+    assert pt.resume_position({'epoch': 0}) == (1, 1, 0.0)
+
+
+def test_optimizer_state_interchange_with_torch_sgd():
+    """The checkpoint's 'optimizer' entry is torch.optim.SGD's state_dict in the reference (pretrain.py:343-349): ours
+    has the same format, a torch state loads into the momentum arena through the parameter views, and back."""
+    import warnings
+    import torch
+    from dualvar_amd import model as M
+    from dualvar_amd.ops import DV_F32
+    from dualvar_amd.optim import SGD
+    from oracle import procedural as P, torch_ref as O
+    ref = O.SimCLR_Naked('r3d', 128, 0.07, False)
+    P.procedural_init(ref)
+    rparams = [p for p in ref.parameters() if p.requires_grad]
+    ropt = torch.optim.SGD([{'params': [p]} for p in rparams], lr=0.003, momentum=0.9, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(5)
+    for p in rparams:
+        p.grad = torch.randn(p.shape, generator=g)
+    ropt.step()                                              # creates the momentum buffers
+    ropt.param_groups[0]['lr'] = 0.0003                      # e.g. after a MultiStepLR milestone
+    mine = M.SimCLR_Naked('r3d', 128, 0.07, False)
+    for st in mine.stores():
+        st.materialize(torch.device('cpu'), DV_F32)
+    mparams = [p for p in mine.parameters() if p.requires_grad]
+    assert [tuple(p.shape) for p in mparams] == [tuple(p.shape) for p in rparams]
+    opt = SGD([{'params': [p]} for p in mparams], lr=0.003, momentum=0.9, weight_decay=1e-4, stores=mine.stores())
+    assert opt.load_state_dict(ropt.state_dict()) == len(rparams)
+    assert opt.param_groups[0]['lr'] == 0.0003 and opt.param_groups[1]['lr'] == 0.003
+    views = dict(opt._momentum_views())
+    for i, p in enumerate(rparams):
+        assert torch.equal(views[i], ropt.state[p]['momentum_buffer']), i
+    # ... and back: torch's SGD takes our state_dict
+    sd = opt.state_dict()
+    assert set(sd) == {'state', 'param_groups'} and sd['param_groups'][3]['params'] == [3]
+    ropt2 = torch.optim.SGD([{'params': [p]} for p in rparams], lr=0.1, momentum=0.9, weight_decay=1e-4)
+    ropt2.load_state_dict(sd)
+    for p in rparams:
+        assert torch.equal(ropt2.state[p]['momentum_buffer'], ropt.state[p]['momentum_buffer'])
+    # a state without momentum (fresh torch optimizer) is loaded with a warning, not silently
+    fresh = torch.optim.SGD([{'params': [p]} for p in rparams], lr=0.1, momentum=0.9).state_dict()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        assert opt.load_state_dict(fresh) == 0
+    assert any('momentum buffers restored' in str(x.message) for x in w)
+    assert all(float(v.abs().sum()) == 0.0 for v in dict(opt._momentum_views()).values())
+
+
 def test_backward_list_reorder_hides_syncbn_exchange_behind_weight_gradients():
     """engine.overlap_bn_exchange: wgrads issued since the previous exchange move between START and WAIT; everything
     else keeps its relative order (dgrad -> bn reduce -> START -> [wgrads] -> WAIT -> bn apply)."""

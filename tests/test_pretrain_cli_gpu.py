@@ -16,7 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                    ['--dataset', 'synthetic-frames', '--model', 'simclr_naked', '--num_seq', '2', '--rand_flip',
                                     '--aug_temp_consist'],
                                    ['--dataset', 'synthetic', '--model', 'moco_naked', '--num_seq', '2', '--moco-k', '1024',
-                                    '--dtype', 'fp32']])
+                                    '--dtype', 'fp32'],
+                                   # uint8 frames through the dual-head objectives (segment shuffle on a FrameBatch, and
+                                   # MoCo's [aug ; aug] pass = FrameBatch.cat)
+                                   ['--dataset', 'synthetic-frames', '--model', 'simclr_timeseriesv4', '--num_seq', '3'],
+                                   ['--dataset', 'synthetic-frames', '--model', 'moco_timeseriesv4', '--num_seq', '3',
+                                    '--moco-k', '1024']])
 def test_pretrain_script_runs(gpu, extra, tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, 'pretrain.py'), '--net', 'r3d', '--batch_size', '8', '--seq_len', '8', '--img_dim', '64',
            '--steps', '4', '--epochs', '1', '--epoch_size', '64', '--print_freq', '1', '-j', '0', '--prefix', 't'] + extra
