@@ -53,6 +53,7 @@ class GemmDesc(C.Structure):
 
 
 P, I32, I64, F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+RETURNS_INT64 = ('dv_conv3d_wgrad_workspace',)       # everything else returns int
 CD, PD = C.POINTER(ConvDesc), C.POINTER(PoolDesc)
 
 # name -> argtypes, exactly as declared in include/dualvar_hip.h
@@ -64,7 +65,9 @@ SIGNATURES = {
     'dv_conv3d_tile_shape': [CD, I32, P, P],
     'dv_conv3d_fwd': [CD, P, P, P, P, P, P],
     'dv_conv3d_dgrad': [CD, P, P, P, P],
-    'dv_conv3d_wgrad': [CD, P, P, P, P],
+    'dv_conv3d_wgrad_workspace': [CD],
+    'dv_conv3d_wgrad_tile': [CD, P, P, P],
+    'dv_conv3d_wgrad': [CD, P, P, P, P, I64, P],
     'dv_pack_dgrad_weights': [I32, P, P, P, P, I32, P],
     'dv_cast_arena': [I32, P, P, I64, P],
     'dv_ingest_ncdhw': [I32, P, P, I32, I32, I32, I32, I32, I64, I32, P, P, P, I32, P],
@@ -139,7 +142,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI and this table disagree
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name in RETURNS_INT64 else C.c_int
     if lib.dv_abi_version() != 1:
         raise DualVarHipError('libdualvar_hip.so ABI version mismatch')
     _lib = lib

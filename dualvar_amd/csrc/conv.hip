@@ -14,6 +14,7 @@
 // MFMA: v_mfma_f32_32x32x16_bf16 (bf16 storage) / v_mfma_f32_32x32x2_f32 (f32 parity mode);
 // both share the 32x32 C/D layout  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include "common.hpp"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -676,18 +677,68 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
 }
 
 // ------------------------------------------------------------------------------------------
-// wgrad kernel.  Each workgroup owns a BI (output channels) x BJ (im2col columns) tile of dW
-// and a contiguous slice of rows; 32 rows per step.  Partial results are added with fp32 atomics.
+// wgrad kernels.  Each workgroup owns a BI (output channels) x BJ (im2col columns) tile of dW and a contiguous slice of
+// rows (a "row split"); 32 rows per step.  DETERMINISTIC two-phase accumulation: a workgroup stores its fp32 partial
+// tile with plain stores into slab[split] (caller-owned scratch, [splits][Cout][J]) and wgrad_reduce_kernel adds the
+// slabs to dW in a fixed order -- no float atomics (their order changed results from run to run, and at ~1.3 TB/s
+// chip-wide they were ~40 % of a mid-size launch).  With one split the tile is added to dW directly.
 struct WgradArgs {
   const void* x;
   const void* dy;
   float* dw;
+  float* slab;            // [splits][slab_stride] partial sums, or nullptr (splits == 1: dW += tile)
+  long long slab_stride;  // elements between consecutive splits (>= Cout * ldw)
   int M, Cout, CoutP, J;  // rows, output channels (padded), J = taps*CP
   int ldx, ldy, ldw;
   int nti, ntj;
   int rows_per_split;
   ConvGeom g;
 };
+
+// one 32x32 accumulator block -> slab / dW.  Per register a half wave stores 32 consecutive floats (128 B).
+__device__ __forceinline__ void wgrad_store_block(const WgradArgs& a, int split, int row0, int col, int h, const f32x16& acc) {
+  if (col >= a.J) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (row < a.Cout) {
+      const size_t e = (size_t)row * a.ldw + col;
+      if (a.slab) a.slab[(size_t)split * a.slab_stride + e] = acc[r];
+      else a.dw[e] += acc[r];
+    }
+  }
+}
+
+// dW[e] += sum_s slab[s][e], s ascending inside each of the 16 interleaved groups, groups combined in ascending order:
+// a fixed summation tree, so the result does not depend on scheduling.  Thread (cx, sg) of a block sums slabs
+// sg, sg+16, ... of float4 column blockIdx*16 + cx (16 lanes = 256 contiguous bytes per slab).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, long long stride, int splits,
+                                                           float* __restrict__ dw, long long n4) {
+  __shared__ f32x4 part[16][17];
+  const int cx = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const long long c = (long long)blockIdx.x * 16 + cx;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+  if (c < n4) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(slab) + c;
+    const long long st4 = stride / 4;
+    int s = sg;
+    for (; s + 48 < splits; s += 64) {                 // four independent loads in flight
+      const f32x4 v0 = p[(long long)s * st4], v1 = p[(long long)(s + 16) * st4], v2 = p[(long long)(s + 32) * st4],
+                  v3 = p[(long long)(s + 48) * st4];
+      s0 += v0; s0 += v1; s0 += v2; s0 += v3;
+    }
+    for (; s < splits; s += 16) s0 += p[(long long)s * st4];
+  }
+  part[sg][cx] = s0;
+  __syncthreads();
+  if (sg == 0 && c < n4) {
+    f32x4* d = reinterpret_cast<f32x4*>(dw) + c;
+    f32x4 t = part[0][cx];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) t += part[g][cx];
+    *d = *d + t;
+  }
+}
 
 // smallest 16-byte-multiple pitch >= bytes with pitch mod 256 in {64, 192}: four consecutive rows of a
 // ds_read_b64_tr_b16 block then fall on four different 64-byte bank groups
@@ -850,34 +901,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      const int col = j0 + wj0 + j * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i0 + wi0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < a.Cout && col < a.J) atomicAdd(a.dw + (size_t)row * a.ldw + col, acc[i][j][r]);
-      }
-    }
+    for (int j = 0; j < TJ; ++j)
+      wgrad_store_block(a, split, i0 + wi0 + i * 32, j0 + wj0 + j * 32 + l31, h, acc[i][j]);
 }
 
 
 // ------------------------------------------------------------------------------------------
-// bf16 wgrad with global -> LDS DMA gathers (16-byte vectors; the RGB stem and the f32 parity mode keep the
-// register-staged kernel above).  Differences from it:
+// wgrad with global -> LDS DMA gathers (16-byte vectors; bf16 and f32).  The 8-byte-gather case keeps the
+// register-staged kernel above.  Differences from it:
 //  * both tiles are UNPADDED row-linear LDS images filled by buffer_load ... lds (one wave instruction = 1 KiB), so no
-//    VGPR staging and no ds_write; the bank conflicts of the transposed fragment reads (4 rows x 64 B per half wave)
-//    are removed by XOR-swizzling the 64-byte chunk index with the row (row&3 for 256-byte rows, (row>>1)&1 for
-//    128-byte rows), applied on the source side (which column slot a lane fetches) and on the read side;
-//  * a row's im2col coordinates are decoded ONCE per workgroup (not once per 16-byte vector): each wave decodes 64 of
+//    VGPR staging and no ds_write.  bf16 reads them transposed (ds_read_b64_tr_b16); the bank conflicts of those reads
+//    (4 rows x 64 B per half wave) are removed by XOR-swizzling the 64-byte chunk index with the row (row&3 for 256- and
+//    512-byte rows, (row>>1)&1 for 128-byte rows), applied on the source side (which column slot a lane fetches) and on
+//    the read side.  f32 reads one dword per lane along a row (conflict free as it is);
+//  * a row's im2col coordinates are decoded ONCE per workgroup (not once per 16-byte vector): each thread decodes one of
 //    the next 256 rows into an LDS table {byte offset of the row's first tap, separable tap-validity masks}; a lane's
 //    column slot -- hence its tap and channel -- is fixed for the whole kernel, so the per-step address is
-//    table.offset + constant, or an out-of-range offset (hardware zero fill) when the tap falls into the padding.
+//    table.offset + constant, or an out-of-range offset (hardware zero fill) when the tap falls into the padding;
+//  * wave tiles are 64 x 64 (2 x 2 MFMA blocks: 8 MFMAs per 32-row step and wave instead of 4, for the same barrier),
+//    workgroup tiles 128 x 128 or 64 x 256 (f32: 64 x 128 with 32 x 64 wave tiles): half the dY / im2col re-reads of
+//    the 128 x 64 tiles this replaces.
 struct WgradDmaArgs {
   WgradArgs w;
   int x_bytes, dy_bytes;
 };
 
-template <int RB> __device__ __forceinline__ int wg_swz(int row) { return RB == 256 ? (row & 3) : ((row >> 1) & 1); }
+// rows of RB bytes: four consecutive rows must fall on four different 64-byte bank groups of the 256-byte LDS line
+// (RB a multiple of 256: XOR the 64-byte chunk index with row&3; RB = 128 mod 256, i.e. 128 or 384: rows 0/1 already
+// differ by 128 bytes, XOR chunk bit 0 with (row>>1)&1)
+template <int RB> __device__ __forceinline__ int wg_swz(int row) { return (RB % 256) ? ((row >> 1) & 1) : (row & 3); }
 
 template <int RB>
 __device__ __forceinline__ bf16x8 wg_frag(const unsigned char* tile, int col0, int lane, int ks) {
@@ -893,19 +945,37 @@ __device__ __forceinline__ bf16x8 wg_frag(const unsigned char* tile, int col0, i
 }
 
 // NS: LDS stages -- tiles s+1 .. s+NS-1 are in flight while tile s is multiplied (counted vmcnt; every wave issues the
-// same NPW + NQW pieces per tile)
-template <int BI, int BJ, int NS>
-__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradDmaArgs aa) {
+// same NPW + NQW pieces per tile).  WVI x WVJ waves, each a 64 x 64 tile of dW.
+// workgroups per CU the LDS footprint admits (<= 3), and the waves per SIMD that makes (the register allocator is
+// asked to make room for them)
+constexpr int wgrad_wgs_per_cu(int es, int bi, int bj, int nw, int ns) {
+  const int lds = ns * 32 * (bi + bj) * es + 16 * nw * 64;
+  const int by_lds = 163840 / lds, by_waves = 32 / nw;
+  const int k = by_lds < by_waves ? by_lds : by_waves;
+  return k >= 3 ? 3 : (k >= 2 ? 2 : 1);
+}
+constexpr int wgrad_waves_per_simd(int es, int bi, int bj, int nw, int ns) {
+  return (wgrad_wgs_per_cu(es, bi, bj, nw, ns) * nw + 3) / 4;
+}
+
+template <typename T, int BI, int BJ, int WVI, int WVJ, int NS>
+__global__ __launch_bounds__(WVI * WVJ * 64)
+__attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI * WVJ, NS)))) void conv_wgrad_dma_kernel(WgradDmaArgs aa) {
   const WgradArgs& a = aa.w;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int EPV = 16 / ES;                       // elements per 16-byte DMA slot
   constexpr int ROWS = 32;
-  constexpr int RBP = BI * 2, RBQ = BJ * 2;          // row bytes of the dY (P) and im2col (Q) tiles
-  static_assert((RBP == 128 || RBP == 256) && (RBQ == 128 || RBQ == 256), "swizzle covers 128/256-byte rows");
+  constexpr int NW = WVI * WVJ, NT = NW * 64;
+  constexpr int RBP = BI * ES, RBQ = BJ * ES;        // row bytes of the dY (P) and im2col (Q) tiles
+  static_assert(RBP % 128 == 0 && RBQ % 128 == 0, "row bytes (swizzle, 1 KiB DMA pieces)");
   constexpr int DP = RBP / 16, DQ = RBQ / 16;        // 16-byte slots per row
   constexpr int QOFF = ROWS * RBP, BUFB = ROWS * (RBP + RBQ);
-  constexpr int NPW = (QOFF / 1024) / 4, NQW = ((BUFB - QOFF) / 1024) / 4;    // DMA instructions per wave and step
-  static_assert(NPW >= 1 && NQW >= 1, "tile");
-  constexpr int RT = 256;                            // rows per decode round (8 steps)
-  constexpr int WI = BI / 2, WJ = BJ / 2, TI = WI / 32, TJ = WJ / 32;
+  constexpr int PPC = QOFF / 1024, QPC = (BUFB - QOFF) / 1024;                   // 1 KiB DMA pieces per tile
+  constexpr int NPW = (PPC + NW - 1) / NW, NQW = (QPC + NW - 1) / NW;             // ... per wave (the last round may be partial)
+  constexpr int RT = NT;                             // rows per decode round: one row per thread
+  constexpr int SPR = RT / ROWS;                     // steps per round
+  constexpr int WI = BI / WVI, WJ = BJ / WVJ, TI = WI / 32, TJ = WJ / 32;
+  static_assert(TI >= 1 && TJ >= 1, "wave tile");
   constexpr unsigned kOOB = 0x80000000u;
 
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * BUFB];
@@ -919,47 +989,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradDmaArgs aa) {
   const int tile_i = bid % a.nti;
   const int split = bid / a.nti;
   const int i0 = tile_i * BI, j0 = tile_j * BJ;
-  const int wi0 = (wave >> 1) * WI, wj0 = (wave & 1) * WJ;
+  const int wi0 = (wave / WVJ) * WI, wj0 = (wave % WVJ) * WJ;
   const int m_begin = split * a.rows_per_split;
-  const int m_end = min(a.M, m_begin + a.rows_per_split);
-  if (m_begin >= m_end) return;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);      // (the host sizes the splits so that none is empty)
 
   const dma_rsrc_t x_rsrc = dma_make_rsrc(a.x, (unsigned)aa.x_bytes), dy_rsrc = dma_make_rsrc(a.dy, (unsigned)aa.dy_bytes);
   const unsigned smem_base = lds_addr(smem);
-  const unsigned ldxb = (unsigned)a.ldx * 2, ldyb = (unsigned)a.ldy * 2;
+  const unsigned ldxb = (unsigned)a.ldx * ES, ldyb = (unsigned)a.ldy * ES;
 
   // fixed per-lane roles: LDS slot -> (row, swizzled source column)
   int prow[NPW]; unsigned pcolb[NPW];
 #pragma unroll
   for (int u = 0; u < NPW; ++u) {
-    const int sl = (wave + 4 * u) * 64 + lane;
+    const int sl = (wave + NW * u) * 64 + lane;
     prow[u] = sl / DP;
-    const int jj = (sl % DP) ^ (wg_swz<RBP>(prow[u]) << 2);
-    const int n = i0 + jj * 8;
-    pcolb[u] = n < a.CoutP ? (unsigned)n * 2 : kOOB;
+    const int jj = ES == 2 ? ((sl % DP) ^ (wg_swz<RBP>(prow[u]) << 2)) : (sl % DP);
+    const int n = i0 + jj * EPV;
+    pcolb[u] = n < a.CoutP ? (unsigned)n * ES : kOOB;
   }
   int qrow[NQW]; unsigned qtb[NQW], qbit[NQW];
 #pragma unroll
   for (int u = 0; u < NQW; ++u) {
-    const int sl = (wave + 4 * u) * 64 + lane;
+    const int sl = (wave + NW * u) * 64 + lane;
     qrow[u] = sl / DQ;
-    const int jj = (sl % DQ) ^ (wg_swz<RBQ>(qrow[u]) << 2);
-    const int col = j0 + jj * 8;
+    const int jj = ES == 2 ? ((sl % DQ) ^ (wg_swz<RBQ>(qrow[u]) << 2)) : (sl % DQ);
+    const int col = j0 + jj * EPV;
     if (col < a.J) {
       const int tap = col / g.CP, c = col - tap * g.CP;
       const int dw = tap % g.kw, t2 = tap / g.kw, dh = t2 % g.kh, dt = t2 / g.kh;
       qbit[u] = (1u << dt) | (1u << (8 + dh)) | (1u << (16 + dw));
-      qtb[u] = (unsigned)((dt * g.sH + dh) * g.sW + dw) * ldxb + (unsigned)c * 2;
+      qtb[u] = (unsigned)((dt * g.sH + dh) * g.sW + dw) * ldxb + (unsigned)c * ES;
     } else {
       qbit[u] = 0xffffffffu;                         // never matches a 24-bit mask: zero fill
       qtb[u] = 0;
     }
   }
 
-  // decode 64 rows of round `rnd` (this wave's share) into rowtab[rnd & 1]
+  // decode RT rows of round `rnd` (one per thread) into rowtab[rnd & 1]
   auto decode = [&](int rnd) {
-    const int idx = wave * 64 + lane;
-    const int m = m_begin + rnd * RT + idx;
+    const int m = m_begin + rnd * RT + tid;
     uint2 e = make_uint2(0u, 0u);
     if (m < m_end) {
       const RowPos r = decode_row<MODE_FWD>((uint32_t)m, a.M, g);
@@ -971,28 +1039,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradDmaArgs aa) {
       e.x = (unsigned)(r.base + (r.t0 * g.sH + r.h0) * g.sW + r.w0) * ldxb;   // modulo 2^32; exact for valid taps
       e.y = (bt && bh && bw) ? (bt | (bh << 8) | (bw << 16)) : 0u;
     }
-    rowtab[rnd & 1][idx] = e;
+    rowtab[rnd & 1][tid] = e;
   };
 
   auto issue = [&](int s, int buf) {
     const int mb = m_begin + s * ROWS;
 #pragma unroll
     for (int u = 0; u < NPW; ++u) {
+      if (PPC % NW != 0 && wave + NW * u >= PPC) break;           // (wave-uniform)
       const int m = mb + prow[u];
       const unsigned off = (m < m_end && pcolb[u] != kOOB) ? (unsigned)m * ldyb + pcolb[u] : kOOB;
-      dma_load16(dy_rsrc, smem_base + buf * BUFB + (wave + 4 * u) * 1024, off);
+      dma_load16(dy_rsrc, smem_base + buf * BUFB + (wave + NW * u) * 1024, off);
     }
-    const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(rowtab[(s >> 3) & 1] + (s & 7) * ROWS);
+    const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(rowtab[(s / SPR) & 1] + (s % SPR) * ROWS);
     unsigned long long e[NQW];
 #pragma unroll
-    for (int u = 0; u < NQW; ++u) e[u] = tab[qrow[u]];          // one ds_read_b64 each, issued back to back
+    for (int u = 0; u < NQW; ++u) e[u] = tab[qrow[u] & (ROWS - 1)];   // one ds_read_b64 each, issued back to back
 #pragma unroll
     for (int u = 0; u < NQW; ++u) {
+      if (QPC % NW != 0 && wave + NW * u >= QPC) break;
       const unsigned ex = (unsigned)e[u], ey = (unsigned)(e[u] >> 32);
       const unsigned off = ((ey & qbit[u]) == qbit[u]) ? ex + qtb[u] : kOOB;
-      dma_load16(x_rsrc, smem_base + buf * BUFB + QOFF + (wave + 4 * u) * 1024, off);
+      dma_load16(x_rsrc, smem_base + buf * BUFB + QOFF + (wave + NW * u) * 1024, off);
     }
   };
+  // pieces this wave issues per step (wave-uniform)
+  int my_pieces = 0;
+#pragma unroll
+  for (int u = 0; u < NPW; ++u) my_pieces += (wave + NW * u < PPC) ? 1 : 0;
+#pragma unroll
+  for (int u = 0; u < NQW; ++u) my_pieces += (wave + NW * u < QPC) ? 1 : 0;
 
   f32x16 acc[TI][TJ];
 #pragma unroll
@@ -1002,48 +1078,60 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradDmaArgs aa) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const int h = lane >> 5, l31 = lane & 31;
   const int nsteps = (m_end - m_begin + ROWS - 1) / ROWS;
-  constexpr int D = NS - 1;                          // prefetch distance (D <= 7: the row table runs one round = 8 steps ahead)
-  static_assert(D >= 1 && D <= 7, "stages");
+  constexpr int D = NS - 1;                          // prefetch distance (the row table runs one round = SPR steps ahead)
+  static_assert(D >= 1 && D < SPR, "stages");
   decode(0);
   __syncthreads();
   for (int t = 0; t < D && t < nsteps; ++t) issue(t, t);
   int cur = 0, nxt = D % NS;
   for (int s = 0; s < nsteps; ++s) {
-    dma_wait_upto(min(D - 1, nsteps - 1 - s) * (NPW + NQW));       // tile s has landed (this wave's pieces)
+    dma_wait_upto(min(D - 1, nsteps - 1 - s) * my_pieces);         // tile s has landed (this wave's pieces)
     __syncthreads();                                 // ... everybody's; stage `nxt` (tile s-1) and the old row table are free
     // table of round R+1 is written during the first step of round R; its previous contents (round R-1) were last read
-    // at least one barrier ago, and its first reader (the issue for step 8(R+1), at step 8(R+1)-D) is later
-    if ((s & 7) == 0 && (s + 8) < nsteps) decode((s >> 3) + 1);
+    // at least one barrier ago, and its first reader (the issue for step SPR(R+1), at step SPR(R+1)-D) is later
+    if ((s % SPR) == 0 && (s + SPR) < nsteps) decode(s / SPR + 1);
     if (s + D < nsteps) issue(s + D, nxt);
+    const unsigned char* tp = smem + cur * BUFB;
+    const unsigned char* tq = tp + QOFF;
+    if constexpr (ES == 2) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[TI], bf[TJ];
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[TI], bf[TJ];
 #pragma unroll
-      for (int i = 0; i < TI; ++i) af[i] = wg_frag<RBP>(smem + cur * BUFB, wi0 + i * 32, lane, ks);
+        for (int i = 0; i < TI; ++i) af[i] = wg_frag<RBP>(tp, wi0 + i * 32, lane, ks);
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) bf[j] = wg_frag<RBQ>(smem + cur * BUFB + QOFF, wj0 + j * 32, lane, ks);
+        for (int j = 0; j < TJ; ++j) bf[j] = wg_frag<RBQ>(tq, wj0 + j * 32, lane, ks);
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int ks = 0; ks < ROWS / 2; ++ks) {
+        float af[TI], bf[TJ];
+        const int kr = ks * 2 + h;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const float*>(tp + kr * RBP + (wi0 + i * 32 + l31) * 4);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const float*>(tq + kr * RBQ + (wj0 + j * 32 + l31) * 4);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
     }
     cur = cur + 1 == NS ? 0 : cur + 1;
     nxt = nxt + 1 == NS ? 0 : nxt + 1;
   }
 
-  const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      const int col = j0 + wj0 + j * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i0 + wi0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < a.Cout && col < a.J) atomicAdd(a.dw + (size_t)row * a.ldw + col, acc[i][j][r]);
-      }
-    }
+    for (int j = 0; j < TJ; ++j)
+      wgrad_store_block(a, split, i0 + wi0 + i * 32, j0 + wj0 + j * 32 + l31, h, acc[i][j]);
 }
 
 
@@ -1301,65 +1389,161 @@ extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void
   return dv_launch_status();
 }
 
-extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void* dy, float* dw, void* stream) {
+// Tile / row-split plan of a weight-gradient problem (shared by the launch and by dv_conv3d_wgrad_workspace).
+struct WgradCfg { int BI, BJ, WVI, WVJ, NS; };
+// DMA-kernel configurations.  The kernel is bound by what a CU can pull from L2 into LDS (~70 GB/s per CU): the bytes
+// filled per unit of work go with 1/BI + 1/BJ, so the largest tile that wastes little padding wins -- see plan_wgrad.
+static const WgradCfg kWgBf16[] = {{128, 128, 2, 2, 3}, {64, 256, 1, 4, 3}, {128, 256, 2, 2, 3}, {192, 256, 3, 4, 4}};
+static const WgradCfg kWgF32[] = {{128, 128, 2, 2, 2}, {64, 128, 2, 2, 2}};
+
+struct WgradPlan {
+  int BI, BJ, nti, ntj, splits, rows_per_split, gvb, cfg;
+  bool dma;
+  long long slab_stride;      // elements
+};
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+static WgradPlan plan_wgrad(const dv_conv_desc* d) {
+  WgradPlan p;
+  const int M = d->N * d->To * d->Ho * d->Wo;
+  const int J = d->kt * d->kh * d->kw * d->cin_pitch;
+  const int es = d->dtype == DV_F32 ? 4 : 2;
+  p.gvb = gather_bytes(d->dtype, d->cin_pitch);
+  p.dma = p.gvb == 16 && d->kt <= 8 && d->kh <= 8 && d->kw <= 8;
+  if (p.dma) {
+    const int64_t xb = ((int64_t)d->N * d->Ti * d->Hi * d->Wi - 1) * d->ldx * es + (int64_t)d->cin_pitch * es;
+    const int64_t yb = ((int64_t)M - 1) * d->ldy * es + (int64_t)d->cout_pitch * es;
+    if (xb >= (1ll << 31) || yb >= (1ll << 31)) p.dma = false;
+  }
+  int per_cu = 3;
+  p.cfg = -1;
+  if (p.dma) {
+    // candidate with the least estimated time: LDS-fill bytes at ~18 TB/s chip-wide against padded MFMA work at ~2/3 of
+    // peak; a configuration whose tiles cannot even fill the chip once (few rows) pays for the idle CUs
+    const WgradCfg* tab = d->dtype == DV_F32 ? kWgF32 : kWgBf16;
+    const int ncfg = d->dtype == DV_F32 ? 2 : 4;
+    static const int force = env_int("DUALVAR_WGRAD_CFG", -1);
+    static const int minrows_ = env_int("DUALVAR_WGRAD_MINROWS", 256);
+    double best = 0;
+    for (int c = 0; c < ncfg; ++c) {
+      const WgradCfg& k = tab[c];
+      const int nti = (d->Cout + k.BI - 1) / k.BI, ntj = (J + k.BJ - 1) / k.BJ;
+      const double fill = (double)M * nti * ntj * (k.BI + k.BJ) * es / 18e12;
+      const double mfma = 2.0 * M * (double)(nti * k.BI) * (ntj * k.BJ) / (d->dtype == DV_F32 ? 120e12 : 1600e12);
+      const int cap = 256 * wgrad_wgs_per_cu(es, k.BI, k.BJ, k.WVI * k.WVJ, k.NS);
+      const int64_t sp = std::max<int64_t>(1, std::min<int64_t>(cap / (nti * ntj), (M + minrows_ - 1) / minrows_));
+      const double wgs = (double)nti * ntj * sp;
+      const double t = std::max(fill, mfma) * std::max(1.0, 256.0 / wgs);
+      if (p.cfg < 0 || t < best) { best = t; p.cfg = c; }
+    }
+    if (force >= 0 && force < ncfg) p.cfg = force;
+    const WgradCfg& k = tab[p.cfg];
+    p.BI = k.BI; p.BJ = k.BJ;
+    per_cu = wgrad_wgs_per_cu(es, k.BI, k.BJ, k.WVI * k.WVJ, k.NS);
+  } else {
+    // tile heights 64 or 128: whichever pads Cout less (144 -> 3 x 64 rather than 2 x 128)
+    const bool narrow = (d->Cout + 63) / 64 * 64 < (d->Cout + 127) / 128 * 128;
+    p.BI = narrow ? 64 : 128;
+    p.BJ = narrow ? 128 : 64;
+  }
+  p.nti = (d->Cout + p.BI - 1) / p.BI;
+  p.ntj = (J + p.BJ - 1) / p.BJ;
+  const int tiles = p.nti * p.ntj;
+  // Row splits: ONE round of co-resident workgroups (256 CUs x the workgroups per CU the kernel's LDS / registers admit)
+  // -- a grid of 1.5 rounds leaves half the chip idle for the second one -- but at least `minrows` rows each: a split's
+  // partial tile costs as much traffic as ~128 rows of its inputs.  DUALVAR_WGRAD_WGS(_F32) / _MINROWS: tuning knobs.
+  static const int tgt_bf16 = env_int("DUALVAR_WGRAD_WGS", 0), tgt_f32 = env_int("DUALVAR_WGRAD_WGS_F32", 0);
+  static const int minrows = env_int("DUALVAR_WGRAD_MINROWS", 256);
+  int tgt = d->dtype == DV_F32 ? tgt_f32 : tgt_bf16;
+  if (tgt <= 0) tgt = 256 * per_cu;
+  int splits = tgt / tiles;                          // round down: never more workgroups than fit at once
+  const int max_splits = (M + minrows - 1) / minrows;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.rows_per_split = ((M + splits - 1) / splits + 31) / 32 * 32;
+  p.splits = (M + p.rows_per_split - 1) / p.rows_per_split;
+  p.slab_stride = ((long long)d->Cout * J + 63) / 64 * 64;
+  return p;
+}
+
+extern "C" int dv_conv3d_wgrad_tile(const dv_conv_desc* d, int32_t* rows, int32_t* cols, int32_t* splits) {
+  if (!d || !rows || !cols || !splits) return DV_EINVAL;
+  int rc = check_desc(d);
+  if (rc) return rc;
+  const WgradPlan p = plan_wgrad(d);
+  *rows = p.BI; *cols = p.BJ; *splits = p.splits;
+  return DV_OK;
+}
+
+extern "C" int64_t dv_conv3d_wgrad_workspace(const dv_conv_desc* d) {
+  if (check_desc(d)) return 0;
+  const WgradPlan p = plan_wgrad(d);
+  return p.splits > 1 ? (int64_t)p.splits * p.slab_stride * 4 : 0;
+}
+
+extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!x || !dy || !dw) return DV_EINVAL;
-  if (!aligned16(dy) || (reinterpret_cast<uintptr_t>(x) & 7)) return DV_EALIGN;
+  if (!aligned16(dy) || !aligned16(dw) || (reinterpret_cast<uintptr_t>(x) & 7)) return DV_EALIGN;
+  const WgradPlan p = plan_wgrad(d);
+  const int64_t need = p.splits > 1 ? (int64_t)p.splits * p.slab_stride * 4 : 0;
+  if (need && (!workspace || workspace_bytes < need)) return DV_EINVAL;
+  if (need && !aligned16(workspace)) return DV_EALIGN;
+  if (p.gvb == 16 && !aligned16(x)) return DV_EALIGN;
   WgradArgs a;
   fill_geom(d, MODE_FWD, a.g);
   a.x = x; a.dy = dy; a.dw = dw;
+  a.slab = need ? reinterpret_cast<float*>(workspace) : nullptr;
+  a.slab_stride = p.slab_stride;
   a.M = d->N * d->To * d->Ho * d->Wo;
   a.Cout = d->Cout; a.CoutP = d->cout_pitch; a.J = a.g.Ktot;
   a.ldx = d->ldx; a.ldy = d->ldy; a.ldw = a.g.Ktot;
-  // 128 output channels x 64 im2col columns per workgroup, or 64 x 128 when the layer has <= 64 output channels
-  // tile heights 64 or 128: whichever pads Cout less (144 -> 3 x 64 rather than 2 x 128)
-  const bool narrow = (a.Cout + 63) / 64 * 64 < (a.Cout + 127) / 128 * 128;
-  const int BI = narrow ? 64 : 128, BJ = narrow ? 128 : 64;
-  a.nti = (a.Cout + BI - 1) / BI;
-  a.ntj = (a.J + BJ - 1) / BJ;
-  const int tiles = a.nti * a.ntj;
-  // row splits: ~1024 workgroups for the long layers; ~512 below 50k rows, where each extra split is mostly extra
-  // atomics (measured in the S3D-G step: 12 544-row layers 772 -> 697 us with 512, the >= 100k-row layers 1351 -> 1802)
-  const int tgt = a.M >= 50000 ? 1024 : 512;
-  int splits = (tgt + tiles - 1) / tiles;
-  const int max_splits = (a.M + 255) / 256;          // at least 256 rows per workgroup
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  a.rows_per_split = ((a.M + splits - 1) / splits + 31) / 32 * 32;
-  splits = (a.M + a.rows_per_split - 1) / a.rows_per_split;
-  const int grid = tiles * splits;
-  const int gvb = gather_bytes(d->dtype, d->cin_pitch);
-  if (gvb == 16 && !aligned16(x)) return DV_EALIGN;
+  a.nti = p.nti; a.ntj = p.ntj;
+  a.rows_per_split = p.rows_per_split;
+  const int grid = p.nti * p.ntj * p.splits;
+  const bool narrow = p.BI == 64;
   hipStream_t s = (hipStream_t)stream;
-  if (d->dtype == DV_BF16 && gvb == 16 && d->kt <= 8 && d->kh <= 8 && d->kw <= 8) {
-    const int64_t xb = ((int64_t)d->N * d->Ti * d->Hi * d->Wi - 1) * d->ldx * 2 + (int64_t)d->cin_pitch * 2;
-    const int64_t yb = ((int64_t)a.M - 1) * d->ldy * 2 + (int64_t)d->cout_pitch * 2;
-    if (xb < (1ll << 31) && yb < (1ll << 31)) {
-      WgradDmaArgs aa;
-      aa.w = a; aa.x_bytes = (int)xb; aa.dy_bytes = (int)yb;
-      // three stages below 50k rows (fewer resident workgroups there anyway: 690 -> 628 us over the 12 544-row layers of
-      // the S3D-G step), two above (1351 vs 1335 / 1392 us with three / four)
-      // (four stages on the 1 152- / 12 544-row layers: no change)
-      const int ns = a.M < 50000 ? 3 : 2;
-#define WGD(NS_)                                                                                               \
-  do {                                                                                                         \
-    if (narrow) hipLaunchKernelGGL((conv_wgrad_dma_kernel<64, 128, NS_>), dim3(grid), dim3(256), 0, s, aa);    \
-    else hipLaunchKernelGGL((conv_wgrad_dma_kernel<128, 64, NS_>), dim3(grid), dim3(256), 0, s, aa);           \
-  } while (0)
-      if (ns == 3) WGD(3); else WGD(2);
-#undef WGD
-      return dv_launch_status();
+  if (p.dma) {
+    const int64_t es = d->dtype == DV_F32 ? 4 : 2;
+    WgradDmaArgs aa;
+    aa.w = a;
+    aa.x_bytes = (int)(((int64_t)d->N * d->Ti * d->Hi * d->Wi - 1) * d->ldx * es + (int64_t)d->cin_pitch * es);
+    aa.dy_bytes = (int)(((int64_t)a.M - 1) * d->ldy * es + (int64_t)d->cout_pitch * es);
+#define WGD(T_, BI_, BJ_, WI_, WJ_, NS_) \
+  hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, BI_, BJ_, WI_, WJ_, NS_>), dim3(grid), dim3(WI_ * WJ_ * 64), 0, s, aa)
+    if (d->dtype == DV_BF16) {
+      switch (p.cfg) {
+        case 0: WGD(bf16_t, 128, 128, 2, 2, 3); break;
+        case 1: WGD(bf16_t, 64, 256, 1, 4, 3); break;
+        case 2: WGD(bf16_t, 128, 256, 2, 2, 3); break;
+        default: WGD(bf16_t, 192, 256, 3, 4, 4); break;
+      }
+    } else {
+      if (p.cfg == 1) WGD(float, 64, 128, 2, 2, 2);
+      else WGD(float, 128, 128, 2, 2, 2);
     }
-  }
+#undef WGD
+  } else {
 #define WG_LAUNCH(T_, G_)                                                                                   \
   do {                                                                                                      \
     if (narrow) hipLaunchKernelGGL((conv_wgrad_kernel<T_, G_, 64, 128>), dim3(grid), dim3(256), 0, s, a);   \
     else hipLaunchKernelGGL((conv_wgrad_kernel<T_, G_, 128, 64>), dim3(grid), dim3(256), 0, s, a);          \
   } while (0)
-  if (d->dtype == DV_F32) WG_LAUNCH(float, 16);
-  else if (gvb == 16) WG_LAUNCH(bf16_t, 16);
-  else WG_LAUNCH(bf16_t, 8);
+    if (d->dtype == DV_F32) WG_LAUNCH(float, 16);
+    else if (p.gvb == 16) WG_LAUNCH(bf16_t, 16);
+    else WG_LAUNCH(bf16_t, 8);
 #undef WG_LAUNCH
+  }
+  if (need) {
+    const long long n4 = (long long)d->Cout * a.ldw / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, a.slab, p.slab_stride,
+                       p.splits, dw, n4);
+  }
   return dv_launch_status();
 }

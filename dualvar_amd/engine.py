@@ -494,6 +494,15 @@ class Plan:
                 key = (g.buf.data_ptr(), g.off)
                 op.acc[name] = key in seen
                 seen.add(key)
+        # scratch of the deterministic weight gradients (row-split partial tiles): ONE buffer per plan, sized for the
+        # largest layer -- the plan's weight gradients all run on one stream (the side stream), each followed by its
+        # reduce, so they can share it
+        self.wgrad_ws = None
+        if self.with_grad:
+            need = max([o.wgrad_workspace_bytes() for o in self.ops if isinstance(o, ConvOp)] + [0])
+            if need:
+                self.wgrad_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                self.bytes += need
         if self.with_grad and self._zero_words:
             self.zero_arena = self.f32(self._zero_words)
             arena = self.zero_arena
@@ -663,6 +672,10 @@ class ConvOp(Op):
     def grad_targets(self):
         return [('x', self.x)] if self.need_dx else []
 
+    def wgrad_workspace_bytes(self):
+        d = ops.conv_desc(self.dtype, self.x, self.y, self.k, self.s, self.p, flags=0)
+        return ops.wgrad_workspace_bytes(d)
+
     def launches(self):
         p, st, lib, sl, x, y = self.plan, self.plan.store, self.plan.lib, self.slot, self.x, self.y
         es = ops.ESIZE[self.dtype]
@@ -679,8 +692,13 @@ class ConvOp(Op):
         b = []
         if p.with_grad:
             self.d_w = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=0)
-            b.append(Launch('conv_wgrad', 'conv_wgrad<%s,%d,%s>' % (_dt(self.dtype), gv, '64,128' if ((sl.Cout + 63) // 64 * 64 < (sl.Cout + 127) // 128 * 128) else '128,64'), lib.dv_conv3d_wgrad,
-                            (C.byref(self.d_w), x.ptr, y.grad.ptr, st.w_grad(sl)),
+            tr, tc, tsp = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            L.check(lib.dv_conv3d_wgrad_tile(C.byref(self.d_w), C.byref(tr), C.byref(tc), C.byref(tsp)), 'dv_conv3d_wgrad_tile')
+            tile = '%d,%d' % (tr.value, tc.value)
+            ws = p.wgrad_ws
+            b.append(Launch('conv_wgrad', 'conv_wgrad<%s,%d,%s>' % (_dt(self.dtype), gv, tile), lib.dv_conv3d_wgrad,
+                            (C.byref(self.d_w), x.ptr, y.grad.ptr, st.w_grad(sl), ws.data_ptr() if ws is not None else 0,
+                             ws.numel() if ws is not None else 0),
                             _abytes(x) + _abytes(y) + sl.Cout * kdim * 4, flops, shp))
             b[-1].gend = sl.off + sl.size
             if self.zero_pad_taps is not None:

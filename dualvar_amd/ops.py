@@ -93,9 +93,18 @@ def conv_dgrad(d, dy, wd, dx):
     L.check(lib.dv_conv3d_dgrad(C.byref(d), _p(dy), _p(wd), _p(dx), stream_ptr()), 'dv_conv3d_dgrad')
 
 
-def conv_wgrad(d, x, dy, dw):
+def wgrad_workspace_bytes(d):
+    return int(L.load().dv_conv3d_wgrad_workspace(C.byref(d)))
+
+
+def conv_wgrad(d, x, dy, dw, workspace=None):
+    """dw += x^T dy.  workspace: uint8/any tensor of >= wgrad_workspace_bytes(d) bytes (allocated here when omitted)"""
     lib = L.load()
-    L.check(lib.dv_conv3d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), stream_ptr()), 'dv_conv3d_wgrad')
+    need = wgrad_workspace_bytes(d)
+    if workspace is None and need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dw.device)
+    nbytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    L.check(lib.dv_conv3d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(workspace), nbytes, stream_ptr()), 'dv_conv3d_wgrad')
 
 
 def stat_tiles(d):

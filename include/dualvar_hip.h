@@ -97,8 +97,16 @@ int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w_fwd, const
                   void* y, float* stats, void* stream);
 /* dx (+)= conv_transpose(dy, w).  strides must be 1 or 2. */
 int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* stream);
-/* dw += x^T * dy  (fp32 atomics into the gradient arena; caller zeroes at zero_grad) */
-int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void* dy, float* dw, void* stream);
+/* dw += x^T * dy into the fp32 gradient arena (caller zeroes at zero_grad).  Deterministic: the rows are split over
+ * workgroups whose partial tiles go to `workspace` ([splits][Cout][taps*CinP] fp32, plain stores) and are then added to dw
+ * in a fixed order -- no float atomics, so two runs on the same inputs give the same bits.  dv_conv3d_wgrad_workspace
+ * returns the bytes `workspace` must hold for this problem (0: none needed, workspace may be NULL); the buffer can be
+ * shared by launches on one stream. */
+int64_t dv_conv3d_wgrad_workspace(const dv_conv_desc* d);
+/* the dW tile (output channels x im2col columns) and the number of row splits dv_conv3d_wgrad will use: informational */
+int dv_conv3d_wgrad_tile(const dv_conv_desc* d, int32_t* rows, int32_t* cols, int32_t* splits);
+int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 
 /* master fp32 [Cout][taps][CinP] -> compute-dtype [Cin][taps][CoutP] for n_desc tensors at once */
 typedef struct dv_pack_desc {

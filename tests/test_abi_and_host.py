@@ -17,7 +17,7 @@ def _header_functions():
     src = open(os.path.join(ROOT, 'include', 'dualvar_hip.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     out = {}
-    for m in re.finditer(r'\bint\s+(dv_\w+)\s*\((.*?)\)\s*;', src, flags=re.S):
+    for m in re.finditer(r'\b(?:int|int64_t)\s+(dv_\w+)\s*\((.*?)\)\s*;', src, flags=re.S):
         args = [a.strip() for a in m.group(2).split(',') if a.strip() and a.strip() != 'void']
         out[m.group(1)] = args
     return out

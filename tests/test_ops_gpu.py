@@ -53,6 +53,45 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
+@pytest.mark.parametrize('case', [('sp3_wide', 8, 32, 4, 16, 16, 48, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+                                  ('tm7_s2', 4, 64, 8, 12, 12, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0)),
+                                  ('pw_192', 4, 192, 4, 14, 14, 176, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+                                  ('full3_208', 6, 96, 4, 10, 10, 208, (3, 3, 3), (1, 1, 1), (1, 1, 1))],
+                         ids=lambda c: c[0])
+def test_conv_wgrad_row_splits_are_deterministic(gpu, dtype, case):
+    """The weight gradient over MANY row splits (scratch partial tiles + ordered reduce, include/dualvar_hip.h): equal to
+    torch's, bit-for-bit reproducible from run to run, `+=` into the gradient arena, and independent of what the
+    (shared) workspace held before."""
+    name, N, Cin, T, H, W, Cout, k, s, p = case
+    x = q(rnd(N, Cin, T, H, W, seed=1), dtype)
+    w = q(rnd(Cout, Cin, *k, seed=2, scale=(Cin * k[0] * k[1] * k[2]) ** -0.5), dtype)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv3d(x, wr, None, s, p)
+    gy = q(rnd(*yr.shape, seed=3), dtype)
+    yr.backward(gy)
+    xa = ops.act_from_ncdhw(x.to(gpu), dtype)
+    dya = ops.act_from_ncdhw(gy.to(gpu), dtype)
+    d = ops.conv_desc(dtype, xa, dya, k, s, p)
+    need = ops.wgrad_workspace_bytes(d)
+    assert need > 0, 'case too small to split: %s' % name
+    wp = ops.pack_weight(w.to(gpu), ops.cp8(Cin))
+    ws = torch.empty(need, dtype=torch.uint8, device=gpu)
+    runs = []
+    for fill in (0, 0xFF, 0x7F):                       # 0xFF.. = NaN patterns: every slab word that is read was written
+        ws.fill_(fill)
+        dw = torch.zeros_like(wp)
+        ops.conv_wgrad(d, xa, dya, dw, workspace=ws)
+        runs.append(dw)
+    torch.cuda.synchronize()
+    close(ops.unpack_weight(runs[0], w.shape), wr.grad, dtype, name + ' wgrad')
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    ops.conv_wgrad(d, xa, dya, runs[2], workspace=ws)     # accumulates
+    assert torch.allclose(runs[2], 2 * runs[0], rtol=1e-6, atol=0)
+    with pytest.raises(Exception):                         # a workspace that is too small is rejected, nothing is launched
+        ops.conv_wgrad(d, xa, dya, dw, workspace=ws[:need // 2])
+
+
+@pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(gpu, dtype, case):
     name, N, Cin, T, H, W, Cout, k, s, p = case

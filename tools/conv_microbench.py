@@ -54,31 +54,36 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--passes', default='fwd,dgrad,wgrad')
     ap.add_argument('--no-stats', action='store_true', help='forward without the fused BatchNorm partials')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     args = ap.parse_args()
     L.require_device()
     dev = torch.device('cuda:0')
+    DT = L.DV_BF16 if args.dtype == 'bf16' else L.DV_F32
+    tdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    es = 2 if args.dtype == 'bf16' else 4
     names = BIG if args.layers == 'big' else (list(LAYERS) if args.layers == 'all' else args.layers.split(','))
     for name in names:
         N, T, H, W, Ci, Co, k, s, p = LAYERS[name]
-        x = ops.new_act(N, T, H, W, Ci, L.DV_BF16, dev)
+        x = ops.new_act(N, T, H, W, Ci, DT, dev)
         x.buf.normal_().relu_()                 # post-ReLU activations: half zeros, as inside the real step (clocks depend on it)
         To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
-        y = ops.new_act(N, To, Ho, Wo, Co, L.DV_BF16, dev)
+        y = ops.new_act(N, To, Ho, Wo, Co, DT, dev)
         dy = y.like()
         dy.buf.normal_()
         dx = x.like()
         taps = k[0] * k[1] * k[2]
-        w = torch.randn(Co, taps * x.cpitch, device=dev).bfloat16()
-        wd = torch.randn(Ci, taps * y.cpitch, device=dev).bfloat16()
+        w = torch.randn(Co, taps * x.cpitch, device=dev).to(tdt)
+        wd = torch.randn(Ci, taps * y.cpitch, device=dev).to(tdt)
         dw = torch.zeros(Co, taps * x.cpitch, device=dev)
-        d = ops.conv_desc(L.DV_BF16, x, y, k, s, p, flags=0 if args.no_stats else L.DV_STATS)
+        d = ops.conv_desc(DT, x, y, k, s, p, flags=0 if args.no_stats else L.DV_STATS)
         stats = torch.zeros(ops.stat_tiles(d) * 2 * Co, device=dev)
-        dd = ops.conv_desc(L.DV_BF16, x, y, k, s, p)
+        dd = ops.conv_desc(DT, x, y, k, s, p)
         flops = 2.0 * y.rows * Co * Ci * taps
-        bx, by = x.rows * x.cpitch * 2, y.rows * y.cpitch * 2
+        bx, by = x.rows * x.cpitch * es, y.rows * y.cpitch * es
+        ws = torch.empty(max(ops.wgrad_workspace_bytes(dd), 16), dtype=torch.uint8, device=dev)
         jobs = {'fwd': (lambda: ops.conv_fwd(d, x, w, None, y, stats), bx + by),
                 'dgrad': (lambda: ops.conv_dgrad(dd, dy, wd, dx), bx + by),
-                'wgrad': (lambda: ops.conv_wgrad(dd, x, dy, dw), bx + by)}
+                'wgrad': (lambda: ops.conv_wgrad(dd, x, dy, dw, workspace=ws), bx + by)}
         for ps in args.passes.split(','):
             fn, nbytes = jobs[ps]
             us = timed(fn, args.reps)
