@@ -93,6 +93,7 @@ class _BackboneFn(torch.autograd.Function):
     def forward(ctx, anchor, x, backbone, perm, want_map):
         plan = backbone._acquire_plan(x, perm is not None, want_map, with_grad=True)
         backbone._run_plan(plan, x, perm)
+        plan.store.pending_backward += 1          # encoder passes of this step still to be back-propagated
         ctx.plan = plan
         ctx.token = _Token()
         plan._busy_ref = weakref.ref(ctx.token)
@@ -106,6 +107,14 @@ class _BackboneFn(torch.autograd.Function):
         plan = ctx.plan
         backbone_store = plan.store
         backbone_store.attach_grads()
+        # Bucket-wise gradient all-reduce from inside the backward list (parallel.GradSync.attach) only on the LAST encoder
+        # backward of the step: the dual-head objectives run the encoder two or three times per step (simclr.py:354,385;
+        # moco.py:492,551) and every pass accumulates into the same arena -- a bucket is final only once the last one
+        # has written it.  (The heads' gradients of every pass are complete by then: a pass's head backward precedes its
+        # encoder backward.)
+        backbone_store.pending_backward = max(backbone_store.pending_backward - 1, 0)
+        if backbone_store.pending_backward > 0:
+            plan.grad_ready = None
         if ctx.want_map:
             a = plan.out_act.grad
             a.buf[:, a.off:a.off + a.C] = g.permute(0, 2, 3, 4, 1).reshape(-1, a.C).to(a.buf.dtype)

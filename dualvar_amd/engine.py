@@ -64,6 +64,7 @@ class ParamStore:
         self._versions = None
         self.total = 0
         self.no_dgrad = False         # key encoders (never back-propagated) skip the dgrad-layout weights
+        self.pending_backward = 0     # forward passes with autograd history whose backward has not run yet (reset by the optimizer)
 
     # ---- registration (idempotent per tensor: S3D registers its stem twice)
     def _add(self, t, kind, **kw):

@@ -69,8 +69,6 @@ class _MoCoBase(_Objective):
 
 
 class MoCo_Naked(_MoCoBase):
-    single_backward_pass = True      # one query-encoder pass with gradients per step (parallel.GradSync.attach)
-
     def __init__(self, network='s3d', dim=128, K=2048, m=0.999, T=0.07, distributed=True, nonlinear=True):
         super().__init__()
         self.dim, self.K, self.m, self.T, self.distributed, self.nonlinear = dim, K, m, T, distributed, nonlinear

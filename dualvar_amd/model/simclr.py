@@ -73,8 +73,6 @@ class _SimCLRLosses:
 
 
 class SimCLR_Naked(_Objective, _SimCLRLosses):
-    single_backward_pass = True      # one encoder pass with gradients per step (parallel.GradSync.attach)
-
     def __init__(self, network='s3d', dim=128, T=0.07, distributed=True, nonlinear=True):
         super().__init__()
         self.dim, self.T, self.distributed, self.nonlinear = dim, T, distributed, nonlinear

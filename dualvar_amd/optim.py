@@ -48,6 +48,7 @@ class SGD(torch.optim.Optimizer):
                 ops.call('dv_sgd_momentum', st.master.data_ptr() + 4 * a, st.grad.data_ptr() + 4 * a, buf.data_ptr() + 4 * a, n,
                          lr, mu, wd, scale, st.dtype, (copy.data_ptr() + es * a) if copy is not None else None)
             st.mark_dirty(cast_done=True)
+            st.pending_backward = 0           # a forward whose result was never back-propagated must not stall the overlap
 
     def _momentum_views(self):
         """[(index in torch's flat parameter order, momentum view shaped like the parameter)] for every parameter that

@@ -40,14 +40,13 @@ def bucket_ranges(total, bucket_elems):
 class GradSync:
     """callable(store) -> grad_scale.  All-reduces store.grad (sum) in buckets; returns 1/world.
 
-    `attach(model)` (optional) overlaps the reduction with the backward pass of models that back-propagate through
-    their encoder exactly ONCE per step (`model.single_backward_pass`: SimCLR_Naked, MoCo_Naked): the launch plan
-    knows, for every point of its backward list, above which arena offset no gradient will be written any more
-    (`engine.Plan._grad_triggers`), and calls `_on_ready` as each bucket -- last layers first, the heads' gradients
-    are complete before the encoder's backward starts -- becomes final; that bucket's all-reduce then runs on the
-    side stream underneath the rest of the backward.  The call from the optimizer reduces whatever is left and waits
-    for everything.  Models with two encoder passes per step (the TimeSeriesV4 objectives accumulate both into the
-    arena) keep the plain reduce-after-backward."""
+    `attach(model)` (optional) overlaps the reduction with the backward pass: the launch plan knows, for every point of
+    its backward list, above which arena offset no gradient will be written any more (`engine.Plan._grad_triggers`), and
+    calls `_on_ready` as each bucket -- last layers first, the heads' gradients are complete before the encoder's
+    backward starts -- becomes final; that bucket's all-reduce then runs on the side stream underneath the rest of the
+    backward.  Objectives that run the encoder several times per step (the TimeSeriesV4 ones accumulate all passes into
+    the arena) arm this on the LAST encoder backward only (backbone/base.py: `pending_backward`).  The call from the
+    optimizer reduces whatever is left and waits for everything."""
 
     def __init__(self, bucket_mb=8, group=None, side_stream=True):
         self.group = group
@@ -66,7 +65,7 @@ class GradSync:
 
     # ---- overlap with backward
     def attach(self, model):
-        if not self.exchange or not getattr(model, 'single_backward_pass', False):
+        if not self.exchange:
             return False
         for m in model.modules():
             if hasattr(m, '_plans') and hasattr(m, 'grad_ready'):
