@@ -198,6 +198,43 @@ template <> struct Mma<float> {
   }
 };
 
+// ---- fp32 operands on the bf16 matrix cores ("3 x bf16 split") ----------------------------------------------------
+// gfx950 has no xf32 / TF32 path and its f32-input MFMA runs at the vector rate, 1/16 of the bf16 MFMA.  An fp32 value
+// is EXACTLY hi + mid + lo with three bf16 (8 significant bits each = fp32's 24; round-to-nearest residues), and a
+// product a*b is the sum of nine partial products of which the six of weight >= 2^-16 are kept: the three dropped ones
+// are <= 2^-24 |a||b| each, i.e. at the level of fp32's own rounding of the product.  Every partial product of two bf16
+// is exact in fp32 and the MFMA accumulates in fp32, small terms first.  Six bf16 MFMAs (32 cycles each) replace eight
+// 32x32x2 f32 MFMAs (64 cycles each) per 32x32x16 block: 2.67x less matrix-pipe time at fp32-level accuracy
+// (DUALVAR_F32_EXACT=1 selects the exact-f32 MFMA kernels instead; tests/test_ops_gpu.py compares both with torch fp32).
+struct Split3 { bf16x8 hi, mid, lo; };
+__device__ __forceinline__ Split3 split3(const float (&v)[8]) {
+  Split3 s;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bf16_t h = (bf16_t)v[e];
+    const float r1 = v[e] - (float)h;
+    const bf16_t m = (bf16_t)r1;
+    const float r2 = r1 - (float)m;
+    s.hi[e] = h; s.mid[e] = m; s.lo[e] = (bf16_t)r2;
+  }
+  return s;
+}
+__device__ __forceinline__ void mma_split3(const Split3& a, const Split3& b, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+// K-contiguous LDS row (64 bytes = 16 f32 per K tile, 16-byte slots XOR-swizzled by s): the 8 floats k = 8h .. 8h+7
+__device__ __forceinline__ Split3 split3_row(const unsigned char* row, int h, int s) {
+  const f32x4 lo4 = *reinterpret_cast<const f32x4*>(row + ((2 * h) ^ s) * 16);
+  const f32x4 hi4 = *reinterpret_cast<const f32x4*>(row + ((2 * h + 1) ^ s) * 16);
+  const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+  return split3(v);
+}
+
 __device__ __forceinline__ float act_apply(float v, int flags) {
   if (flags & DV_RELU) v = fmaxf(v, 0.f);
   if (flags & DV_SIGMOID) v = 1.f / (1.f + __expf(-v));
@@ -220,9 +257,10 @@ constexpr int conv_waves_per_simd(int es, int gvb, int bm, int bn) {
   return (es != 2 || gvb != 16) ? 1 : (bm * bn == 128 * 64) ? 6 : (bm == 128 && bn == 128) ? 3 : 1;
 }
 
-template <typename T, int MODE, int GVB, int BM, int BN, int WAVES_M, int WAVES_N, int GM, int NS = 2>
+template <typename T, int MODE, int GVB, int BM, int BN, int WAVES_M, int WAVES_N, int GM, int NS = 2, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))) void conv_gemm_kernel(ConvArgs a) {
+  static_assert(!SPLIT || sizeof(T) == 4, "the bf16 split is the fp32 mode's product");
   // DMA: 16-byte gathers go global -> LDS directly (buffer_load ... lds), no VGPR staging and no ds_write.  One wave
   // instruction fills 16 rows x 64 B = 1 KiB of a row-linear, UNPADDED tile; bank conflicts of the ds_read_b128 fragment
   // reads are avoided by XOR-swizzling the 16-byte slot with (row>>2)&3, applied on the source side (which k-slot a
@@ -439,12 +477,25 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
   // 32-row fragment blocks start at multiples of 32, so (row>>2)&3 of a fragment row is (l31>>2)&3 for A and B alike
   const int swz = DMA ? ((l31 >> 2) & 3) : 0;
   auto compute = [&](int buf) {
+    if constexpr (SPLIT) {
+      // each fragment is split ONCE per K tile and used by TN (TM) blocks
+      Split3 af[TM], bf[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i) af[i] = split3_row(smem + buf * BUFB + (wm0 + i * 32 + l31) * PITCH, h, swz);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        Mma<T>::tile(smem + buf * BUFB + (wm0 + i * 32 + l31) * PITCH,
-                     smem + buf * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, swz, swz, acc[i][j]);
+      for (int j = 0; j < TN; ++j) bf[j] = split3_row(smem + buf * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, swz);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_split3(af[i], bf[j], acc[i][j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          Mma<T>::tile(smem + buf * BUFB + (wm0 + i * 32 + l31) * PITCH,
+                       smem + buf * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, swz, swz, acc[i][j]);
+    }
   };
   if constexpr (DMA) {
     // pieces this wave issues per tile (the B groups may not divide evenly over the waves)
@@ -958,9 +1009,10 @@ constexpr int wgrad_waves_per_simd(int es, int bi, int bj, int nw, int ns) {
   return (wgrad_wgs_per_cu(es, bi, bj, nw, ns) * nw + 3) / 4;
 }
 
-template <typename T, int BI, int BJ, int WVI, int WVJ, int NS>
+template <typename T, int BI, int BJ, int WVI, int WVJ, int NS, bool SPLIT = false>
 __global__ __launch_bounds__(WVI * WVJ * 64)
 __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI * WVJ, NS)))) void conv_wgrad_dma_kernel(WgradDmaArgs aa) {
+  static_assert(!SPLIT || sizeof(T) == 4, "the bf16 split is the fp32 mode's product");
   const WgradArgs& a = aa.w;
   constexpr int ES = (int)sizeof(T);
   constexpr int EPV = 16 / ES;                       // elements per 16-byte DMA slot
@@ -1108,6 +1160,31 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
 #pragma unroll
           for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
+    } else if constexpr (SPLIT) {
+      // f32 tiles, products on the bf16 matrix cores (split3 above): the K index of this GEMM is the ROW, so a lane's
+      // fragment is 8 rows of one column (conflict-free dword reads, immediate offsets)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        Split3 af[TI], bf[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(tp + (ks * 16 + 8 * h + e) * RBP + (wi0 + i * 32 + l31) * 4);
+          af[i] = split3(v);
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(tq + (ks * 16 + 8 * h + e) * RBQ + (wj0 + j * 32 + l31) * 4);
+          bf[j] = split3(v);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) mma_split3(af[i], bf[j], acc[i][j]);
+      }
     } else {
 #pragma unroll 4
       for (int ks = 0; ks < ROWS / 2; ++ks) {
@@ -1184,6 +1261,11 @@ static int gather_bytes(int dtype, int cp) {
   return (cp % 8 == 0) ? 16 : 8;                    // bf16: 8 elements, or 4 for the padded RGB input
 }
 
+static bool f32_exact() {
+  static const bool v = getenv("DUALVAR_F32_EXACT") && atoi(getenv("DUALVAR_F32_EXACT")) != 0;
+  return v;
+}
+
 static int pick_bn(int np) {
   if (np <= 32) return 32;
   if (np <= 64) return 64;
@@ -1201,23 +1283,38 @@ static int pick_bm(int M, int ntn) {
 // padding, rows 128 when that still gives >= 1024 workgroups, else 64.  (96- and 192-column tiles -- wave tiles 32x96
 // and 64x96 -- were measured too: 15-20 % faster on random data in isolation, but equal within noise inside the real
 // training step, where post-ReLU activations are half zeros and the clocks are higher; not kept.)
-static void pick_tile(int M, int NP, int& bm, int& bn) {
+// fp32 through the bf16 split (split3): every fragment costs ~44 vector instructions to split, so the kernel is bound
+// by the vector ALU unless a fragment feeds enough MFMAs -- 256 x 64 tiles (wave tiles 64x64: 1 fragment per 32x32 block
+// instead of the 1.5 of 128 x 64) wherever the grid still fills the chip twice over (c2c 1x3x3 forward 664 -> 609 us;
+// a 256 x 128 tile with 128 x 64 wave tiles spills registers and is far slower).
+static void pick_tile(int dtype, int M, int NP, int& bm, int& bn) {
   bn = pick_bn(NP);
-  bm = pick_bm(M, (NP + bn - 1) / bn);
+  const int ntn = (NP + bn - 1) / bn;
+  bm = pick_bm(M, ntn);
+  static const int big = getenv("DUALVAR_F32_BM256") ? atoi(getenv("DUALVAR_F32_BM256")) : 1;
+  if (dtype == DV_F32 && !f32_exact() && big && bm == 128 && bn == 64 && (int64_t)((M + 255) / 256) * ntn >= 512) bm = 256;
 }
 
-template <typename T, int MODE, int GVB, int GM, int NS>
+template <typename T, int MODE, int GVB, int GM, int NS, bool SPLIT = false>
 static void launch_gemm_ns(int bm, int bn, const ConvArgs& a, int grid, hipStream_t s) {
+  if constexpr (SPLIT) {
+    if (bm == 256) {
+      hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 256, 64, 4, 1, GM, NS, SPLIT>), dim3(grid), dim3(256), 0, s, a);
+      return;
+    }
+  }
   if (bm == 64) {
-    if (bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 32, 2, 1, GM, NS>), dim3(grid), dim3(128), 0, s, a);
-    else if (bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 64, 2, 2, GM, NS>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 128, 2, 2, GM, NS>), dim3(grid), dim3(256), 0, s, a);
+    if (bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 32, 2, 1, GM, NS, SPLIT>), dim3(grid), dim3(128), 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 64, 2, 2, GM, NS, SPLIT>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 128, 2, 2, GM, NS, SPLIT>), dim3(grid), dim3(256), 0, s, a);
     return;
   }
-  if (bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 32, 4, 1, GM, NS>), dim3(grid), dim3(256), 0, s, a);
-  else if (bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 64, 4, 1, GM, NS>), dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 128, 2, 2, GM, NS>), dim3(grid), dim3(256), 0, s, a);
+  if (bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 32, 4, 1, GM, NS, SPLIT>), dim3(grid), dim3(256), 0, s, a);
+  else if (bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 64, 4, 1, GM, NS, SPLIT>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 128, 2, 2, GM, NS, SPLIT>), dim3(grid), dim3(256), 0, s, a);
 }
+
+
 
 // Two LDS stages where the grid fills the chip several times over: there three to six stages measured equal or slower
 // (they cost resident workgroups, and the K loop is issue bound).  Launches of at most ~2 workgroups per CU (64-row tiles
@@ -1234,6 +1331,12 @@ static void launch_gemm_gm(int bm, int bn, const ConvArgs& a, int grid, hipStrea
       if (grid <= tiny_grid) launch_gemm_ns<T, MODE, GVB, GM, 6>(bm, bn, a, grid, s);
       else if (ns_small == 3) launch_gemm_ns<T, MODE, GVB, GM, 3>(bm, bn, a, grid, s);
       else launch_gemm_ns<T, MODE, GVB, GM, 4>(bm, bn, a, grid, s);
+      return;
+    }
+  }
+  if constexpr (sizeof(T) == 4) {
+    if (!f32_exact()) {
+      launch_gemm_ns<T, MODE, GVB, GM, 2, true>(bm, bn, a, grid, s);
       return;
     }
   }
@@ -1257,8 +1360,9 @@ static void launch_gemm(int bm, int bn, const ConvArgs& a, int grid, hipStream_t
 extern "C" int dv_conv3d_tile_rows(const dv_conv_desc* d) {
   if (!d) return DV_EINVAL;
   const int64_t m = (int64_t)d->N * d->To * d->Ho * d->Wo;
-  const int bn = pick_bn(d->cout_pitch);
-  return pick_bm((int)m, (d->cout_pitch + bn - 1) / bn);
+  int bm, bn;
+  pick_tile(d->dtype, (int)m, d->cout_pitch, bm, bn);
+  return bm;
 }
 
 extern "C" int dv_conv3d_tile_shape(const dv_conv_desc* d, int32_t dgrad, int32_t* rows, int32_t* cols) {
@@ -1266,10 +1370,10 @@ extern "C" int dv_conv3d_tile_shape(const dv_conv_desc* d, int32_t dgrad, int32_
   int bm, bn;
   if (dgrad) {
     const int64_t m = (int64_t)d->N * d->Ti * d->Hi * d->Wi;
-    pick_tile((int)m, d->cin_pitch, bm, bn);
+    pick_tile(d->dtype, (int)m, d->cin_pitch, bm, bn);
   } else {
     const int64_t m = (int64_t)d->N * d->To * d->Ho * d->Wo;
-    pick_tile((int)m, d->cout_pitch, bm, bn);
+    pick_tile(d->dtype, (int)m, d->cout_pitch, bm, bn);
   }
   *rows = bm; *cols = bn;
   return DV_OK;
@@ -1312,7 +1416,7 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   const int esz = d->dtype == DV_F32 ? 4 : 2;
   if ((d->ldx * esz) % gvb || (a.ldw * esz) % gvb) return DV_EALIGN;
   int bm, bn;
-  pick_tile(a.M, a.NP, bm, bn);
+  pick_tile(d->dtype, a.M, a.NP, bm, bn);
   a.ntn = (a.NP + bn - 1) / bn;
   const int grid = a.ntn * ((a.M + bm - 1) / bm);
   hipStream_t s = (hipStream_t)stream;
@@ -1372,7 +1476,7 @@ extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void
           c.cls_on = 1; c.cst = d->st; c.csh = d->sh; c.csw = d->sw; c.cot = ot; c.coh = oh; c.cow = ow;
           c.crt = rt; c.crh = rh; c.crw = rw; c.oKH = d->kh; c.oKW = d->kw; c.oT = d->Ti; c.oH = d->Hi; c.oW = d->Wi;
           int bm, bn;
-          pick_tile(c.M, c.NP, bm, bn);
+          pick_tile(d->dtype, c.M, c.NP, bm, bn);
           c.ntn = (c.NP + bn - 1) / bn;
           const int grid = c.ntn * ((c.M + bm - 1) / bm);
           if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, c, grid, s);
@@ -1381,7 +1485,7 @@ extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void
     return dv_launch_status();
   }
   int bm, bn;
-  pick_tile(a.M, a.NP, bm, bn);
+  pick_tile(d->dtype, a.M, a.NP, bm, bn);
   a.ntn = (a.NP + bn - 1) / bn;
   const int grid = a.ntn * ((a.M + bm - 1) / bm);
   if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, a, grid, s);
@@ -1394,6 +1498,8 @@ struct WgradCfg { int BI, BJ, WVI, WVJ, NS; };
 // DMA-kernel configurations.  The kernel is bound by what a CU can pull from L2 into LDS (~70 GB/s per CU): the bytes
 // filled per unit of work go with 1/BI + 1/BJ, so the largest tile that wastes little padding wins -- see plan_wgrad.
 static const WgradCfg kWgBf16[] = {{128, 128, 2, 2, 3}, {64, 256, 1, 4, 3}, {128, 256, 2, 2, 3}, {192, 256, 3, 4, 4}};
+// (f32 split mode: a two-wave 64 x 128 workgroup with 64 x 64 wave tiles -- one fragment split per 32x32 block instead of
+// 1.5 -- was measured slower than the four-wave one with 32 x 64 wave tiles: 950 vs 827 us on the 7x1x1 stem layer)
 static const WgradCfg kWgF32[] = {{128, 128, 2, 2, 2}, {64, 128, 2, 2, 2}};
 
 struct WgradPlan {
@@ -1515,8 +1621,8 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
     aa.w = a;
     aa.x_bytes = (int)(((int64_t)d->N * d->Ti * d->Hi * d->Wi - 1) * d->ldx * es + (int64_t)d->cin_pitch * es);
     aa.dy_bytes = (int)(((int64_t)a.M - 1) * d->ldy * es + (int64_t)d->cout_pitch * es);
-#define WGD(T_, BI_, BJ_, WI_, WJ_, NS_) \
-  hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, BI_, BJ_, WI_, WJ_, NS_>), dim3(grid), dim3(WI_ * WJ_ * 64), 0, s, aa)
+#define WGD(T_, BI_, BJ_, WI_, WJ_, NS_, ...) \
+  hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, BI_, BJ_, WI_, WJ_, NS_, ##__VA_ARGS__>), dim3(grid), dim3(WI_ * WJ_ * 64), 0, s, aa)
     if (d->dtype == DV_BF16) {
       switch (p.cfg) {
         case 0: WGD(bf16_t, 128, 128, 2, 2, 3); break;
@@ -1525,8 +1631,13 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
         default: WGD(bf16_t, 192, 256, 3, 4, 4); break;
       }
     } else {
-      if (p.cfg == 1) WGD(float, 64, 128, 2, 2, 2);
-      else WGD(float, 128, 128, 2, 2, 2);
+      if (f32_exact()) {
+        if (p.cfg == 1) WGD(float, 64, 128, 2, 2, 2);
+        else WGD(float, 128, 128, 2, 2, 2);
+      } else {
+        if (p.cfg == 1) WGD(float, 64, 128, 2, 2, 2, true);
+        else WGD(float, 128, 128, 2, 2, 2, true);
+      }
     }
 #undef WGD
   } else {

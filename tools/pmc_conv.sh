@@ -1,7 +1,7 @@
 #!/bin/bash
-# PMC passes over one microbenchmarked conv layer (development aid).  usage: tools/pmc_conv.sh <layer> <pass> <outdir>
+# PMC passes over one microbenchmarked conv layer (development aid).  usage: tools/pmc_conv.sh <layer> <pass> <outdir> [extra microbench args, e.g. --dtype fp32]
 set -e
-LAYER=${1:-c2c_3x1x1}; PASS=${2:-fwd}; OUT=${3:-gpurun_out/pmcconv}
+LAYER=${1:-c2c_3x1x1}; PASS=${2:-fwd}; OUT=${3:-gpurun_out/pmcconv}; EXTRA="${@:4}"
 export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
@@ -11,7 +11,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_WAVES SQ_INSTS_SMEM" \
            "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -k 10 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -- python tools/conv_microbench.py --layers $LAYER --passes $PASS --reps 3 > $OUT.p$i.log 2>&1
+  timeout -k 10 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -- python tools/conv_microbench.py --layers $LAYER --passes $PASS --reps 3 $EXTRA > $OUT.p$i.log 2>&1
   echo "pass $i done"
 done
 python - "$OUT" <<'PY'
