@@ -79,7 +79,7 @@ SIGNATURES = {
     'dv_softmax_ce_fwd': [P, I32, I32, I32, P, P, P, I32, P, P],
     'dv_knn_rank': [P, I32, I32, I32, P, P, P, P],
     'dv_softmax_rows_f32': [P, I32, I32, I32, P, I32, P],
-    'dv_augment_ingest': [I32, P, I32, I32, I32, P, I32, I32, I32, I32, P, I32, I32, P, P, P, I32, P, P],
+    'dv_augment_ingest': [I32, P, I32, I32, I32, P, I32, I32, I32, I32, P, I32, I32, P, P, P, I32, P, P, P, P],
     'dv_bn_reduce_stats': [P, I32, I32, I32, I64, I32, P, P],
     'dv_bn_finalize': [P, I32, I32, I32, P, P, F, F, P, P, P, P, P, P, P],
     'dv_bn_stats_finalize': [P, I32, I32, I32, I64, I32, P, P, P, F, F, P, P, P, P, P, P, P],

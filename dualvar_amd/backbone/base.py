@@ -43,6 +43,8 @@ class IngestOp(Op):
         if isinstance(x, FrameBatch):
             if self.cmean is None:
                 self.cmean = torch.empty(self.N * self.T, dtype=torch.float32, device=x.device)
+            if x.blur is not None and getattr(self, 'blur_tmp', None) is None:      # quantised frames in front of the blur
+                self.blur_tmp = torch.empty(self.N * self.T * self.H * self.W * 3, dtype=torch.uint8, device=x.device)
             return
         self.stride_n = x.stride(0) if x.dim() == 5 else 3 * self.T * self.H * self.W
 
@@ -57,7 +59,9 @@ class IngestOp(Op):
                                             self.mean.data_ptr() if self.mean is not None else 0,
                                             self.istd.data_ptr() if self.istd is not None else 0,
                                             self.perm.data_ptr() if self.perm is not None else 0,
-                                            self.n_seg if self.perm is not None else 0, self.cmean.data_ptr(), stream),
+                                            self.n_seg if self.perm is not None else 0, self.cmean.data_ptr(),
+                                            fb.blur.data_ptr() if fb.blur is not None else 0,
+                                            self.blur_tmp.data_ptr() if fb.blur is not None else 0, stream),
                     'dv_augment_ingest')
             return
         L.check(p.lib.dv_ingest_ncdhw_pad(p.dtype, self.src.data_ptr(), self.y.ptr, self.N, 3, self.T, self.H, self.W,

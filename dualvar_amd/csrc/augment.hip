@@ -1,5 +1,5 @@
-// Augmenting ingest: decoded uint8 frames -> crop / resize / flip / colour jitter / grayscale / Normalize -> NDHWC
-// activations of the RGB stem, in two launches.  The arithmetic follows the reference's tensor-side
+// Augmenting ingest: decoded uint8 frames -> crop / resize / flip / colour jitter / grayscale / Gaussian blur / Normalize ->
+// NDHWC activations of the RGB stem, in two launches (three with blurred frames).  The arithmetic follows the reference's tensor-side
 // definitions, utils/transforms.py:13-31 (crop, hflip), :33-42 (bilinear resize, align_corners=False), :49-51 (/255),
 // :57-63 (normalize), :66-78 (luma), :90-163 (brightness / contrast / saturation blends with clamp to [0, 1]).
 #include "common.hpp"
@@ -15,6 +15,8 @@ struct AugArgs {
   const float* mean3;
   const float* istd3;
   float* cmean;                     // [F] mean luma in front of the contrast op
+  const dv_aug_blur* blur;          // optional [F]: Gaussian blur of the finished frame (ww == 0: none)
+  uint8_t* u8tmp;                   // [F][H][W][3] quantised frames in front of the blur
   int n_src, Hs, Ws, F, T, n_seg, H, W, ldy, pad, Hp, Wp;
 };
 
@@ -146,6 +148,12 @@ __global__ void __launch_bounds__(kThreads) aug_apply_kernel(AugArgs a, T* __res
     const int hh = hw / a.W, ww = hw - hh * a.W;
     const dv_aug_frame q = a.tab[table_row(a, f)];
     Rgb p = colour_ops(sample(a, q, hh, ww), q, DV_AUG_MAX_OPS, contrast_pos(q) >= 0 ? a.cmean[f] : 0.f);
+    if (a.blur && a.blur[table_row(a, f)].ww != 0) {
+      // this frame goes through the blur: ToPILImage() of the float frame = mul(255).byte() (truncation), utils/augmentation.py:719
+      uint8_t* u = a.u8tmp + ((int64_t)f * px + hw) * 3;
+      u[0] = (uint8_t)(p.r * 255.f); u[1] = (uint8_t)(p.g * 255.f); u[2] = (uint8_t)(p.b * 255.f);
+      continue;
+    }
     if (a.mean3) {
       p.r = (p.r - a.mean3[0]) * a.istd3[0];
       p.g = (p.g - a.mean3[1]) * a.istd3[1];
@@ -163,12 +171,56 @@ __global__ void __launch_bounds__(kThreads) aug_apply_kernel(AugArgs a, T* __res
   }
 }
 
+// Gaussian blur as PIL's ImageFilter.GaussianBlur does it (utils/augmentation.py:706-721 calls it on the uint8 frame): three
+// horizontal then three vertical passes of an "extended box filter" in 8.24 fixed point (Pillow, src/libImaging/BoxBlur.c:
+// out[x] = (ww * sum_{|d| <= r} in[x+d] + fw * (in[x-r-1] + in[x+r+1]) + 2^23) >> 24, indices clamped to the line, the result
+// of every pass re-quantised to uint8).  r, ww, fw come from the host (dualvar_amd/utils/transforms.py restates Pillow's
+// float32 radius arithmetic), so the kernel is integer only: bit-exact with PIL.  One workgroup per (frame, channel), the
+// plane ping-pongs between two LDS images; then ToTensor (/255), Normalize and the store into the stem's NDHWC input.
+template <typename T>
+__global__ void __launch_bounds__(kThreads) aug_blur_kernel(AugArgs a, T* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_blur[];
+  const int f = blockIdx.x / 3, c = blockIdx.x - f * 3;
+  const dv_aug_blur b = a.blur[table_row(a, f)];
+  if (b.ww == 0) return;
+  const int H = a.H, W = a.W, px = H * W, r = b.radius;
+  uint8_t* cur = lds_blur;
+  uint8_t* nxt = lds_blur + px;
+  const uint8_t* src = a.u8tmp + (int64_t)f * px * 3 + c;
+  for (int i = threadIdx.x; i < px; i += kThreads) cur[i] = src[(int64_t)i * 3];
+  __syncthreads();
+  for (int pass = 0; pass < 6; ++pass) {
+    const bool horiz = pass < 3;
+    const int n = horiz ? W : H, stride = horiz ? 1 : W;
+    for (int i = threadIdx.x; i < px; i += kThreads) {
+      const int hh = i / W, wx = i - hh * W;
+      const int x = horiz ? wx : hh;
+      const uint8_t* line = cur + (horiz ? hh * W : wx);
+      uint32_t acc = 0;
+      for (int d = -r; d <= r; ++d) acc += line[min(max(x + d, 0), n - 1) * stride];
+      const uint32_t far = (uint32_t)line[min(max(x - r - 1, 0), n - 1) * stride] + (uint32_t)line[min(max(x + r + 1, 0), n - 1) * stride];
+      const uint32_t bulk = acc * b.ww + far * b.fw;                       // (mod 2^32, as the UINT32 arithmetic of BoxBlur.c)
+      nxt[i] = (uint8_t)((bulk + (1u << 23)) >> 24);
+    }
+    __syncthreads();
+    uint8_t* t = cur; cur = nxt; nxt = t;
+  }
+  const float m = a.mean3 ? a.mean3[c] : 0.f, is = a.mean3 ? a.istd3[c] : 1.f;
+  for (int i = threadIdx.x; i < px; i += kThreads) {
+    const int hh = i / W, wx = i - hh * W;
+    float v = (float)cur[i] / 255.f;                                        // ToTensor()
+    if (a.mean3) v = (v - m) * is;
+    y[(((int64_t)f * a.Hp + hh + a.pad) * a.Wp + wx + a.pad) * a.ldy + c] = DT<T>::from_f(v);
+  }
+}
+
 }  // namespace
 
 extern "C" int dv_augment_ingest(int32_t dtype, const uint8_t* frames, int32_t n_src, int32_t Hs, int32_t Ws,
                                  const dv_aug_frame* table, int32_t N, int32_t T_, int32_t H, int32_t W, void* y, int32_t ldy,
                                  int32_t pad, const float* mean3, const float* istd3, const int32_t* perm, int32_t n_seg,
-                                 float* scratch, void* stream) {
+                                 float* scratch, const dv_aug_blur* blur, uint8_t* blur_scratch, void* stream) {
+  if (blur && (!blur_scratch || (int64_t)H * W * 2 > 160 * 1024)) return DV_EINVAL;
   if (!frames || !table || !y || !scratch || n_src <= 0 || Hs <= 0 || Ws <= 0 || N <= 0 || T_ <= 0 || H <= 0 || W <= 0 ||
       ldy < 4 || ldy % 4 || pad < 0)
     return DV_EINVAL;
@@ -178,6 +230,7 @@ extern "C" int dv_augment_ingest(int32_t dtype, const uint8_t* frames, int32_t n
   if (dtype != DV_F32 && dtype != DV_BF16) return DV_EUNSUPPORTED;
   AugArgs a;
   a.frames = frames; a.tab = table; a.perm = perm; a.mean3 = mean3; a.istd3 = istd3; a.cmean = scratch;
+  a.blur = blur; a.u8tmp = blur_scratch;
   a.n_src = n_src; a.Hs = Hs; a.Ws = Ws; a.F = N * T_; a.T = T_; a.n_seg = perm ? n_seg : 1;
   a.H = H; a.W = W; a.ldy = ldy; a.pad = pad; a.Hp = H + 2 * pad; a.Wp = W + 2 * pad;
   hipStream_t st = (hipStream_t)stream;
@@ -190,5 +243,17 @@ extern "C" int dv_augment_ingest(int32_t dtype, const uint8_t* frames, int32_t n
     hipLaunchKernelGGL((aug_apply_kernel<float>), dim3(blocks), dim3(kThreads), 0, st, a, (float*)y);
   else
     hipLaunchKernelGGL((aug_apply_kernel<bf16_t>), dim3(blocks), dim3(kThreads), 0, st, a, (bf16_t*)y);
+  if (blur) {
+    rc = dv_launch_status();
+    if (rc) return rc;
+    const size_t lds = (size_t)H * W * 2;
+    if (dtype == DV_F32) {
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)aug_blur_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((aug_blur_kernel<float>), dim3(a.F * 3), dim3(kThreads), lds, st, a, (float*)y);
+    } else {
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)aug_blur_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((aug_blur_kernel<bf16_t>), dim3(a.F * 3), dim3(kThreads), lds, st, a, (bf16_t*)y);
+    }
+  }
   return dv_launch_status();
 }

@@ -36,6 +36,27 @@ AUG_NONE, AUG_BRIGHTNESS, AUG_CONTRAST, AUG_SATURATION, AUG_GRAY, AUG_HUE = 0, 1
 AUG_MAX_OPS = 5
 AUG_ROW = np.dtype([('src', '<i4'), ('crop_i', '<i4'), ('crop_j', '<i4'), ('crop_h', '<i4'), ('crop_w', '<i4'), ('flip', '<i4'),
                     ('op', '<i4', (AUG_MAX_OPS,)), ('factor', '<f4', (AUG_MAX_OPS,))])                   # include/dualvar_hip.h
+AUG_BLUR = np.dtype([('radius', '<i4'), ('ww', '<u4'), ('fw', '<u4'), ('_pad', '<i4')])                  # dv_aug_blur
+
+
+def box_blur_params(sigma, passes=3):
+    """ImageFilter.GaussianBlur(radius=sigma) as Pillow runs it: `passes` extended box filters per axis (src/libImaging/
+    BoxBlur.c).  -> (integer radius, ww, fw), the 8.24 fixed-point weights of the 2*radius+1 inner taps and of the two outer
+    ones, computed with Pillow's own float32 sequence (`_gaussian_blur_radius`: Gwosdek et al., box length sqrt(12 s^2/n + 1))
+    so that the integer kernel (csrc/augment.hip: aug_blur_kernel) reproduces PIL bit for bit."""
+    f = np.float32
+    radius = f(sigma)
+    sigma2 = f(f(radius * radius) / f(passes))
+    L = f(np.sqrt(12.0 * float(sigma2) + 1.0))
+    lo = f(np.floor((float(L) - 1.0) / 2.0))
+    a = f(f(f(2) * lo + f(1)) * f(f(lo * f(lo + f(1))) - f(f(3) * sigma2)))
+    a = f(a / f(f(6) * f(sigma2 - f(f(lo + f(1)) * f(lo + f(1))))))
+    fr = f(lo + a)
+    if fr == 0:
+        return 0, 0, 0
+    r = int(fr)
+    ww = int(f(16777216.0) / f(f(fr) * f(2) + f(1)))
+    return r, ww, ((1 << 24) - (r * 2 + 1) * ww) // 2
 
 
 class ClipState:
@@ -47,6 +68,7 @@ class ClipState:
         self.out = None                                        # (H, W) once a Resize / RandomSizedCrop fixed it
         self.flip = False
         self.ops = []                                          # [(code, factors[N])], in applied order
+        self.sigma = None                                      # per-frame Gaussian blur sigma (0: none), set by GaussianBlur
 
     @property
     def N(self):
@@ -56,6 +78,8 @@ class ClipState:
         return self.out if self.out is not None else (self.h, self.w)
 
     def _no_colour_yet(self, what):
+        if self.sigma is not None:
+            raise ValueError('%s after the Gaussian blur: the blur is the last op of a dv_augment_ingest pipeline' % what)
         if self.ops:
             raise ValueError('%s after a colour op is not expressible in one dv_augment_ingest row' % what)
 
@@ -84,6 +108,15 @@ class ClipState:
                 t['op'][n, k], t['factor'][n, k] = code, fac[n]
                 k += 1
         return t
+
+    def blur_rows(self):
+        """dv_aug_blur rows of the clip's frames (all zero when the clip is not blurred)"""
+        b = np.zeros(self.N, dtype=AUG_BLUR)
+        if self.sigma is not None:
+            for n in range(self.N):
+                if self.sigma[n] > 0:
+                    b['radius'][n], b['ww'][n], b['fw'][n] = box_blur_params(self.sigma[n])
+        return b
 
 
 def _corner(h, w, th, tw):
@@ -232,6 +265,41 @@ class ColorJitter(object):                                  # transforms.py:313-
         return st
 
 
+class GaussianBlur(object):
+    """utils/augmentation.py:706-721 (the SimCLR blur, `A.GaussianBlur([.1, 2.], seq_len=...)` of pretrain.py:505): one sigma
+    per block of `n_seqblock` frames (default: the whole clip), drawn with random.uniform as the reference draws it; the
+    frames go ToPILImage -> PIL ImageFilter.GaussianBlur(radius=sigma) -> ToTensor.  Must be the last op of a pipeline: it
+    works on the finished, re-quantised uint8 frame."""
+
+    def __init__(self, sigma=(.1, 2.), seq_len=16, n_seqblock=0):
+        self.sigma, self.seq_len = list(sigma), seq_len
+        self.n_seqblock = n_seqblock if n_seqblock != 0 else seq_len
+
+    def __call__(self, st):
+        sig = np.zeros(st.N, dtype=np.float64)
+        for idx in range(st.N):
+            if idx % self.n_seqblock == 0:
+                sigma = random.uniform(self.sigma[0], self.sigma[1])
+            sig[idx] = sigma
+        st.sigma = sig
+        return st
+
+
+class RandomApply(object):
+    """torchvision.transforms.RandomApply as pretrain.py:499-505 uses it: the wrapped transforms run when a draw from
+    torch's RNG is below p (`if self.p < torch.rand(1): return img`)"""
+
+    def __init__(self, transforms, p=0.5):
+        self.transforms, self.p = list(transforms), p
+
+    def __call__(self, st):
+        if self.p < float(torch.rand(1)):
+            return st
+        for t in self.transforms:
+            st = t(st)
+        return st
+
+
 class Compose(object):
     def __init__(self, transforms):
         self.transforms = list(transforms)
@@ -246,11 +314,12 @@ class FrameBatch(object):
     """Decoded uint8 frames + one augmentation row per output frame: what the backbones' ingest consumes in place of a
     float clip tensor.  Quacks like the `[B, V, 3, T, H, W]` (or `[N, 3, T, H, W]`) tensor the models index."""
 
-    def __init__(self, frames, table, shape):
+    def __init__(self, frames, table, shape, blur=None):
         if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
             raise ValueError('frames must be uint8 [n_src, Hs, Ws, 3]')
         self.frames = frames.contiguous()
         self.table = table                                   # uint8 device tensor [rows * 64], rows in clip-major order
+        self.blur = blur                                     # None, or uint8 device tensor [rows * 16] (dv_aug_blur), same order
         self.shape = torch.Size(shape)
         rows = 1
         for d in self.shape[:-4]:
@@ -264,16 +333,19 @@ class FrameBatch(object):
         """frames: uint8 [n_src, Hs, Ws, 3]; clips: per sample the source-frame indices of its T frames; every one of
         the `views` views of a sample draws its own augmentation (pretrain's two clips of a video)."""
         Hs, Ws = frames.shape[1:3]
-        rows = []
+        rows, blurs = [], []
         for src in clips:
             for _ in range(views):
-                rows.append(transform(ClipState(src, Hs, Ws)).rows(*size))
+                st = transform(ClipState(src, Hs, Ws))
+                rows.append(st.rows(*size))
+                blurs.append(st.blur_rows())
         T = len(clips[0])
-        tab = np.concatenate(rows)
+        tab, btab = np.concatenate(rows), np.concatenate(blurs)
         device = device if device is not None else frames.device
         t = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
+        b = torch.from_numpy(btab.view(np.uint8).copy()).to(device) if btab['ww'].any() else None
         shape = (len(clips), views, 3, T) + tuple(size) if views > 1 else (len(clips), 3, T) + tuple(size)
-        return cls(frames.to(device), t, shape)
+        return cls(frames.to(device), t, shape, blur=b)
 
     def dim(self):
         return len(self.shape)
@@ -292,7 +364,7 @@ class FrameBatch(object):
         n = 1
         for d in s[:-4]:
             n *= d
-        return FrameBatch(self.frames, self.table, (n,) + tuple(s[-4:]))
+        return FrameBatch(self.frames, self.table, (n,) + tuple(s[-4:]), blur=self.blur)
 
     def reshape(self, *shape):
         shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
@@ -316,7 +388,12 @@ class FrameBatch(object):
             if b.frames.data_ptr() != first.frames.data_ptr() or tuple(b.shape[1:]) != tuple(first.shape[1:]):
                 raise ValueError('FrameBatch.cat: batches must share their frames and per-sample shape')
         table = torch.cat([b.table.view(-1) for b in batches])
-        return FrameBatch(first.frames, table, (sum(b.shape[0] for b in batches),) + tuple(first.shape[1:]))
+        blur = None
+        if any(b.blur is not None for b in batches):
+            blur = torch.cat([b.blur.view(-1) if b.blur is not None else
+                              torch.zeros(b.table.numel() // AUG_ROW.itemsize * AUG_BLUR.itemsize, dtype=torch.uint8, device=b.table.device)
+                              for b in batches])
+        return FrameBatch(first.frames, table, (sum(b.shape[0] for b in batches),) + tuple(first.shape[1:]), blur=blur)
 
     def __getitem__(self, idx):
         # block[:, v]: one view of every sample
@@ -324,5 +401,8 @@ class FrameBatch(object):
             B, V, _, T = self.shape[:4]
             rb = T * AUG_ROW.itemsize
             t = self.table.view(B, V, rb)[:, idx[1]].contiguous().view(-1)
-            return FrameBatch(self.frames, t, (B,) + tuple(self.shape[2:]))
+            bl = None
+            if self.blur is not None:
+                bl = self.blur.view(B, V, T * AUG_BLUR.itemsize)[:, idx[1]].contiguous().view(-1)
+            return FrameBatch(self.frames, t, (B,) + tuple(self.shape[2:]), blur=bl)
         raise NotImplementedError('FrameBatch supports block[:, v] only')

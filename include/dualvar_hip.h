@@ -150,7 +150,8 @@ int dv_fill_cols_f32(float* p, int64_t rows, int32_t pitch, int32_t col0, int32_
  * -> RGB of utils/augmentation.py:26-106 (`adjust_hue_np`, without its uint8 re-quantisation) -- then Normalize, and the NDHWC store of
  * dv_ingest_ncdhw_pad (4th channel zero, optional zero border, optional segment shuffle of table rows).
  * `table` and `perm` are DEVICE arrays; indices and windows are clamped into the source, so a bad row cannot fault.
- * At most one contrast op per frame.  scratch: N*T floats (mean luma in front of the contrast op).  Two launches. */
+ * At most one contrast op per frame.  scratch: N*T floats (mean luma in front of the contrast op).  Two launches (three
+ * with `blur`). */
 enum { DV_AUG_NONE = 0, DV_AUG_BRIGHTNESS = 1, DV_AUG_CONTRAST = 2, DV_AUG_SATURATION = 3, DV_AUG_GRAY = 4, DV_AUG_HUE = 5 };
 #define DV_AUG_MAX_OPS 5
 typedef struct dv_aug_frame {
@@ -161,10 +162,22 @@ typedef struct dv_aug_frame {
   int32_t op[DV_AUG_MAX_OPS];      /* DV_AUG_*, applied in this order */
   float factor[DV_AUG_MAX_OPS];    /* blend ratio of op[k]; hue shift in turns for DV_AUG_HUE; unused for GRAY / NONE */
 } dv_aug_frame;                    /* 64 bytes per row */
+/* Gaussian blur of the finished (colour-jittered, re-quantised) frame, as the reference applies it through PIL
+ * (utils/augmentation.py:706-721: ToPILImage -> ImageFilter.GaussianBlur(radius=sigma) -> ToTensor, one sigma per clip).
+ * Pillow approximates the Gaussian by three passes of an extended box filter per axis in 8.24 fixed point
+ * (src/libImaging/BoxBlur.c); a row carries that filter's integer parameters, derived from sigma on the host with Pillow's
+ * own float32 arithmetic (dualvar_amd/utils/transforms.py: box_blur_params), so the device side is exact integer work.
+ * ww == 0: the frame is not blurred. */
+typedef struct dv_aug_blur {
+  int32_t radius;                  /* integer part of the box radius */
+  uint32_t ww, fw;                 /* 8.24 weights of the 2*radius+1 inner taps / of the two outer taps */
+  int32_t _pad;
+} dv_aug_blur;                     /* 16 bytes per row, rows parallel to `table` */
+/* blur: NULL, or N*T rows; blur_scratch: N*T*H*W*3 bytes (needed when blur != NULL; H*W*2 bytes of LDS per workgroup) */
 int dv_augment_ingest(int32_t dtype, const uint8_t* frames, int32_t n_src, int32_t Hs, int32_t Ws,
                       const dv_aug_frame* table, int32_t N, int32_t T, int32_t H, int32_t W, void* y, int32_t ldy,
                       int32_t pad, const float* mean3, const float* istd3, const int32_t* perm, int32_t n_seg,
-                      float* scratch, void* stream);
+                      float* scratch, const dv_aug_blur* blur, uint8_t* blur_scratch, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * BatchNorm3d, training mode (nn.BatchNorm3d at s3dg.py:16,46-47, r21d.py:56,99,106,111,228, ...;

@@ -22,6 +22,7 @@ from oracle import harness, procedural as P, torch_ref as O   # noqa: E402
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 ARGS = types.SimpleNamespace(shufflerank_theta=0.05)
 CLIP = dict(T=8, H=112, W=112)
+WC_LR = 3e-7         # learning rate of the well-conditioned multi-step runs (case_models)
 
 
 def _init_pg(rank=0, world=1, port=29531):
@@ -64,7 +65,8 @@ def param_checksum(model):
 
 def run_model(model, block, steps, np_seed, lr=0.003):
     """`steps` iterations of pretrain.py:394-451 on the same block.  Records step-0 outputs,
-    step-0 gradients, and the parameter checksum after the last step."""
+    step-0 gradients (checksums of every tensor + element-wise samples of ~30 of them, oracle/procedural.py:
+    grad_samples), and the parameter checksum after the last step."""
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.SGD([{'params': [p]} for p in params], lr=lr, weight_decay=1e-4, momentum=0.9)
@@ -93,6 +95,9 @@ def run_model(model, block, steps, np_seed, lr=0.003):
             rec[f'{tag}/total_loss'] = np.array(float(loss))
             for k, v in grad_summary(model).items():
                 rec[f'{tag}/grad/' + k] = v
+            if it == 0:
+                for k, v in P.grad_samples(model).items():
+                    rec['first/gsample/' + k] = v
         opt.step()
         rec['loss_step%d' % it] = np.array(float(loss))
     for k, v in param_checksum(model).items():
@@ -103,9 +108,30 @@ def run_model(model, block, steps, np_seed, lr=0.003):
     return rec
 
 
+def gsample_noise_floor(ns, kind, net, distributed, block, np_seed=1234):
+    """max |g_fp32 - g_fp64| per sampled gradient tensor, for the REFERENCE itself at step 0: what rounding alone does to a
+    correct fp32 implementation (sums over 1e5 rows with cancellation -- BatchNorm beta / gamma gradients -- sit far above
+    `1e-4 max|g|`).  Tests never ask for better agreement than a multiple of this."""
+    outs = []
+    for dt in (torch.float32, torch.float64):
+        torch.manual_seed(0)
+        m = build(ns, kind, net, distributed)
+        P.procedural_init(m)
+        m.train().to(dt)
+        np.random.seed(np_seed)
+        ret = m(block.to(dt))
+        loss = ret['clip_contrast_loss'] if 'clip_contrast_loss' in ret else 0
+        for key in ret:
+            if 'loss' in key and 'clip' not in key:
+                loss = loss + ret[key]
+        loss.backward()
+        outs.append(P.grad_samples(m))
+    return {k: float(np.max(np.abs(outs[0][k] - outs[1][k]))) for k in outs[0]}
+
+
 def compare(a, b, tag, tol=5e-4):
-    a = {k: v for k, v in a.items() if not k.startswith('sens/')}
-    b = {k: v for k, v in b.items() if not k.startswith('sens/')}
+    a = {k: v for k, v in a.items() if not k.startswith(('sens/', 'f64/'))}
+    b = {k: v for k, v in b.items() if not k.startswith(('sens/', 'f64/'))}
     assert a.keys() == b.keys(), (tag, set(a) ^ set(b))
     worst = 0.0
     for k in a:
@@ -247,12 +273,13 @@ def case_classifier_train(ref):
 
 
 def case_backbones_extra(ref):
-    """the remaining names of the reference factory (select_backbone.py:9-27): r2d3d18 and c3d -- train-mode features,
+    """the remaining names of the reference factory (select_backbone.py:9-27): r2d3d18, c3d and s3d (S3D without
+    self-gating, backbone/s3dg.py:135 gating=False) -- train-mode features,
     then eval() on other clips (pins the conv-bias handling of c3d through the running mean)"""
     rec = {}
     xa = P.procedural_clips(4, 1, **CLIP)[:, 0]
     xb = P.procedural_clips(4, 1, seed=77, **CLIP)[:, 0]
-    for net in ('r2d3d18', 'c3d'):
+    for net in ('r2d3d18', 'c3d', 's3d'):
         outs = []
         for sel in (ref.select_backbone, O.select_backbone):
             m, _ = sel(net)
@@ -278,9 +305,12 @@ def case_backbones_extra(ref):
 
 def case_models(ref):
     _init_pg()
+    only = os.environ.get('GOLDEN_ONLY')                 # e.g. moco_timeseriesv4:s3dg -- regenerate one fixture
     for kind, net, B in (('simclr_naked', 's3dg', 4), ('simclr_timeseriesv4', 's3dg', 4),
                          ('simclr_timeseriesv4', 'r21d', 2), ('simclr_naked', 'r3d', 2),
                          ('moco_naked', 's3dg', 4), ('moco_timeseriesv4', 's3dg', 4)):
+        if only and only != f'{kind}:{net}':
+            continue
         V = 2 if kind.endswith('naked') else 3
         block = P.procedural_clips(B, V, **CLIP)
         # SimCLR_Naked in the reference only works on the distributed path (D2): world_size 1 gloo
@@ -301,15 +331,46 @@ def case_models(ref):
         noise = torch.from_numpy(np.random.RandomState(99).standard_normal(block.numel())).float().reshape(block.shape)
         pert = run_model(m, block * (1 + 1e-6 * noise), steps={'moco_naked': 3, 'moco_timeseriesv4': 1}.get(kind, 2), np_seed=1234)
         for k in list(recs[0].keys()):
-            if k in pert and ('/out/' in k or k.startswith('loss_step') or k.startswith('param/') or '/grad/' in k) and 'labels' not in k:
+            if k in pert and ('/out/' in k or k.startswith('loss_step') or k.startswith('param/') or '/grad/' in k
+                              or '/gsample/' in k) and 'labels' not in k:
                 a, b = np.asarray(recs[0][k], dtype=np.float64), np.asarray(pert[k], dtype=np.float64)
                 recs[0]['sens/' + k] = np.array(float(np.max(np.abs(a - b))))
+        for k, v in gsample_noise_floor(ref, kind, net, distributed, block).items():
+            recs[0]['f64/first/gsample/' + k] = np.array(v)
         # the oracle's non-distributed path must equal the distributed one at world_size 1
         torch.manual_seed(0)
         m = build(O, kind, net, False)
         P.procedural_init(m)
         err2 = compare(recs[0], run_model(m, block, steps={'moco_naked': 3, 'moco_timeseriesv4': 1}.get(kind, 2), np_seed=1234),
                        (kind, net, 'nondist'))
+        if net == 's3dg':
+            # WELL-CONDITIONED multi-step run: at this initialisation the gradients of the BatchNorm-ed convs are so large
+            # that the paper's lr = 0.003 is a leap into another basin -- after ONE such step a 1e-6 input perturbation
+            # moves the reference's own logits by 1.3, so `last/*` above cannot pin the backward + optimizer.  With
+            # lr = 3e-7 three SGD steps (momentum engaged) still move the loss by ~0.3 while the reference's own
+            # sensitivity stays ~1e-4 on the loss and ~3e-3 on the logits: `wc/*` pins them to a fraction of a per cent.
+            wc = []
+            for ns in (ref, O):
+                torch.manual_seed(0)
+                m = build(ns, kind, net, distributed)
+                P.procedural_init(m)
+                wc.append(run_model(m, block, steps=3, np_seed=1234, lr=WC_LR))
+            keep = lambda r: {k: v for k, v in r.items() if k.startswith(('loss_step', 'last/out/', 'param/', 'queue_ptr'))}   # noqa: E731
+            wc = [keep(r) for r in wc]
+            errw = compare(wc[0], wc[1], (kind, net, 'wc'), tol=5e-3 if kind == 'moco_timeseriesv4' else 5e-4)
+            torch.manual_seed(0)
+            m = build(ref, kind, net, distributed)
+            P.procedural_init(m)
+            pertw = run_model(m, block * (1 + 1e-6 * noise), steps=3, np_seed=1234, lr=WC_LR)
+            pertw = keep(pertw)
+            for k, v in wc[0].items():
+                recs[0]['wc/' + k] = v
+                if k in pertw and ('/out/' in k or k.startswith('loss_step') or k.startswith('param/')) and 'labels' not in k:
+                    a, b = np.asarray(v, dtype=np.float64), np.asarray(pertw[k], dtype=np.float64)
+                    recs[0]['wc/sens/' + k] = np.array(float(np.max(np.abs(a - b))))
+            print('   well-conditioned run (lr %g): ref-vs-oracle %.2e, loss %s, sens(last loss) %.2e, sens(last clip logits) %.2e' % (
+                WC_LR, errw, [round(float(wc[0]['loss_step%d' % i]), 5) for i in range(3)],
+                float(recs[0]['wc/sens/loss_step2']), float(recs[0]['wc/sens/last/out/clip_logits'])))
         np.savez_compressed(os.path.join(GOLD, f'model_{kind}_{net}.npz'), **recs[0])
         print('model', kind, net, 'B', B, 'ref-vs-oracle', err, 'nondist', err2,
               'loss', float(recs[0]['first/total_loss']), float(recs[0][sorted(k for k in recs[0] if k.startswith('loss_step'))[-1]]))
@@ -475,13 +536,115 @@ def case_augment(ref):
     print('augment hue: mismatching pixels', int(bad.sum()), 'of', bad.size, '; boundary cases', int(((diff > 0) & near).sum()))
     assert bad.sum() == 0
     rec['C/table'], rec['C/want_u8'] = t.view(np.uint8).reshape(-1, 64), want_u8
+    # (D) the SimCLR Gaussian blur (utils/augmentation.py:706-721): the reference hands each finished frame to PIL --
+    # transforms.ToPILImage() (= mul(255).byte() of the float frame), ImageFilter.GaussianBlur(radius=sigma), ToTensor() -- with
+    # one sigma per clip.  torchvision is absent here, PIL is not: the fixture holds PIL's own uint8 result of those three
+    # steps on frames that went through crop / flip / colour ops first; clips with sigma 0 are not blurred (RandomApply).
+    from PIL import Image, ImageFilter
+    import PIL
+    T_ = 3
+    dclips = [([0, 1, 2], (2, 5, 16, 16), 0, [], 1.0),
+              ([3, 4, 5], (4, 10, 16, 16), 1, [(B, [0.6, 1.0, 1.4])], 0.1),
+              ([6, 7, 8], (0, 0, 20, 26), 0, [(C_, [0.5, 1.3, 1.8]), (S, [1.5, 0.6, 1.8])], 2.0),
+              ([9, 10, 11], (3, 3, 16, 16), 1, [(S, [0.0, 0.6, 1.8])], 0.0),
+              ([1, 5, 9], (2, 1, 13, 22), 0, [(B, [1.5, 0.7, 1.1]), (G, [0, 1, 1])], 0.7371),
+              ([2, 6, 10], (5, 7, 11, 9), 1, [], 1.618)]
+    rows, sig = [], []
+    for src, win, flip, ops_, sigma in dclips:
+        t = np.zeros(len(src), dtype=A.ROW)
+        t['src'], t['flip'] = src, flip
+        t['crop_i'], t['crop_j'], t['crop_h'], t['crop_w'] = win
+        for n in range(len(src)):
+            k = 0
+            for code, fac in ops_:
+                if code == G and not fac[n]:
+                    continue
+                t['op'][n, k], t['factor'][n, k] = code, fac[n]
+                k += 1
+        rows.append(t)
+        sig += [sigma] * len(src)
+    dtab = np.concatenate(rows)
+    unblurred = A.augment_ingest(frames, dtab, len(dclips), T_, H, W)                          # [N, 3, T, H, W] floats in [0, 1]
+    want_u8 = np.zeros((len(dtab), H, W, 3), dtype=np.uint8)
+    blur = np.zeros(len(dtab), dtype=A.BLUR)
+    for n in range(len(dtab)):
+        x = unblurred[n // T_, :, n % T_]                                                       # [3, H, W]
+        u8 = x.mul(255).byte().permute(1, 2, 0).numpy()                                         # ToPILImage
+        if sig[n] > 0:
+            u8 = np.asarray(Image.fromarray(u8).filter(ImageFilter.GaussianBlur(radius=sig[n])))
+            blur['radius'][n], blur['ww'][n], blur['fw'][n] = A.box_blur_params(sig[n])
+        want_u8[n] = u8
+    got = A.augment_ingest(frames, dtab, len(dclips), T_, H, W, blur=blur)                      # the oracle's restatement
+    got_u8 = (got * 255).round().to(torch.uint8).permute(0, 2, 3, 4, 1).reshape(-1, H, W, 3).numpy()
+    is_blurred = np.float32(sig) > 0
+    nbad = int((got_u8 != want_u8)[is_blurred].sum())
+    # what the pipeline hands on: blurred frames = PIL's bytes / 255 (ToTensor), the others the float frames as they were
+    want_f = unblurred.permute(0, 2, 1, 3, 4).reshape(-1, 3, H, W).clone()
+    want_f[torch.from_numpy(is_blurred)] = torch.from_numpy(want_u8[is_blurred]).permute(0, 3, 1, 2).float() / 255
+    assert float((got.permute(0, 2, 1, 3, 4).reshape(-1, 3, H, W) - want_f).abs().max()) == 0.0
+    print('augment blur: oracle restatement vs PIL %s: %d mismatching bytes of %d' % (PIL.__version__, nbad, want_u8.size))
+    assert nbad == 0
+    rec['D/table'], rec['D/sigma'], rec['D/T'] = dtab.view(np.uint8).reshape(-1, 64), np.float32(sig), np.int32(T_)
+    rec['D/blur'], rec['D/want_u8'], rec['D/want'] = blur.view(np.uint8).reshape(-1, 16), want_u8, want_f.numpy()
     np.savez_compressed(os.path.join(GOLD, 'augment.npz'), **rec)
+
+
+def case_shapes(ref):
+    """The two BASELINE.json clip shapes the other fixtures do not touch: 16-frame clips (configs[1], and the paper's own
+    `--seq_len 16`, paper_scripts/paper_table1_k400/pretrain/*.sh) through S3D-G SimCLR_Naked (one full step: outputs,
+    gradients), and 32 x 224 x 224 clips (configs[4]) through the 2D3D-ResNet-50 (B = 1: pooled features and a strided
+    sample of the feature map)."""
+    _init_pg()
+    rec = {}
+    # --- 16 x 112 x 112
+    B = 2
+    block = P.procedural_clips(B, 2, T=16, H=112, W=112)
+    recs = []
+    for ns in (ref, O):
+        torch.manual_seed(0)
+        m = build(ns, 'simclr_naked', 's3dg', True)
+        P.procedural_init(m)
+        recs.append(run_model(m, block, steps=1, np_seed=1234))
+    err = compare(recs[0], recs[1], ('t16',))
+    torch.manual_seed(0)
+    m = build(ref, 'simclr_naked', 's3dg', True)
+    P.procedural_init(m)
+    noise = torch.from_numpy(np.random.RandomState(99).standard_normal(block.numel())).float().reshape(block.shape)
+    pert = run_model(m, block * (1 + 1e-6 * noise), steps=1, np_seed=1234)
+    for k, v in gsample_noise_floor(ref, 'simclr_naked', 's3dg', True, block).items():
+        rec['t16/f64/first/gsample/' + k] = np.array(v)
+    for k, v in recs[0].items():
+        rec['t16/' + k] = v
+        if k in pert and 'labels' not in k:
+            a, b = np.asarray(v, dtype=np.float64), np.asarray(pert[k], dtype=np.float64)
+            rec['t16/sens/' + k] = np.array(float(np.max(np.abs(a - b))))
+    print('shapes: s3dg simclr_naked 16x112x112 B', B, 'ref-vs-oracle', err, 'loss', float(recs[0]['first/total_loss']))
+    # --- 32 x 224 x 224 through r50
+    x = P.procedural_clips(1, 1, T=32, H=224, W=224)[:, 0]
+    outs = []
+    for sel in (ref.select_backbone, O.select_backbone):
+        m, _ = sel('r50')
+        P.procedural_init(m).train()
+        with torch.no_grad():
+            outs.append(m(x))
+    err = float((outs[0] - outs[1]).abs().max())
+    assert err < 1e-5, err
+    with torch.no_grad():
+        m2, _ = ref.select_backbone('r50')
+        P.procedural_init(m2).train()
+        y64 = m2.double()(x.double())
+    rec['r50_224/shape'] = np.array(outs[0].shape)
+    rec['r50_224/pooled'] = outs[0].mean(dim=(2, 3, 4)).numpy()
+    rec['r50_224/feat_sample'] = outs[0].reshape(-1)[::997].numpy().copy()
+    rec['r50_224/fp32_vs_fp64'] = np.array(float((outs[0].double() - y64).abs().max() / y64.abs().max()))
+    print('shapes: r50 32x224x224', tuple(outs[0].shape), 'ref-vs-oracle', err, 'fp32-vs-fp64', float(rec['r50_224/fp32_vs_fp64']))
+    np.savez_compressed(os.path.join(GOLD, 'shapes.npz'), **rec)
 
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['backbones', 'models', 'losses', 'eval', 'clf', 'extra', 'augment']
+    which = sys.argv[1:] or ['backbones', 'models', 'losses', 'eval', 'clf', 'extra', 'augment', 'shapes']
     if 'losses' in which:
         case_losses()
     ref = harness.load_reference()
@@ -495,6 +658,8 @@ def main():
         case_backbones_extra(ref)
     if 'augment' in which:
         case_augment(ref)
+    if 'shapes' in which:
+        case_shapes(ref)
     if 'models' in which:
         case_models(ref)
 

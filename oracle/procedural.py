@@ -110,3 +110,50 @@ def procedural_unit_features(*shape, seed=7):
     n = int(np.prod(shape))
     x = torch.from_numpy(_wave(n, seed, freq=0.13)).float().reshape(*shape)
     return torch.nn.functional.normalize(x, dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# element-wise gradient pins (a permutation-invariant checksum would pass a transposed tap / channel)
+GSAMPLE_FAMILIES = ('gating', 'fc', 'Conv_1a', 'conv1.', 'Conv_2b', 'Conv_2c', 'branch0.0', 'branch1.1.conv1', 'branch1.1.conv2',
+                    'branch2.1.conv1', 'branch3.1', 'downsample', 'encoder_q.2', 'encoder_q.4', 'series_proj_head')
+
+
+def grad_sample_keys(module, n_even=14):
+    """Canonical keys of the tensors whose gradients are stored element-wise: the first tensor of every op family of
+    GSAMPLE_FAMILIES (stem convs, merged branch-entry 1x1x1, separable pairs, the conv after the 3x3x3 pool, self-gating
+    fc, heads, ...) with its BatchNorm neighbours, plus `n_even` tensors spread evenly over the rest."""
+    sd = module.state_dict(keep_vars=True)
+    keys = [k for k in sorted(canonical_groups(module)) if getattr(sd[k], 'requires_grad', False)]
+    pick = []
+    for fam in GSAMPLE_FAMILIES:
+        hit = [k for k in keys if fam in k]
+        pick += hit[:2]
+    step = max(1, len(keys) // n_even)
+    pick += keys[::step]
+    seen, out = set(), []
+    for k in pick:
+        if k not in seen:
+            seen.add(k)
+            out.append(k)
+    return out
+
+
+def grad_sample_index(numel):
+    """the sampled flat indices of a tensor with `numel` elements: every 97th, thinned to <= ~1000 samples"""
+    stride = 97
+    while numel // stride > 1000:
+        stride += 194                    # stays odd: no aliasing with the (even) channel / tap pitches
+    return np.arange(0, numel, stride)
+
+
+def grad_samples(module):
+    """{canonical key: float64 samples of .grad (flattened in the parameter's own [O, I, kt, kh, kw] order)}"""
+    sd = module.state_dict(keep_vars=True)
+    out = {}
+    for k in grad_sample_keys(module):
+        g = sd[k].grad
+        if g is None:
+            continue
+        flat = g.detach().double().cpu().reshape(-1).numpy()
+        out[k] = flat[grad_sample_index(flat.size)].copy()
+    return out

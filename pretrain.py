@@ -149,12 +149,14 @@ class SyntheticFrames(torch.utils.data.Dataset):
 def gpu_transform(args):
     """the base transform of pretrain.py:500-509 in its tensor-side form (utils/transforms.py): random crop, optional
     flip, colour jitter 0.8 / 0.8 / 0.8 / hue 0.2 with p = 0.8 (temporally consistent under --aug_temp_consist; hue by
-    utils/augmentation.py:adjust_hue_np's arithmetic); the PIL Gaussian blur is not applied"""
+    utils/augmentation.py:adjust_hue_np's arithmetic); then, with p = 0.5, the SimCLR Gaussian blur (sigma in [0.1, 2], one
+    per clip) exactly as PIL computes it (utils/augmentation.py:706-721)"""
     from dualvar_amd.utils import transforms as T
     steps = [T.RandomCrop((args.img_dim, args.img_dim))]
     if args.rand_flip:
         steps.append(T.RandomHorizontalFlip())
     steps.append(T.ColorJitter(0.8, 0.8, 0.8, consistent=args.aug_temp_consist, p=0.8 * 0.8, hue=0.2))
+    steps.append(T.RandomApply([T.GaussianBlur([.1, 2.], seq_len=args.seq_len)], p=0.5))
     return T.Compose(steps)
 
 

@@ -129,6 +129,25 @@ def test_train_steps_fp32_against_reference_fixture(gpu, kind, net, B, steps):
                     worst = max(worst, e / bound)
                 report.append(('first', 'grad |g| checksum worst err/bound', worst))
                 assert worst < 1.0, worst
+                # element-wise: strided samples of ~30 gradient tensors, one or two per op family (stem convs, merged
+                # branch-entry 1x1x1, separable pairs, the conv behind the 3x3x3 pool, self-gating fc, BatchNorm, heads).
+                # A transposed tap or channel inside a weight gradient passes the |g| checksum above, not this.
+                # Bound per tensor: 1e-4 of its largest sampled element, 5x the recorded input sensitivity, or 20x what fp32
+                # rounding alone does to the REFERENCE's own gradient (`f64/...` = max |g_fp32 - g_fp64| of the reference:
+                # BatchNorm beta / gamma gradients are sums over 1e5 rows that nearly cancel).  A transposed tap or channel
+                # is wrong by O(1) of the largest element.
+                worst, wkey, nsamp = 0.0, None, 0
+                for k, v in P.grad_samples(m).items():
+                    ref = g[f'first/gsample/{k}']
+                    assert v.shape == ref.shape, (k, v.shape, ref.shape)
+                    sens = float(g[f'sens/first/gsample/{k}'])
+                    bound = max(1e-4 * float(np.abs(ref).max()) + 1e-9, 5 * sens, 20 * float(g[f'f64/first/gsample/{k}']))
+                    e = float(np.abs(v - ref).max()) / bound
+                    if e > worst:
+                        worst, wkey = e, k
+                    nsamp += 1
+                report.append(('first', 'element-wise gradient samples of %d tensors, worst err/bound' % nsamp, worst, wkey))
+                assert nsamp >= 12 and worst < 1.0, (nsamp, worst, wkey)
         opt.step()
         lsens = max([float(g[k]) for k in g.files if k.startswith('sens/last/out/') and 'logits' in k] + [0.0]) if it > 0 else 0.0
         assert abs(float(loss) - float(g[f'loss_step{it}'])) < max(1e-3, 5 * float(g[f'sens/loss_step{it}']), 0.1 * lsens)
@@ -140,6 +159,62 @@ def test_train_steps_fp32_against_reference_fixture(gpu, kind, net, B, steps):
     assert worst < 1.0, worst
     if 'queue_ptr' in g.files:
         assert int(m.queue_ptr) == int(g['queue_ptr'])
+
+
+WC_CASES = [('simclr_naked', 4), ('simclr_timeseriesv4', 4), ('moco_naked', 4), ('moco_timeseriesv4', 4)]
+
+
+@pytest.mark.parametrize('kind,B', WC_CASES, ids=[c[0] for c in WC_CASES])
+def test_s3dg_well_conditioned_steps_fp32(gpu, kind, B):
+    """S3D-G backward + optimizer, pinned where the case is well conditioned.  At the fixtures' initialisation lr = 0.003
+    (pretrain.py's default) throws the net into another basin: after ONE step the REFERENCE's own logits move by 1.3 under a
+    1e-6 input perturbation, so the `last/*` entries used above only bound the HIP path to within 6.6.  The `wc/*` entries
+    are the same three SGD steps (momentum engaged) at lr = 3e-7: the loss still moves by several tenths per step while
+    the reference's own sensitivity stays ~5e-4 (loss) / ~1e-2 (logits) -- a gradient or optimizer error of one per cent
+    shows.  Bounds: loss 1e-3 or 5x the recorded sensitivity, logits 2e-3 or 5x, parameter checksums 1e-4 relative or 10x."""
+    from dualvar_amd.optim import SGD
+    P = _P()
+    net = 's3dg'
+    g = gold(f'model_{kind}_{net}')
+    torch.manual_seed(0)
+    m = _build(kind, net)
+    P.procedural_init(m)
+    m.set_compute_dtype('fp32').train().to(gpu)
+    V = 2 if kind.endswith('naked') else 3
+    block = P.procedural_clips(B, V, **CLIP).to(gpu)
+    opt = SGD([p for p in m.parameters() if p.requires_grad], lr=3e-7, momentum=0.9, weight_decay=1e-4, stores=m.stores())
+    np.random.seed(1234)
+    report = []
+    for it in range(3):
+        ret = m(block)
+        loss = total_loss(ret)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ref, sens = float(g[f'wc/loss_step{it}']), float(g[f'wc/sens/loss_step{it}'])
+        err = abs(float(loss) - ref)
+        report.append(('loss_step%d' % it, ref, err, sens))
+        assert err < max(1e-3, 5 * sens), (it, float(loss), ref, sens)
+    moved = abs(float(g['wc/loss_step2']) - float(g['wc/loss_step0']))
+    assert moved > 0.1, 'the fixture must move: %g' % moved       # (else the steps pin nothing)
+    for k in g.files:
+        if k.startswith('wc/last/out/') and 'logits' in k:
+            name = k.split('/', 3)[3]
+            sens = float(g['wc/sens/' + k[3:]])
+            err = float(np.max(np.abs(ret[name].detach().float().cpu().numpy() - g[k])))
+            report.append((name, err, sens))
+            assert err < max(2e-3, 5 * sens), (name, err, sens)
+    pc = param_checksum(m, P)
+    worst = 0.0
+    for k, v in pc.items():
+        if f'wc/param/{k}' in g.files:
+            ref = g[f'wc/param/{k}']
+            worst = max(worst, abs(v[0] - ref[0]) / max(1e-4 * abs(ref[0]) + 1e-9, 10 * float(g[f'wc/sens/param/{k}'])))
+    report.append(('param checksum worst err/bound', worst))
+    print(kind, report)
+    assert worst < 1.0, worst
+    if 'wc/queue_ptr' in g.files:
+        assert int(m.queue_ptr) == int(np.asarray(g['wc/queue_ptr']).reshape(-1)[0])
 
 
 @pytest.mark.parametrize('kind,net,B', [('simclr_naked', 's3dg', 4), ('simclr_timeseriesv4', 's3dg', 4)])
@@ -300,7 +375,7 @@ def test_frame_batch_through_backbone_and_model(gpu):
     from dualvar_amd.ops import DV_F32
     act = ops.new_act(8, 8, 64, 64, 3, DV_F32, gpu, cpitch=4, zero=True)
     ops.call('dv_augment_ingest', DV_F32, fb.frames, 16, 72, 96, fb.table, 8, 8, 64, 64, act, 4, 0, torch.tensor(mean).to(gpu),
-             (1 / torch.tensor(std)).to(gpu), None, 0, torch.empty(64, device=gpu))
+             (1 / torch.tensor(std)).to(gpu), None, 0, torch.empty(64, device=gpu), None, None)
     block = ops.act_to_ncdhw(act).view(4, 2, 3, 8, 64, 64).contiguous()
     losses = []
     for inp, norm in ((fb, (mean, std)), (block, (None, None))):
@@ -382,10 +457,11 @@ def test_classifier_finetune_steps_against_reference_fixture(gpu, mode, kw):
     assert np.max(np.abs(ev - g[f'{mode}/eval_logit'])) < bound('eval_logit', 1e-3)
 
 
-@pytest.mark.parametrize('net', ['r2d3d18', 'c3d'])
+@pytest.mark.parametrize('net', ['r2d3d18', 'c3d', 's3d'])
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_remaining_factory_backbones(gpu, net, dtype):
-    """select_backbone('r2d3d18' / 'c3d') (select_backbone.py:9-27): train-mode features and eval-mode
+    """select_backbone('r2d3d18' / 'c3d' / 's3d' = S3D without self-gating, s3dg.py:135) (select_backbone.py:9-27; SURVEY 8f
+    rank 4): train-mode features and eval-mode
     features after that forward, against the reference's own classes (tests/golden/backbones_extra.npz).  c3d's convs
     carry a bias in front of their BatchNorm: the eval output checks that it reached the running mean."""
     from dualvar_amd.backbone import select_backbone
@@ -404,4 +480,67 @@ def test_remaining_factory_backbones(gpu, net, dtype):
     e2 = rel_err(ev.cpu().numpy(), g[net + '/eval_pooled'])
     print(f'{net} {dtype}: train map rel err {e1:.2e}, eval pooled rel err {e2:.2e}')
     tol = max(3e-4, 4 * float(g[net + '/fp32_vs_fp64'])) if dtype == 'fp32' else 8e-2
+    if net == 's3d' and dtype == 'bf16':
+        # train-mode S3D at random initialisation amplifies bf16 storage rounding like S3D-G does (test_backbone_features
+        # prints what it does to the oracle itself: ~0.5 relative): sanity bound on the map, 0.1 on the eval-mode features
+        assert e1 < 1.5 and e2 < 0.1
+        return
     assert e1 < tol and e2 < tol
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the BASELINE.json clip shapes the 8 x 112 x 112 fixtures do not touch
+def test_s3dg_simclr_16_frame_step_fp32_against_reference_fixture(gpu):
+    """BASELINE configs[1] / the paper's own --seq_len 16 (paper_scripts/paper_table1_k400/pretrain/*.sh): S3D-G SimCLR_Naked on
+    16 x 112 x 112 clips, one full step in fp32 against tests/golden/shapes.npz (the reference's outputs): logits, loss,
+    gradient checksums and element-wise gradient samples."""
+    P = _P()
+    g = gold('shapes')
+    torch.manual_seed(0)
+    m = _build('simclr_naked', 's3dg')
+    P.procedural_init(m)
+    m.set_compute_dtype('fp32').train().to(gpu)
+    block = P.procedural_clips(2, 2, T=16, H=112, W=112).to(gpu)
+    ret = m(block)
+    loss = total_loss(ret)
+    loss.backward()
+    lg = ret['clip_logits'].detach().float().cpu().numpy()
+    e_l = float(np.abs(lg - g['t16/first/out/clip_logits']).max())
+    e_s = abs(float(loss) - float(g['t16/first/total_loss']))
+    print(f'16-frame step: logits err {e_l:.2e} (sens {float(g["t16/sens/first/out/clip_logits"]):.1e}), loss err {e_s:.2e}')
+    assert e_l < max(2e-3, 5 * float(g['t16/sens/first/out/clip_logits']))
+    assert e_s < max(1e-3, 5 * float(g['t16/sens/first/total_loss']))
+    worst = 0.0
+    for k, v in grad_summary(m, P).items():
+        ref, sens = g[f't16/first/grad/{k}'], float(g[f't16/sens/first/grad/{k}'])
+        worst = max(worst, abs(v[0] - ref[0]) / max(2e-2 * abs(ref[0]) + 1e-7, 5 * sens))
+    assert worst < 1.0, worst
+    worst = 0.0
+    for k, v in P.grad_samples(m).items():
+        ref, sens = g[f't16/first/gsample/{k}'], float(g[f't16/sens/first/gsample/{k}'])
+        worst = max(worst, float(np.abs(v - ref).max()) / max(1e-4 * float(np.abs(ref).max()) + 1e-9, 5 * sens,
+                                                                20 * float(g[f't16/f64/first/gsample/{k}'])))
+    assert worst < 1.0, worst
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_r50_32x224_features_against_reference_fixture(gpu, dtype):
+    """BASELINE configs[4]: the 2D3D-ResNet-50 (backbone/resnet_2d3d.py:272-341) on a 32 x 224 x 224 clip, B = 1: pooled
+    features and a strided sample of the [1, 2048, 16, 7, 7] map against the reference (tests/golden/shapes.npz)."""
+    from dualvar_amd.backbone import select_backbone
+    P = _P()
+    g = gold('shapes')
+    m, prm = select_backbone('r50')
+    P.procedural_init(m)
+    m.set_compute_dtype(dtype).train().to(gpu)
+    x = P.procedural_clips(1, 1, T=32, H=224, W=224)[:, 0].to(gpu)
+    with torch.no_grad():
+        fmap = m(x)
+    assert tuple(fmap.shape) == tuple(g['r50_224/shape'])
+    e1 = rel_err(fmap.mean(dim=(2, 3, 4)).cpu().numpy(), g['r50_224/pooled'])
+    e2 = rel_err(fmap.reshape(-1)[::997].cpu().numpy(), g['r50_224/feat_sample'])
+    cond = float(g['r50_224/fp32_vs_fp64'])
+    print(f'r50 32x224x224 {dtype}: pooled rel err {e1:.2e}, map sample rel err {e2:.2e} (reference fp32-vs-fp64 {cond:.1e})')
+    tol = max(3e-4, 4 * cond) if dtype == 'fp32' else 8e-2
+    # (bf16, B = 1: single elements of the map are far noisier than their spatial mean -- 7.5x the pooled bound)
+    assert e1 < tol and e2 < (2.5 if dtype == 'fp32' else 7.5) * tol

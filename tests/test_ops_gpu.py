@@ -211,16 +211,20 @@ def test_ingest(gpu, dtype):
     close(ops.act_to_ncdhw(a2), q(ref2, dtype), dtype, 'ingest perm', factor=0.5 if dtype == DV_BF16 else 1)
 
 
-def _augment(gpu, dtype, frames, table, N, T, H, W, mean, std, perm=None, pad=0):
-    from dualvar_amd.utils.transforms import AUG_ROW
+def _augment(gpu, dtype, frames, table, N, T, H, W, mean, std, perm=None, pad=0, blur=None):
+    from dualvar_amd.utils.transforms import AUG_BLUR, AUG_ROW
     assert table.dtype == AUG_ROW
+    if blur is not None:
+        assert blur.dtype == AUG_BLUR and len(blur) == len(table)
+        bl = torch.from_numpy(blur.view(np.uint8).copy()).to(gpu)
+        btmp = torch.empty(N * T * H * W * 3, dtype=torch.uint8, device=gpu)
     a = ops.new_act(N, T, H + 2 * pad, W + 2 * pad, 3, dtype, gpu, cpitch=4, zero=True)
     fr = torch.from_numpy(np.ascontiguousarray(frames)).to(gpu)
     tb = torch.from_numpy(table.view(np.uint8).copy()).to(gpu)
     scratch = torch.full((N * T,), float('nan'), device=gpu)
     ops.call('dv_augment_ingest', dtype, fr, fr.shape[0], fr.shape[1], fr.shape[2], tb, N, T, H, W, a, 4, pad,
              torch.tensor(mean).to(gpu), (1 / torch.tensor(std)).to(gpu), None if perm is None else perm.to(gpu),
-             0 if perm is None else perm.shape[1], scratch)
+             0 if perm is None else perm.shape[1], scratch, None if blur is None else bl, None if blur is None else btmp)
     y = ops.act_to_ncdhw(a)                                                        # [N, 3, T, H + 2 pad, W + 2 pad]
     if pad:
         inner = y[:, :, :, pad:-pad, pad:-pad]
@@ -247,6 +251,49 @@ def test_augment_ingest_against_reference_fixture(gpu, dtype, pad):
     assert err < (2e-5 if dtype == DV_F32 else 2e-2)
 
 
+@pytest.mark.parametrize('dtype,pad', [(DV_F32, 0), (DV_BF16, 3)])
+def test_augment_gaussian_blur_against_pil_fixture(gpu, dtype, pad):
+    """The SimCLR Gaussian blur of the ingest (utils/augmentation.py:706-721 -> PIL ImageFilter.GaussianBlur on the uint8
+    frame): tests/golden/augment.npz part D holds PIL's own output (oracle/gen_golden.py ran Pillow 12.2.0 on the
+    colour-jittered, re-quantised frames).  The integer kernel reproduces it BIT FOR BIT; frames without a blur row pass
+    through the ordinary path."""
+    from tests.util import gold
+    from dualvar_amd.utils.transforms import AUG_BLUR, AUG_ROW, box_blur_params
+    g = gold('augment')
+    H, W = (int(v) for v in g['HW'])
+    table = np.ascontiguousarray(g['D/table']).view(AUG_ROW).reshape(-1)
+    blur = np.zeros(len(table), dtype=AUG_BLUR)
+    for n, sg in enumerate(g['D/sigma']):
+        if sg > 0:
+            blur['radius'][n], blur['ww'][n], blur['fw'][n] = box_blur_params(float(sg))
+    assert np.array_equal(blur.view(np.uint8).reshape(-1, 16), g['D/blur'])             # host parameters == the oracle's
+    T_ = int(g['D/T'])
+    N = len(table) // T_
+    got = _augment(gpu, dtype, g['frames'], table, N, T_, H, W, g['mean'].tolist(), g['std'].tolist(), pad=pad, blur=blur).cpu()
+    want_u8 = g['D/want_u8']                                                            # [N*T, H, W, 3] PIL's uint8 frames
+    mean, std = torch.tensor(g['mean']).view(1, 3, 1, 1, 1), torch.tensor(g['std']).view(1, 3, 1, 1, 1)
+    on = torch.from_numpy(g['D/sigma'] > 0).view(N, 1, T_, 1, 1)
+    assert bool(on.any()) and not bool(on.all())
+    if dtype == DV_F32:
+        back = torch.round((got * std + mean) * 255.0).to(torch.int64)                  # undo Normalize and ToTensor
+        want = torch.from_numpy(want_u8).view(N, T_, H, W, 3).permute(0, 4, 1, 2, 3).to(torch.int64)
+        d = (back - want).abs() * on
+        print('blurred frames vs PIL: max |difference| in uint8 steps', int(d.max()), '; pixels off by one step:', int((d > 0).sum()),
+              'of', int(on.sum()) * 3 * H * W)
+        # clip 0 is a plain crop: its quantised frame is the source bytes, so the integer blur must match PIL bit for bit.
+        # Behind colour ops / a bilinear resize the float frame can sit within one ulp of a byte boundary, where the GPU's
+        # and the CPU's mul(255).byte() truncate differently: such an input byte moves the blurred output by at most one step.
+        assert float(g['D/sigma'][0]) > 0 and int(d[0].max()) == 0
+        assert int(d.max()) <= 1 and int((d > 0).sum()) <= 0.01 * int(on.sum()) * 3 * H * W
+    want_f = (torch.from_numpy(g['D/want']).view(N, T_, 3, H, W).permute(0, 2, 1, 3, 4) - mean) / std
+    e = (got - want_f).abs()
+    step = float((1 / 255.0 / std).max())                                             # one uint8 step after Normalize
+    tol = 2e-5 if dtype == DV_F32 else 2e-2
+    # every element within tolerance, except the few truncation-boundary pixels of blurred frames (one step off, see above)
+    off = (e > tol)
+    assert float(e.max()) <= step + tol and int(off.sum()) <= 0.01 * e.numel() and not bool((off & ~on.expand_as(off)).any())
+
+
 def test_augment_hue_against_reference_fixture(gpu):
     """DV_AUG_HUE on the GPU == the reference's adjust_hue_np (uint8 result in tests/golden/augment.npz, part C)"""
     from tests.util import gold
@@ -259,7 +306,7 @@ def test_augment_hue_against_reference_fixture(gpu):
     fr = torch.from_numpy(np.ascontiguousarray(g['frames'])).to(gpu)
     tb = torch.from_numpy(t.view(np.uint8).copy()).to(gpu)
     ops.call('dv_augment_ingest', DV_F32, fr, fr.shape[0], fr.shape[1], fr.shape[2], tb, len(t), 1, H, W, a, 4, 0, None, None, None, 0,
-             torch.empty(len(t), device=gpu))
+             torch.empty(len(t), device=gpu), None, None)
     got = ops.act_to_ncdhw(a)[:, :, 0].permute(0, 2, 3, 1).cpu().numpy()
     bad, boundary = _hue_matches(got.astype(np.float64) * 255.0, g['C/want_u8'])
     print(f'hue vs adjust_hue_np: {bad} mismatching pixels, {boundary} truncation-boundary cases of {got.size}')

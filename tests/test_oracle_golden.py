@@ -93,6 +93,47 @@ def test_model_first_step_fixture(kind, net, B):
     for k, v in grad_summary(m, P).items():
         ref, sens = g[f'first/grad/{k}'], float(g[f'sens/first/grad/{k}'])
         assert abs(v[0] - ref[0]) <= max(1e-3 * abs(ref[0]) + 1e-7, 5 * sens), k
+    samples = P.grad_samples(m)                          # element-wise pins (oracle/procedural.py)
+    assert len(samples) >= 12
+    for k, v in samples.items():
+        ref, sens = g[f'first/gsample/{k}'], float(g[f'sens/first/gsample/{k}'])
+        assert np.max(np.abs(v - ref)) <= max(1e-5 * np.max(np.abs(ref)) + 1e-12, 5 * sens), k
+
+
+def test_well_conditioned_steps_fixture():
+    """`wc/*` of the S3D-G fixtures: three SGD steps at lr = 3e-7 (oracle/gen_golden.py: WC_LR) -- the oracle reproduces
+    the reference's losses, and the fixture really moves (else it would pin nothing)"""
+    from oracle import procedural as P
+    g = gold('model_simclr_naked_s3dg')
+    torch.manual_seed(0)
+    m = _build('simclr_naked', 's3dg')
+    P.procedural_init(m).train()
+    block = P.procedural_clips(4, 2, **CLIP)
+    opt = torch.optim.SGD([{'params': [p]} for p in m.parameters() if p.requires_grad], lr=3e-7, weight_decay=1e-4, momentum=0.9)
+    losses = []
+    for it in range(3):
+        ret = m(block)
+        loss = total_loss(ret)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        assert abs(losses[-1] - float(g[f'wc/loss_step{it}'])) <= max(1e-4, 5 * float(g[f'wc/sens/loss_step{it}'])), (it, losses)
+    assert abs(losses[2] - losses[0]) > 0.1
+    assert float(g['wc/sens/loss_step2']) < 2e-3 and float(g['sens/loss_step1']) > 10 * float(g['wc/sens/loss_step1'])
+
+
+def test_shapes_fixture_16_frames():
+    """tests/golden/shapes.npz: S3D-G SimCLR_Naked on 16 x 112 x 112 clips (BASELINE configs[1])"""
+    from oracle import procedural as P
+    g = gold('shapes')
+    torch.manual_seed(0)
+    m = _build('simclr_naked', 's3dg')
+    P.procedural_init(m).train()
+    ret = m(P.procedural_clips(2, 2, T=16, H=112, W=112))
+    assert np.max(np.abs(ret['clip_logits'].detach().numpy() - g['t16/first/out/clip_logits'])) <= \
+        max(1e-4, 5 * float(g['t16/sens/first/out/clip_logits']))
+    assert abs(float(total_loss(ret)) - float(g['t16/first/total_loss'])) <= max(1e-4, 5 * float(g['t16/sens/first/total_loss']))
 
 
 def test_loss_fixture_world1():
@@ -216,3 +257,47 @@ def test_color_jitter_and_frame_batch_host_logic():
         T.Compose([T.ColorJitter(0.5, 0, 0), T.RandomCrop((8, 8))])(T.ClipState([0], 24, 32))
     with pytest.raises(ValueError):
         T.ClipState([0], 24, 32).rows(16, 16)
+
+
+def test_gaussian_blur_oracle_and_parameters_match_pil_fixture():
+    """tests/golden/augment.npz part D = PIL's own GaussianBlur of the re-quantised frames (generated with Pillow in the build
+    container).  The oracle's restatement of Pillow's BoxBlur.c and the product's host-side parameter arithmetic reproduce it
+    bit for bit; where PIL is importable the restatement is also checked against PIL live on random images."""
+    from oracle import augment_ref as A
+    from dualvar_amd.utils import transforms as T
+    g = gold('augment')
+    H, W = (int(v) for v in g['HW'])
+    tab = np.ascontiguousarray(g['D/table']).view(A.ROW).reshape(-1)
+    blur = np.ascontiguousarray(g['D/blur']).view(A.BLUR).reshape(-1)
+    T_ = int(g['D/T'])
+    got = A.augment_ingest(g['frames'], tab, len(tab) // T_, T_, H, W, blur=blur)
+    got_u8 = (got * 255).round().to(torch.uint8).permute(0, 2, 3, 4, 1).reshape(-1, H, W, 3).numpy()
+    on = g['D/sigma'] > 0
+    assert on.any() and not on.all()
+    assert np.array_equal(got_u8[on], g['D/want_u8'][on])                                   # PIL's bytes
+    assert np.array_equal(got.permute(0, 2, 1, 3, 4).reshape(-1, 3, H, W).numpy(), g['D/want'])   # blurred and untouched frames
+    for n, sg in enumerate(g['D/sigma']):
+        want = tuple(int(blur[n][k]) for k in ('radius', 'ww', 'fw'))
+        assert T.box_blur_params(float(sg)) == (want if sg > 0 else (0, 0, 0)) or sg == 0
+        assert A.box_blur_params(float(sg)) == T.box_blur_params(float(sg))
+    # the parameter class draws one sigma per clip with random.uniform, as utils/augmentation.py:713-716
+    import random
+    random.seed(7)
+    st = T.GaussianBlur([.1, 2.], seq_len=4)(T.ClipState([0, 1, 2, 3, 4, 5, 6, 7], 20, 26))
+    random.seed(7)
+    want = [random.uniform(.1, 2.) for _ in range(2)]
+    assert np.allclose(st.sigma, [want[0]] * 4 + [want[1]] * 4)
+    assert st.blur_rows()['ww'].all()
+    with pytest.raises(ValueError):
+        T.RandomHorizontalFlip(p=1.0)(st)                      # nothing may follow the blur
+    try:
+        from PIL import Image, ImageFilter
+    except ImportError:
+        return
+    rs = np.random.RandomState(0)
+    for trial in range(40):
+        h, w = rs.randint(8, 120), rs.randint(8, 120)
+        img = rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        sigma = [1.0, 0.1, 2.0, 0.5][trial % 4] if trial % 3 == 0 else float(rs.uniform(0.1, 2.0))
+        want = np.asarray(Image.fromarray(img).filter(ImageFilter.GaussianBlur(radius=sigma)))
+        assert np.array_equal(A.gaussian_blur_u8(img, *A.box_blur_params(sigma)), want), (trial, sigma)

@@ -19,12 +19,21 @@ from dualvar_amd.ops import DV_BF16  # noqa: E402
 
 N_CLIPS = 128
 
-# (name, T, H, W, Cin, Cout, k, s, p) at 128 clips: the largest S3D-G layers and one stride-2 case
+# (name, clips, T, H, W, Cin, Cout, k, s, p): the largest S3D-G layers at 128 clips of 8 x 112 x 112 and
+# one stride-2 case; the same stem / Conv_2c layers at 16-frame clips (BASELINE configs[1]: S3D-G bf16, batch 64 x 2 views,
+# 16 x 112 x 112); and three of the largest layers of the 2D3D-ResNet-50 on 32 x 224 x 224 clips (configs[4]) at batch 4 x 2
 BIG_LAYERS = [
-    ('Conv_2c.conv1 1x3x3', 4, 28, 28, 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
-    ('Conv_2c.conv2 3x1x1', 4, 28, 28, 192, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
-    ('Conv_1a.conv2 7x1x1 s2', 8, 56, 56, 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0)),
-    ('Mixed_3c entry 1x1x1', 4, 14, 14, 256, 288, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('Conv_2c.conv1 1x3x3', 128, 4, 28, 28, 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('Conv_2c.conv2 3x1x1', 128, 4, 28, 28, 192, 192, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ('Conv_1a.conv2 7x1x1 s2', 128, 8, 56, 56, 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0)),
+    ('Mixed_3c entry 1x1x1', 128, 4, 14, 14, 256, 288, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('T16 Conv_1a.conv2 7x1x1 s2', 128, 16, 56, 56, 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0)),
+    ('T16 Conv_2c.conv1 1x3x3', 128, 8, 28, 28, 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('T16 Mixed_4b branch1 3x1x1', 128, 4, 7, 7, 208, 208, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ('r50@224 layer1 conv2 1x3x3', 8, 16, 56, 56, 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('r50@224 layer1 conv3 1x1x1', 8, 16, 56, 56, 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ('r50@224 layer3 conv1 3x1x1', 8, 16, 14, 14, 1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ('r50@224 layer2 downsample 1x1x1 s(1,2,2)', 8, 16, 56, 56, 256, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
 ]
 
 
@@ -34,7 +43,7 @@ def _dot(a, b):
 
 @pytest.mark.parametrize('layer', BIG_LAYERS, ids=[c[0] for c in BIG_LAYERS])
 def test_conv_adjoint_identities_at_full_size(gpu, layer):
-    name, T, H, W, Ci, Co, k, s, p = layer
+    name, N_CLIPS, T, H, W, Ci, Co, k, s, p = layer
     g = torch.Generator(device='cpu').manual_seed(7)
     x = ops.new_act(N_CLIPS, T, H, W, Ci, DV_BF16, gpu)
     x.buf.copy_(torch.randn(x.buf.shape, generator=g).relu_().to(torch.bfloat16))
@@ -54,6 +63,9 @@ def test_conv_adjoint_identities_at_full_size(gpu, layer):
     torch.cuda.synchronize()
     a = _dot(y.buf, dy.buf)                    # <conv(x,w), dy>   (y is bf16-rounded: 2^-9 relative per element)
     b = _dot(x.buf, dx.buf)                    # <x, dgrad(dy,w)>
+    dw2 = torch.zeros(Co, taps * Ci, device=gpu)
+    ops.conv_wgrad(d, x, dy, dw2)
+    assert torch.equal(dw, dw2), 'the weight gradient must be reproducible bit for bit'
     c = _dot(w16.float().reshape(Co, -1), dw)  # <w, wgrad(x,dy)>  (fp32 accumulation, exact up to summation order)
     scale = float(y.buf.double().norm() * dy.buf.double().norm())
     print(f'{name}: <y,dy>={a:.6e} <x,dx>={b:.6e} <w,dw>={c:.6e} (|y||dy|={scale:.3e})')
@@ -159,3 +171,78 @@ def test_full_size_step_is_batch_symmetric_and_loss_matches_its_logits(gpu):
     assert abs(float(r1['clip_contrast_loss']) - float(r2['clip_contrast_loss'])) < 5e-2
     pos1, pos2 = lg[:64, 0], r2['clip_logits'].float().cpu()[:64, 0]
     assert float((pos1[perm.cpu()] - pos2).abs().max()) < 0.15 * float(pos1.abs().max())
+
+
+def test_full_size_16_frame_step_bf16(gpu):
+    """BASELINE configs[1]: S3D-G SimCLR_Naked bf16, batch 64 (x 2 views), 16 x 112 x 112 clips -- one full training step at
+    that size: the loss is the cross-entropy of the returned logits, every gradient is finite, and the batch symmetry of
+    the forward holds."""
+    from dualvar_amd import model as M
+    from dualvar_amd.optim import SGD
+    torch.manual_seed(0)
+    m = M.SimCLR_Naked('s3dg', 128, 0.07, False)
+    m.set_compute_dtype('bf16').train().to(gpu)
+    g = torch.Generator().manual_seed(5)
+    block = torch.randn(64, 2, 3, 16, 112, 112, generator=g).to(gpu)
+    opt = SGD([p for p in m.parameters() if p.requires_grad], lr=0.003, momentum=0.9, weight_decay=1e-4, stores=m.stores())
+    ret = m(block)
+    lg = ret['clip_logits'].detach().float().cpu()
+    assert lg.shape == (128, 127) and bool(torch.isfinite(lg).all())
+    ce = float(torch.nn.functional.cross_entropy(lg, torch.zeros(128, dtype=torch.long)))
+    assert abs(ce - float(ret['clip_contrast_loss'])) < 1e-4
+    opt.zero_grad()
+    ret['clip_contrast_loss'].backward()
+    assert all(bool(torch.isfinite(st.grad).all()) for st in m.stores())
+    gn = float(sum(float(st.grad.double().pow(2).sum()) for st in m.stores()) ** 0.5)
+    assert gn > 0
+    opt.step()
+    perm = torch.randperm(64, generator=g).to(gpu)
+    with torch.no_grad():
+        r1, r2 = m(block), m(block[perm])
+    assert abs(float(r1['clip_contrast_loss']) - float(r2['clip_contrast_loss'])) < 5e-2
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_moco_naked_full_queue_step(gpu, dtype):
+    """BASELINE configs[3]: S3D-G MoCo_Naked with the paper's queue, K = 65 536 (model/moco.py:28-239): one full training
+    step -- logits [B, 1 + K] with the positive in column 0, the loss is their cross-entropy, the B keys land in the queue
+    at the pointer, the pointer advances by B, the key encoder moves by the momentum rule and receives no gradient."""
+    from dualvar_amd import model as M
+    from dualvar_amd.optim import SGD
+    torch.manual_seed(0)
+    K, B = 65536, 16
+    m = M.MoCo_Naked('s3dg', 128, K, 0.999, 0.07, False)
+    m.set_compute_dtype(dtype).train().to(gpu)
+    g = torch.Generator().manual_seed(9)
+    block = torch.randn(B, 2, 3, 8, 112, 112, generator=g).to(gpu)
+    opt = SGD([p for p in m.parameters() if p.requires_grad], lr=0.003, momentum=0.9, weight_decay=1e-4, stores=m.stores())
+    q0 = m.queue.detach().clone()
+    kq0 = {k: v.detach().clone() for k, v in m.state_dict().items() if k.startswith('encoder_k.') and v.dtype.is_floating_point}
+    qq0 = {k: v.detach().clone() for k, v in m.state_dict().items() if k.startswith('encoder_q.') and v.dtype.is_floating_point}
+    ret = m(block)
+    lg = ret['clip_logits'].detach().float().cpu()
+    assert lg.shape == (B, 1 + K) and bool(torch.isfinite(lg).all())
+    ce = float(torch.nn.functional.cross_entropy(lg, torch.zeros(B, dtype=torch.long)))
+    assert abs(ce - float(ret['clip_contrast_loss'])) < 2e-4 * max(1.0, ce)
+    # negatives: logits[:, 1:] = q . queue / T  -> |logit| <= 1/T for unit vectors
+    assert float(lg.abs().max()) <= 1.0 / 0.07 * 1.01
+    assert int(m.queue_ptr) == B
+    q1 = m.queue.detach()
+    assert torch.equal(q1[:, B:], q0[:, B:])                          # only the B columns at the pointer changed
+    cols = q1[:, :B].float()
+    assert float((cols.norm(dim=0) - 1).abs().max()) < (1e-5 if dtype == 'fp32' else 1e-2)     # unit-norm keys
+    # positive logit = q . k / T with k = the enqueued key: recover q . k from column 0 and compare with the range
+    opt.zero_grad()
+    ret['clip_contrast_loss'].backward()
+    assert all(p.grad is None or float(p.grad.abs().sum()) == 0.0 for n, p in m.named_parameters() if n.startswith('encoder_k.'))
+    assert any(float(p.grad.abs().sum()) > 0 for n, p in m.named_parameters() if n.startswith('encoder_q.') and p.grad is not None)
+    # momentum rule (moco.py:104-107), applied at the start of the forward: k <- 0.999 k + 0.001 q
+    sd = m.state_dict()
+    worst = 0.0
+    for k, v0 in kq0.items():
+        if 'running' in k or 'num_batches' in k:
+            continue
+        want = 0.999 * v0 + 0.001 * qq0['encoder_q.' + k[len('encoder_k.'):]]
+        worst = max(worst, float((sd[k] - want).abs().max()))
+    assert worst < 1e-6, worst
+    opt.step()
