@@ -30,7 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_PEAK_TF = {'bf16': 2500.0, 'fp32': 157.3}
+# dense MFMA peaks (MI355X_MICROARCH.md).  fp32: the step's fp32 products run as six bf16 partial products (csrc/conv.hip: split3),
+# so the roof of ALGORITHMIC fp32 flops is the bf16 peak / 6; DUALVAR_F32_EXACT=1 (exact-f32 MFMA kernels) prices against 157.3.
+MFMA_PEAK_TF = {'bf16': 2500.0, 'fp32': 157.3 if os.environ.get('DUALVAR_F32_EXACT') == '1' else 2500.0 / 6, 'fp8pw': 2500.0}
 
 
 def parse():
@@ -41,8 +43,9 @@ def parse():
     # fp32 is the reference's arithmetic (no autocast / half anywhere in lzhangbj/DualVar) and the mode whose outputs match
     # the reference within the north-star 1e-3 (tests/test_models_gpu.py): it is the headline `value`.  bf16 storage is
     # reported next to it as `secondary` (--secondary none switches that leg off).
-    ap.add_argument('--dtype', default='fp32', choices=['bf16', 'fp32'])
-    ap.add_argument('--secondary', default='auto', choices=['auto', 'bf16', 'fp32', 'none'],
+    ap.add_argument('--dtype', default='fp32', choices=['bf16', 'fp32', 'fp8pw'],
+                    help="fp8pw: bf16 storage with the bottleneck 1x1x1 convs on the fp8 matrix cores (BASELINE configs[4], --net r50)")
+    ap.add_argument('--secondary', default='auto', choices=['auto', 'bf16', 'fp32', 'fp8pw', 'none'],
                     help="second timed leg in the other storage dtype (auto: bf16 when --dtype is fp32)")
     ap.add_argument('--net', default='s3dg')
     ap.add_argument('--model', default='simclr_naked',
@@ -325,9 +328,14 @@ def main():
             'config': {'workload': f'{args.net} {args.model} pretrain step (fwd+loss+bwd+SGD), {args.frames}x{args.size}x{args.size} '
                                    f'RGB clips, {B} samples x {V} views per GPU, random-init weights',
                        'global_batch': world * B, 'clips_per_step': world * B * V, 'parallelism': f'dp{world}',
-                       'arithmetic': ('fp32 storage, exact-fp32 products, fp32 accumulate: the reference\'s arithmetic; parity with the '
-                                      'reference within 1e-3 on the loss is asserted in this mode (tests/test_models_gpu.py)')
-                       if first['dtype'] == 'fp32' else 'bf16 storage, fp32 accumulate / statistics'},
+                       'arithmetic': ('fp32 storage, fp32 accumulate; products on the bf16 matrix cores through an exact 3-way bf16 split of '
+                                      'each fp32 operand (6 partial products, error at fp32 rounding level; DUALVAR_F32_EXACT=1: exact-f32 '
+                                      'MFMA).  The reference\'s arithmetic: parity with the reference within 1e-3 on the loss is asserted '
+                                      'in this mode (tests/test_models_gpu.py)')
+                       if first['dtype'] == 'fp32' else
+                       ('bf16 storage, fp32 accumulate / statistics' if first['dtype'] == 'bf16' else
+                        'bf16 storage; bottleneck 1x1x1 convs: e4m3 x e4m3 (forward) / e5m2 x e4m3 (data gradient) on the fp8 MFMA, fp32 '
+                        'accumulate, per-tensor scales')},
             'loss': first['loss'],
             'roofline': first['roofline'],
             'whole_step': first['whole_step'],

@@ -68,6 +68,10 @@ SIGNATURES = {
     'dv_conv3d_wgrad_workspace': [CD],
     'dv_conv3d_wgrad_tile': [CD, P, P, P],
     'dv_conv3d_wgrad': [CD, P, P, P, P, I64, P],
+    'dv_quantize_fp8_workspace': [],
+    'dv_quantize_fp8': [I32, P, I64, I32, I32, I32, P, I32, P, P, P],
+    'dv_conv3d_fwd_fp8': [CD, P, P, P, P, P, P, P],
+    'dv_conv3d_dgrad_fp8': [CD, P, P, P, P, P, P],
     'dv_pack_dgrad_weights': [I32, P, P, P, P, I32, P],
     'dv_cast_arena': [I32, P, P, I64, P],
     'dv_ingest_ncdhw': [I32, P, P, I32, I32, I32, I32, I32, I64, I32, P, P, P, I32, P],

@@ -143,6 +143,7 @@ class HipBackbone(nn.Module):
         self._own_store = True
         self._plans = {}
         self._dtype = None
+        self._fp8pw = False
         self._anchor = None
         self._norm = None
         self.comm = None
@@ -152,7 +153,10 @@ class HipBackbone(nn.Module):
 
     # -- configuration
     def set_compute_dtype(self, name):
-        self._dtype = _DTYPES[name] if isinstance(name, str) else name
+        """'fp32' | 'bf16' | 'fp8pw': bf16 storage with the 1x1x1 convs a network marks (the 2D3D-ResNet bottlenecks' conv1 /
+        conv3, BASELINE configs[4]) on the fp8 matrix-core path -- forward and data gradient, per-tensor e4m3 / e5m2 scaling"""
+        self._fp8pw = isinstance(name, str) and name.lower() in ('fp8pw', 'fp8')
+        self._dtype = DV_BF16 if self._fp8pw else (_DTYPES[name] if isinstance(name, str) else name)
         self._plans.clear()
         return self
 
@@ -205,7 +209,7 @@ class HipBackbone(nn.Module):
     def _acquire_plan(self, x, use_perm, want_map, with_grad):
         N, _, T, H, W = x.shape
         n_seg = 0
-        key = (N, T, H, W, use_perm, want_map, with_grad, self.store.generation, self.dtype, self.training)
+        key = (N, T, H, W, use_perm, want_map, with_grad, self.store.generation, self.dtype, self.training, self._fp8pw)
         lst = self._plans.setdefault(key, [])
         for pl in lst:
             ref = pl._busy_ref
@@ -213,6 +217,7 @@ class HipBackbone(nn.Module):
                 return pl
         comm = self.comm if self.comm is not None else Comm()
         pl = Plan(self.store, self.dtype, x.device, with_grad=with_grad, comm=comm, training=self.training)
+        pl.fp8_pointwise = self._fp8pw
         pl.ingest = pl._push(IngestOp(pl, N, T, H, W, n_seg, pad=self.stem_pad))
         out = self.emit(pl, pl.ingest.y)
         pl.out_act = out
@@ -241,6 +246,8 @@ class HipBackbone(nn.Module):
             from ..parallel import bucket_ranges
             plan.bucket_starts = tuple(a for a, _ in bucket_ranges(self.store.total, self.bucket_elems))
         with torch.no_grad():
+            if self.store._fp8_stale:            # a plan built after prepare() registered new fp8 weight copies
+                self.store._refresh_fp8()
             if self.training:
                 self.store.bump_bn_counters()
             plan.run_forward()
@@ -282,10 +289,11 @@ def conv_geometry(conv):
     return tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding)
 
 
-def emit_conv_bn(plan, conv, bn, x, relu=True, residual=None, out=None):
-    """conv (bias-free) -> train-mode BN (+residual) (+ReLU)."""
+def emit_conv_bn(plan, conv, bn, x, relu=True, residual=None, out=None, fp8=False):
+    """conv (bias-free) -> train-mode BN (+residual) (+ReLU).  fp8: the layer may run on the fp8 pointwise path when the
+    plan's compute mode is 'fp8pw' (Plan.conv checks that it is a 1x1x1 stride-1 conv with 16-aligned channel pitches)."""
     k, s, p = conv_geometry(conv)
-    raw = plan.conv(plan.store.slot(conv.weight), x, k, s, p)
+    raw = plan.conv(plan.store.slot(conv.weight), x, k, s, p, fp8=fp8)
     return plan.bn(bn, raw, relu=relu, residual=residual, out=out)
 
 

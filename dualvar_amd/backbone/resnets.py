@@ -165,13 +165,14 @@ class _Bottleneck(nn.Module):
             register_conv_bn(store, self.downsample[0], self.downsample[1])
 
     def emit(self, plan, x, force_relu):
-        y = emit_conv_bn(plan, self.conv1, self.bn1, x)
+        # conv1 (1x1x1 in the 2d blocks) and conv3 are the pointwise GEMMs BASELINE configs[4] puts on the fp8 matrix cores
+        y = emit_conv_bn(plan, self.conv1, self.bn1, x, fp8=True)
         y = emit_conv_bn(plan, self.conv2, self.bn2, y)
         shortcut = x
         if self.downsample is not None:
             shortcut = emit_conv_bn(plan, self.downsample[0], self.downsample[1], x, relu=False)
         # the net ends with F.relu(x) (resnet_2d3d.py:341), so the final block's missing ReLU is applied here
-        return emit_conv_bn(plan, self.conv3, self.bn3, y, relu=self.use_final_relu or force_relu, residual=shortcut)
+        return emit_conv_bn(plan, self.conv3, self.bn3, y, relu=self.use_final_relu or force_relu, residual=shortcut, fp8=True)
 
 
 class Bottleneck2d(_Bottleneck):

@@ -11,6 +11,13 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// OCP fp8 storage tags for the pointwise-conv GEMMs (one byte per element; e4m3 for activations / weights, e5m2 for
+// gradients).  They only carry the operand format into the kernel templates; arithmetic happens in the MFMA.
+struct fp8e4_t { unsigned char v; };
+struct fp8e5_t { unsigned char v; };
 
 #define DV_WAVE 64
 

@@ -43,6 +43,8 @@ struct ConvArgs {
   int lds_, ldo, ldw;    // pitches in elements (src, out, weights)
   int ntn;               // number of N tiles
   int flags;
+  const float* sc_a;     // fp8 GEMMs: device scalars, result = acc * sc_a[0] * sc_b[0] (per-tensor scales of the operands)
+  const float* sc_b;
   int src_bytes, w_bytes; // extents for the buffer descriptors (< 2 GiB)
   FastDiv fCP;           // k -> (tap, c)
   ConvGeom g;
@@ -197,6 +199,30 @@ template <> struct Mma<float> {
     }
   }
 };
+
+// fp8 operands (1x1x1 convs of the bottleneck blocks, BASELINE configs[4]): one K tile = 64 bytes = 64 fp8 per row = ONE
+// v_mfma_f32_32x32x64_f8f6f4 (twice the bf16 rate per clock); lane (r = lane&31, h = lane>>5) holds k = 32h .. 32h+31 of
+// its row in eight VGPRs.  FA / FB: 0 = e4m3, 1 = e5m2 (cbsz / blgp).  Scales 0 select the unscaled form of the instruction.
+template <int FA, int FB>
+__device__ __forceinline__ void mma_fp8(const unsigned char* a_row, const unsigned char* b_row, int h, int sa, int sb, f32x16& acc) {
+  const i32x4 a0 = *reinterpret_cast<const i32x4*>(a_row + ((2 * h) ^ sa) * 16), a1 = *reinterpret_cast<const i32x4*>(a_row + ((2 * h + 1) ^ sa) * 16);
+  const i32x4 b0 = *reinterpret_cast<const i32x4*>(b_row + ((2 * h) ^ sb) * 16), b1 = *reinterpret_cast<const i32x4*>(b_row + ((2 * h + 1) ^ sb) * 16);
+  const i32x8 a = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, b = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, FA, FB, 0, 0, 0, 0);
+}
+template <> struct Mma<fp8e4_t> {       // forward: x (e4m3) * w (e4m3)
+  static __device__ __forceinline__ void tile(const unsigned char* a_row, const unsigned char* b_row, int h, int sa, int sb, f32x16& acc) {
+    mma_fp8<0, 0>(a_row, b_row, h, sa, sb, acc);
+  }
+};
+template <> struct Mma<fp8e5_t> {       // data gradient: dy (e5m2) * w (e4m3)
+  static __device__ __forceinline__ void tile(const unsigned char* a_row, const unsigned char* b_row, int h, int sa, int sb, f32x16& acc) {
+    mma_fp8<1, 0>(a_row, b_row, h, sa, sb, acc);
+  }
+};
+template <typename T> struct OutOf { typedef T type; };
+template <> struct OutOf<fp8e4_t> { typedef bf16_t type; };          // fp8 GEMMs write bf16 activations / gradients
+template <> struct OutOf<fp8e5_t> { typedef bf16_t type; };
 
 // ---- fp32 operands on the bf16 matrix cores ("3 x bf16 split") ----------------------------------------------------
 // gfx950 has no xf32 / TF32 path and its f32-input MFMA runs at the vector rate, 1/16 of the bf16 MFMA.  An fp32 value
@@ -527,8 +553,18 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
   }
 
   // ---------------- epilogue
-  T* out = reinterpret_cast<T*>(a.out);
+  typedef typename OutOf<T>::type OT;           // what is stored (T, or bf16 for the fp8 GEMMs)
+  OT* out = reinterpret_cast<OT*>(a.out);
   const int flags = a.flags;
+  if constexpr (sizeof(T) == 1) {               // fp8 operands were scaled per tensor: undo it on the fp32 accumulators
+    const float sc = a.sc_a[0] * a.sc_b[0];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= sc;
+  }
   // row of the output tensor for row `m` of this launch (identity, or class sub-lattice -> full input: see ConvArgs)
   auto out_row = [&](int m) -> size_t {
     if (!a.cls_on) return (size_t)m;
@@ -559,7 +595,7 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
       st_s2[j] = fmaf(d, d, st_s2[j]);
     }
   };
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (sizeof(OT) == 2) {
     // bf16: each wave stages a 32-row strip of its tile in LDS ([row][col], 2-byte writes at immediate offsets) and
     // writes it out as 16-byte vectors, eight lanes per 128-byte row segment -- instead of one 2-byte global store and
     // a 64-bit address computation per element (the old epilogue was ~1/3 of all instructions a workgroup issued).
@@ -584,9 +620,9 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
             v = act_apply(v + bv, flags);
             if (col >= a.N || m0 + wm0 + i * 32 + rl >= a.M) v = 0.f;
           }
-          const T tv = DT<T>::from_f(v);
-          *reinterpret_cast<T*>(stg + rl * SP + (j * 32 + l31) * 2) = tv;
-          if (do_stats) stat_acc(i, j, r, DT<T>::to_f(tv), rl);
+          const OT tv = DT<OT>::from_f(v);
+          *reinterpret_cast<OT*>(stg + rl * SP + (j * 32 + l31) * 2) = tv;
+          if (do_stats) stat_acc(i, j, r, DT<OT>::to_f(tv), rl);
         }
       }
 #pragma unroll
@@ -596,7 +632,7 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
         const int row = m0 + wm0 + i * 32 + rl, col0 = n0 + wn0 + ch * 8;
         if (row < a.M && col0 < a.NP) {
           bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + rl * SP + ch * 16);
-          T* p = out + out_row(row) * a.ldo + col0;
+          OT* p = out + out_row(row) * a.ldo + col0;
           if (flags & DV_ACCUM) {
             const bf16x8 o = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
@@ -620,11 +656,11 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
           float v = act_apply(acc[i][j][r] + bv, flags);
           if (col >= a.N) v = 0.f;
           if (row < a.M && col < a.NP) {
-            T* p = out + out_row(row) * a.ldo + col;
-            if (flags & DV_ACCUM) v += DT<T>::to_f(*p);
-            T tv = DT<T>::from_f(v);
+            OT* p = out + out_row(row) * a.ldo + col;
+            if (flags & DV_ACCUM) v += DT<OT>::to_f(*p);
+            OT tv = DT<OT>::from_f(v);
             *p = tv;
-            v = DT<T>::to_f(tv);
+            v = DT<OT>::to_f(tv);
           } else {
             v = 0.f;
           }
@@ -684,7 +720,7 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
       }
     }
   }
-  if constexpr (STATS_MODE && sizeof(T) == 2) {
+  if constexpr (STATS_MODE && sizeof(OT) == 2) {
     if (do_stats) {
       // merge: halves of a wave share the centre; the WAVES_M row strips of a column are combined pairwise (Chan)
       float* red = reinterpret_cast<float*>(smem);            // [WAVES_M][2][BN]
@@ -1396,7 +1432,7 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   if (!aligned16(w) || !aligned16(y) || (reinterpret_cast<uintptr_t>(x) & 7)) return DV_EALIGN;
   ConvArgs a;
   fill_geom(d, MODE_FWD, a.g);
-  a.src = x; a.w = w; a.out = y; a.bias = bias; a.stats = stats;
+  a.src = x; a.w = w; a.out = y; a.bias = bias; a.stats = stats; a.sc_a = a.sc_b = nullptr;
   a.M = d->N * d->To * d->Ho * d->Wo;
   a.N = d->Cout; a.NP = d->cout_pitch;
   a.lds_ = d->ldx; a.ldo = d->ldy; a.ldw = a.g.Ktot;
@@ -1426,6 +1462,75 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   return dv_launch_status();
 }
 
+// ---- fp8 pointwise GEMMs (BASELINE configs[4]: the 1x1x1 convs of resnet_2d3d.py's bottleneck blocks) --------------------
+template <typename T, int MODE>
+static void launch_gemm_fp8(int bm, int bn, const ConvArgs& a, int grid, hipStream_t s) {
+  // one tap, channel pitch a multiple of the 64-element K tile: the uniform-tap gather (tap state in SGPRs)
+  if (a.g.CP % 64 == 0) launch_gemm_ns<T, MODE, 16, 1, 2>(bm, bn, a, grid, s);
+  else launch_gemm_ns<T, MODE, 16, 0, 2>(bm, bn, a, grid, s);
+}
+
+static int check_fp8_desc(const dv_conv_desc* d) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (d->dtype != DV_BF16) return DV_EUNSUPPORTED;                       // the bf16 side of the GEMM (output, other tensors)
+  if (d->kt != 1 || d->kh != 1 || d->kw != 1 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt || d->ph || d->pw)
+    return DV_EUNSUPPORTED;                                              // pointwise only
+  if (d->cin_pitch % 16 || d->cout_pitch % 16) return DV_EALIGN;          // 16-byte gathers of fp8 channels
+  return DV_OK;
+}
+
+extern "C" int dv_conv3d_fwd_fp8(const dv_conv_desc* d, const void* x8, const void* w8, const float* scale_x,
+                                 const float* scale_w, void* y, float* stats, void* stream) {
+  int rc = check_fp8_desc(d);
+  if (rc) return rc;
+  if (!x8 || !w8 || !y || !scale_x || !scale_w) return DV_EINVAL;
+  if ((d->flags & DV_STATS) && !stats) return DV_EINVAL;
+  if (!aligned16(x8) || !aligned16(w8) || !aligned16(y) || d->ldx % 16 || (d->ldy * 2) % 16) return DV_EALIGN;
+  ConvArgs a;
+  fill_geom(d, MODE_FWD, a.g);
+  a.src = x8; a.w = w8; a.out = y; a.bias = nullptr; a.stats = stats; a.sc_a = scale_x; a.sc_b = scale_w;
+  a.M = d->N * d->To * d->Ho * d->Wo;
+  a.N = d->Cout; a.NP = d->cout_pitch;
+  a.lds_ = d->ldx; a.ldo = d->ldy; a.ldw = a.g.Ktot;
+  a.flags = d->flags & DV_STATS;
+  a.cls_on = 0;
+  const int64_t sb = ((int64_t)a.M - 1) * d->ldx + d->cin_pitch, wb = (int64_t)d->Cout * a.g.Ktot;
+  if (sb >= (1ll << 31) || wb >= (1ll << 31)) return DV_EUNSUPPORTED;
+  a.src_bytes = (int)sb; a.w_bytes = (int)wb;
+  a.fCP = make_fastdiv((uint32_t)a.g.CP);
+  int bm, bn;
+  pick_tile(DV_BF16, a.M, a.NP, bm, bn);
+  a.ntn = (a.NP + bn - 1) / bn;
+  launch_gemm_fp8<fp8e4_t, MODE_FWD>(bm, bn, a, a.ntn * ((a.M + bm - 1) / bm), (hipStream_t)stream);
+  return dv_launch_status();
+}
+
+extern "C" int dv_conv3d_dgrad_fp8(const dv_conv_desc* d, const void* dy8, const void* wd8, const float* scale_dy,
+                                   const float* scale_w, void* dx, void* stream) {
+  int rc = check_fp8_desc(d);
+  if (rc) return rc;
+  if (!dy8 || !wd8 || !dx || !scale_dy || !scale_w) return DV_EINVAL;
+  if (!aligned16(dy8) || !aligned16(wd8) || !aligned16(dx) || d->ldy % 16 || (d->ldx * 2) % 16) return DV_EALIGN;
+  ConvArgs a;
+  fill_geom(d, MODE_DGRAD, a.g);
+  a.src = dy8; a.w = wd8; a.out = dx; a.bias = nullptr; a.stats = nullptr; a.sc_a = scale_dy; a.sc_b = scale_w;
+  a.M = d->N * d->Ti * d->Hi * d->Wi;
+  a.N = d->Cin; a.NP = d->cin_pitch;
+  a.lds_ = d->ldy; a.ldo = d->ldx; a.ldw = a.g.Ktot;
+  a.flags = d->flags & DV_ACCUM;
+  a.cls_on = 0;
+  const int64_t sb = ((int64_t)a.M - 1) * d->ldy + d->cout_pitch, wb = (int64_t)d->Cin * a.g.Ktot;
+  if (sb >= (1ll << 31) || wb >= (1ll << 31)) return DV_EUNSUPPORTED;
+  a.src_bytes = (int)sb; a.w_bytes = (int)wb;
+  a.fCP = make_fastdiv((uint32_t)a.g.CP);
+  int bm, bn;
+  pick_tile(DV_BF16, a.M, a.NP, bm, bn);
+  a.ntn = (a.NP + bn - 1) / bn;
+  launch_gemm_fp8<fp8e5_t, MODE_DGRAD>(bm, bn, a, a.ntn * ((a.M + bm - 1) / bm), (hipStream_t)stream);
+  return dv_launch_status();
+}
+
 extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void* wd, void* dx, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
@@ -1437,7 +1542,7 @@ extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void
   if ((d->ldx * esz) % 16) return DV_EALIGN;
   ConvArgs a;
   fill_geom(d, MODE_DGRAD, a.g);
-  a.src = dy; a.w = wd; a.out = dx; a.bias = nullptr; a.stats = nullptr;
+  a.src = dy; a.w = wd; a.out = dx; a.bias = nullptr; a.stats = nullptr; a.sc_a = a.sc_b = nullptr;
   a.M = d->N * d->Ti * d->Hi * d->Wi;
   a.N = d->Cin; a.NP = d->cin_pitch;
   a.lds_ = d->ldy; a.ldo = d->ldx; a.ldw = a.g.Ktot;

@@ -1619,3 +1619,99 @@ extern "C" int dv_pack_dgrad_weights(int32_t dtype, const float* master, void* d
   else return DV_EUNSUPPORTED;
   return dv_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------
+// fp8 quantisation for the pointwise-conv GEMMs (dv_conv3d_fwd_fp8 / dv_conv3d_dgrad_fp8): per-tensor scaling,
+//   scale = amax / FMAX (448 for e4m3, 57344 for e5m2; 1 when the tensor is all zero),  q = fp8(x / scale)  (RNE, finite).
+// Two launches and no atomics: block maxima -> every block of the second launch folds them (<= 1024 floats) and converts.
+#include <hip/hip_fp8.h>
+namespace {
+
+constexpr int kAmaxBlocks = 512;
+
+template <typename T>
+__global__ void __launch_bounds__(256) amax_partials_kernel(const T* __restrict__ x, int64_t M, int C, int ld, float* __restrict__ part) {
+  constexpr int V = DT<T>::VEC;
+  const int vpr = C / V;
+  const int64_t total = M * vpr;
+  float m = 0.f;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / vpr;
+    const int cv = (int)(i - r * vpr);
+    float v[V];
+    Pack16<T>::load(x + r * ld + cv * V, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) m = fmaxf(m, fabsf(v[e]));
+  }
+  m = wave_max(m);
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+template <typename T, int FMT>
+__global__ void __launch_bounds__(256) quantize_fp8_kernel(const T* __restrict__ x, int64_t M, int C, int ld, const float* __restrict__ part,
+                                                           int nparts, unsigned char* __restrict__ q, int ldq, float* __restrict__ scale_out) {
+  __shared__ float s_amax;
+  {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, part[i]);
+    m = wave_max(m);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) s_amax = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+  }
+  constexpr float FMAX = FMT == 0 ? 448.f : 57344.f;
+  const float amax = s_amax;
+  const float scale = amax > 0.f ? amax / FMAX : 1.f;
+  const float inv = 1.f / scale;
+  if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = scale;
+  const int vpr = C / 16;                                       // 16 fp8 per 16-byte store
+  const int64_t total = M * vpr;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / vpr;
+    const int cv = (int)(i - r * vpr);
+    union { unsigned char b[16]; uint4 u; } o;
+    constexpr int V = DT<T>::VEC;
+#pragma unroll
+    for (int hv = 0; hv < 16 / V; ++hv) {
+      float v[V];
+      Pack16<T>::load(x + r * ld + cv * 16 + hv * V, v);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float t = fminf(fmaxf(v[e] * inv, -FMAX), FMAX);
+        o.b[hv * V + e] = __hip_cvt_float_to_fp8(t, __HIP_SATFINITE, FMT == 0 ? __HIP_E4M3 : __HIP_E5M2);
+      }
+    }
+    *reinterpret_cast<uint4*>(q + r * ldq + cv * 16) = o.u;
+  }
+}
+
+}  // namespace
+
+extern "C" int dv_quantize_fp8_workspace(void) { return kAmaxBlocks * 4; }
+
+extern "C" int dv_quantize_fp8(int32_t dtype, const void* x, int64_t M, int32_t C, int32_t ld, int32_t fmt, void* q, int32_t ldq,
+                               float* scale_out, float* workspace, void* stream) {
+  if (!x || !q || !scale_out || !workspace || M <= 0 || C <= 0 || C % 16 || ld < C || ldq < C || ldq % 16) return DV_EINVAL;
+  if (dtype != DV_F32 && dtype != DV_BF16) return DV_EUNSUPPORTED;
+  if (fmt != 0 && fmt != 1) return DV_EINVAL;
+  const int es = dtype == DV_F32 ? 4 : 2;
+  if (!aligned16(x) || !aligned16(q) || (ld * es) % 16) return DV_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t vecs = M * (C / 16);
+  const int blocks = (int)(vecs / 256 + 1 < kAmaxBlocks ? vecs / 256 + 1 : kAmaxBlocks);
+#define DV_Q(T_, F_)                                                                                                         \
+  do {                                                                                                                       \
+    hipLaunchKernelGGL((amax_partials_kernel<T_>), dim3(blocks), dim3(256), 0, st, (const T_*)x, M, C, ld, workspace);        \
+    hipLaunchKernelGGL((quantize_fp8_kernel<T_, F_>), dim3(blocks * 2), dim3(256), 0, st, (const T_*)x, M, C, ld, workspace,  \
+                       blocks, (unsigned char*)q, ldq, scale_out);                                                          \
+  } while (0)
+  if (dtype == DV_F32) { if (fmt == 0) DV_Q(float, 0); else DV_Q(float, 1); }
+  else { if (fmt == 0) DV_Q(bf16_t, 0); else DV_Q(bf16_t, 1); }
+#undef DV_Q
+  return dv_launch_status();
+}

@@ -65,6 +65,7 @@ class ParamStore:
         self.total = 0
         self.no_dgrad = False         # key encoders (never back-propagated) skip the dgrad-layout weights
         self.pending_backward = 0     # forward passes with autograd history whose backward has not run yet (reset by the optimizer)
+        self._fp8, self._fp8_ws, self._fp8_stale = {}, None, False    # fp8 copies of pointwise-conv weights (fp8_weights)
 
     # ---- registration (idempotent per tensor: S3D registers its stem twice)
     def _add(self, t, kind, **kw):
@@ -210,6 +211,7 @@ class ParamStore:
         self.generation += 1
         self._dirty = True
         self._versions = None
+        self._fp8, self._fp8_stale = {}, False
 
     def trainable_ranges(self):
         """[(first element, count)] of the maximal runs of arena slots whose tensors require gradients (alignment
@@ -265,15 +267,45 @@ class ParamStore:
             if v != self._versions:
                 self._dirty = True
         if not self._dirty:
+            if self._fp8_stale:
+                self._refresh_fp8()
             return
         if self.dtype == DV_BF16 and not self._cast_done:
             ops.call('dv_cast_arena', DV_BF16, self.master, self.cc, self.total)
         if self._n_pack_blocks:
             ops.call('dv_pack_dgrad_weights', self.dtype, self.master, self.wd, self._pack_descs, self._pack_map,
                      self._n_pack_blocks)
+        self._refresh_fp8()
         self._dirty = False
         self._cast_done = False
         self._versions = self._version_sum()
+
+    def fp8_weights(self, s):
+        """(w8 [Cout][CinP] e4m3, scale, wd8 [Cin][CoutP] e4m3, scale) of a 1x1x1 conv slot for the fp8 pointwise path; the
+        copies are re-quantised (per-tensor amax scaling) whenever the master weights change -- see refresh()"""
+        e = self._fp8.get(id(s))
+        if e is None:
+            dev = self.master.device
+            e = (s, torch.zeros(s.Cout, s.cin_pitch, dtype=torch.uint8, device=dev), torch.ones(1, device=dev),
+                 torch.zeros(s.Cin, s.cout_pitch, dtype=torch.uint8, device=dev), torch.ones(1, device=dev))
+            self._fp8[id(s)] = e
+            self._fp8_stale = True
+        return e[1:]
+
+    def _refresh_fp8(self):
+        if not self._fp8:
+            return
+        lib = L.load()
+        if self._fp8_ws is None:
+            self._fp8_ws = torch.empty(lib.dv_quantize_fp8_workspace() // 4, dtype=torch.float32, device=self.master.device)
+        es = ops.ESIZE[self.dtype]
+        for s, w8, sw, wd8, swd in self._fp8.values():
+            ops.call('dv_quantize_fp8', self.dtype, self.cc.data_ptr() + s.off * es, s.Cout, s.cin_pitch, s.cin_pitch, 0, w8, s.cin_pitch,
+                     sw, self._fp8_ws)
+            if s.wd_off >= 0:
+                ops.call('dv_quantize_fp8', self.dtype, self.wd.data_ptr() + s.wd_off * es, s.Cin, s.cout_pitch, s.cout_pitch, 0, wd8,
+                         s.cout_pitch, swd, self._fp8_ws)
+        self._fp8_stale = False
 
     # pointers
     def w_fwd(self, s):
@@ -383,6 +415,8 @@ class Plan:
         self._side = None            # side stream + events of run_backward
         self._events = None
         self.grad_ready = None       # callable(plan, lo): gradient-arena elements [lo, total) are final (GradSync.attach)
+        self.fp8_pointwise = False   # compute mode 'fp8pw' (backbone/base.py: set_compute_dtype)
+        self._fp8_ws = None
         self.bucket_starts = ()      # ... called when lo drops to / below each of these element offsets
         self._triggers = None
 
@@ -421,7 +455,10 @@ class Plan:
         self.ops.append(op)
         return op
 
-    def conv(self, slot, x, k, s, p, out=None, stats=True):
+    def conv(self, slot, x, k, s, p, out=None, stats=True, fp8=False):
+        fp8 = bool(fp8 and getattr(self, 'fp8_pointwise', False) and self.dtype == DV_BF16 and tuple(k) == (1, 1, 1)
+                   and tuple(s) == (1, 1, 1) and tuple(p) == (0, 0, 0) and slot.cin_pitch % 16 == 0 and slot.cout_pitch % 16 == 0
+                   and slot.kind == 'conv' and x.cpitch == slot.cin_pitch)
         if getattr(x, 'hw_pad', 0):
             # RGB stem on the zero-bordered ingest frames (include/dualvar_hip.h, dv_ingest_ncdhw_pad): the 7x7
             # stride-2 padding-3 conv becomes a (kt,7,4)-tap stride-(st,2,1) conv over 8-channel pixel pairs
@@ -437,7 +474,7 @@ class Plan:
             op.zero_pad_taps = (slot.Cout * k[0] * 7, 32, 28, 4)    # rows, pitch, first pad column, count
             op.y.producer = op
             return op.y
-        op = self._push(ConvOp(self, slot, x, k, s, p, out, stats))
+        op = self._push(ConvOp(self, slot, x, k, s, p, out, stats, fp8=fp8))
         op.y.producer = op
         return op.y
 
@@ -654,9 +691,10 @@ def _abytes(a, c=None):
 class ConvOp(Op):
     """conv (bias-free, BN partial statistics in the epilogue) with wgrad + dgrad."""
 
-    def __init__(self, plan, slot, x, k, s, p, out, stats):
+    def __init__(self, plan, slot, x, k, s, p, out, stats, fp8=False):
         super().__init__(plan)
         self.slot, self.x, self.k, self.s, self.p = slot, x, k, s, p
+        self.fp8 = fp8
         self.dtype = plan.dtype
         To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
         self.y = out if out is not None else plan.act(x.N, To, Ho, Wo, slot.Cout)
@@ -690,6 +728,8 @@ class ConvOp(Op):
         f = [Launch('conv_fwd', kf, lib.dv_conv3d_fwd,
                     (C.byref(self.d), x.ptr, st.w_fwd(sl), 0, y.ptr, self.stats.data_ptr() if self.stats is not None else 0),
                     _abytes(x) + wbytes + _abytes(y), flops, shp)]
+        if self.fp8:
+            f = self._fp8_forward(shp, flops, wbytes)
         b = []
         if p.with_grad:
             self.d_w = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=0)
@@ -706,13 +746,64 @@ class ConvOp(Op):
                 rows, pitch, c0, nc = self.zero_pad_taps
                 b.append(Launch('stem_pad_taps', 'fill_cols', lib.dv_fill_cols_f32, (st.w_grad(sl), rows, pitch, c0, nc, 0.0)))
                 b[-1].gend = sl.off + sl.size
-            if self.need_dx:
+            if self.need_dx and self.fp8:
+                b += self._fp8_dgrad(shp, flops, wbytes)
+            elif self.need_dx:
                 acc = bool(self.acc.get('x'))
                 self.d_g = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=DV_ACCUM if acc else 0)
                 b.append(Launch('conv_dgrad', 'conv_gemm<%s,DGRAD,16,%d,%d>' % ((_dt(self.dtype),) + _tile_shape(lib, self.d_g, 1)),
                                 lib.dv_conv3d_dgrad, (C.byref(self.d_g), y.grad.ptr, st.w_dgrad(sl), x.grad.ptr),
                                 _abytes(y) + wbytes + _abytes(x) * (2 if acc else 1), flops, shp))
         return f, b
+
+
+def _fp8_methods():
+    """fp8 pointwise path of ConvOp (compute mode 'fp8pw'; include/dualvar_hip.h: dv_conv3d_fwd_fp8 / dv_conv3d_dgrad_fp8)"""
+    def _ws(self):
+        p = self.plan
+        if p._fp8_ws is None:
+            p._fp8_ws = p.f32(p.lib.dv_quantize_fp8_workspace() // 4)
+        return p._fp8_ws
+
+    def _fp8_forward(self, shp, flops, wbytes):
+        p, st, lib, sl, x, y = self.plan, self.plan.store, self.plan.lib, self.slot, self.x, self.y
+        w8, sw, _, _ = st.fp8_weights(sl)
+        self.x8 = torch.empty(x.rows, x.cpitch, dtype=torch.uint8, device=p.device)
+        self.sx = p.f32(1)
+        p.bytes += self.x8.numel()
+        ws = _ws(self)
+        self.d8 = ops.conv_desc(DV_BF16, x, y, self.k, self.s, self.p, flags=self.d.flags)
+        self.d8.ldx = x.cpitch
+        tile = _tile_shape(lib, self.d, 0)
+        return [Launch('quantize_fp8', 'quantize_fp8<e4m3>', lib.dv_quantize_fp8,
+                       (DV_BF16, x.ptr, x.rows, x.cpitch, x.ld, 0, self.x8.data_ptr(), x.cpitch, self.sx.data_ptr(), ws.data_ptr()),
+                       2 * _abytes(x) + x.rows * x.cpitch, 0, shp),
+                Launch('conv_fwd', 'conv_gemm<fp8,FWD,16,%d,%d>' % tile, lib.dv_conv3d_fwd_fp8,
+                       (C.byref(self.d8), self.x8.data_ptr(), w8.data_ptr(), self.sx.data_ptr(), sw.data_ptr(), y.ptr,
+                        self.stats.data_ptr() if self.stats is not None else 0),
+                       x.rows * x.cpitch + wbytes // 2 + _abytes(y), flops, shp)]
+
+    def _fp8_dgrad(self, shp, flops, wbytes):
+        p, st, lib, sl, x, y = self.plan, self.plan.store, self.plan.lib, self.slot, self.x, self.y
+        _, _, wd8, swd = st.fp8_weights(sl)
+        self.dy8 = torch.empty(y.rows, y.cpitch, dtype=torch.uint8, device=p.device)
+        self.sdy = p.f32(1)
+        p.bytes += self.dy8.numel()
+        ws = _ws(self)
+        acc = bool(self.acc.get('x'))
+        self.d8g = ops.conv_desc(DV_BF16, x, y, self.k, self.s, self.p, flags=DV_ACCUM if acc else 0)
+        self.d8g.ldy = y.cpitch
+        g = y.grad
+        return [Launch('quantize_fp8', 'quantize_fp8<e5m2>', lib.dv_quantize_fp8,
+                       (DV_BF16, g.ptr, g.rows, g.cpitch, g.ld, 1, self.dy8.data_ptr(), y.cpitch, self.sdy.data_ptr(), ws.data_ptr()),
+                       2 * _abytes(y) + y.rows * y.cpitch, 0, shp),
+                Launch('conv_dgrad', 'conv_gemm<fp8,DGRAD,16,%d,%d>' % _tile_shape(lib, self.d8g, 1), lib.dv_conv3d_dgrad_fp8,
+                       (C.byref(self.d8g), self.dy8.data_ptr(), wd8.data_ptr(), self.sdy.data_ptr(), swd.data_ptr(), x.grad.ptr),
+                       y.rows * y.cpitch + wbytes // 2 + _abytes(x) * (2 if acc else 1), flops, shp)]
+    return _fp8_forward, _fp8_dgrad
+
+
+ConvOp._fp8_forward, ConvOp._fp8_dgrad = _fp8_methods()
 
 
 class BNMember:

@@ -107,6 +107,27 @@ def conv_wgrad(d, x, dy, dw, workspace=None):
     L.check(lib.dv_conv3d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(workspace), nbytes, stream_ptr()), 'dv_conv3d_wgrad')
 
 
+def quantize_fp8(x, M, C, ld, fmt, dtype, q=None, scale=None, workspace=None):
+    """per-tensor fp8 quantisation of the [M, C] view at `x` (pitch ld elements): -> (q uint8 [M, C], scale float32[1])"""
+    lib = L.load()
+    dev = x.device if isinstance(x, torch.Tensor) else x.buf.device
+    q = torch.empty(M, C, dtype=torch.uint8, device=dev) if q is None else q
+    scale = torch.empty(1, dtype=torch.float32, device=dev) if scale is None else scale
+    if workspace is None:
+        workspace = torch.empty(lib.dv_quantize_fp8_workspace() // 4, dtype=torch.float32, device=dev)
+    L.check(lib.dv_quantize_fp8(dtype, _p(x), M, C, ld, fmt, _p(q), q.stride(0), _p(scale), _p(workspace), stream_ptr()),
+            'dv_quantize_fp8')
+    return q, scale
+
+
+def conv_fwd_fp8(d, x8, w8, sx, sw, y, stats):
+    L.check(L.load().dv_conv3d_fwd_fp8(C.byref(d), _p(x8), _p(w8), _p(sx), _p(sw), _p(y), _p(stats), stream_ptr()), 'dv_conv3d_fwd_fp8')
+
+
+def conv_dgrad_fp8(d, dy8, wd8, sdy, sw, dx):
+    L.check(L.load().dv_conv3d_dgrad_fp8(C.byref(d), _p(dy8), _p(wd8), _p(sdy), _p(sw), _p(dx), stream_ptr()), 'dv_conv3d_dgrad_fp8')
+
+
 def stat_tiles(d):
     return L.load().dv_conv3d_stat_tiles(C.byref(d))
 

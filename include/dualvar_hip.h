@@ -108,6 +108,23 @@ int dv_conv3d_wgrad_tile(const dv_conv_desc* d, int32_t* rows, int32_t* cols, in
 int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace,
                     int64_t workspace_bytes, void* stream);
 
+/* ---- fp8 pointwise path (BASELINE configs[4]: "fp8 MFMA pointwise convs" of the 2D3D-ResNet-50 bottlenecks,
+ * resnet_2d3d.py:130,167,173).  A 1x1x1 stride-1 conv is the GEMM Y[M, Cout] = X[M, Cin] W[Cout, Cin]^T; with OCP fp8
+ * operands it runs on v_mfma_f32_32x32x64_f8f6f4 (fp32 accumulate, twice the bf16 rate per clock).  Operands are quantised
+ * per TENSOR: dv_quantize_fp8 computes amax, scale = amax / 448 (e4m3; 57344 for e5m2) and q = fp8_rne(x / scale) into a
+ * dense [M][ldq] byte tensor (channel pitch a multiple of 16); the GEMMs multiply the fp32 accumulators by the two scales
+ * (device scalars: no host round trip).  Forward: x, w e4m3 -> y bf16 (+ DV_STATS partials like dv_conv3d_fwd); data
+ * gradient: dy e5m2, w (dgrad layout [Cin][CoutP]) e4m3 -> dx bf16 (DV_ACCUM as dv_conv3d_dgrad).  The weight gradient stays
+ * on the bf16 path (dv_conv3d_wgrad on the bf16 tensors): its reduction runs over up to 4e5 rows.
+ * `d` describes the bf16 side (dtype DV_BF16, pitches of y / dx in elements); ldx / ldy of the fp8 operand are in BYTES. */
+int dv_quantize_fp8_workspace(void);            /* bytes of `workspace` for dv_quantize_fp8 */
+int dv_quantize_fp8(int32_t dtype, const void* x, int64_t M, int32_t C, int32_t ld, int32_t fmt /* 0 e4m3, 1 e5m2 */, void* q,
+                    int32_t ldq, float* scale_out, float* workspace, void* stream);
+int dv_conv3d_fwd_fp8(const dv_conv_desc* d, const void* x8, const void* w8, const float* scale_x, const float* scale_w,
+                      void* y, float* stats, void* stream);
+int dv_conv3d_dgrad_fp8(const dv_conv_desc* d, const void* dy8, const void* wd8, const float* scale_dy, const float* scale_w,
+                        void* dx, void* stream);
+
 /* master fp32 [Cout][taps][CinP] -> compute-dtype [Cin][taps][CoutP] for n_desc tensors at once */
 typedef struct dv_pack_desc {
   int64_t src_off;   /* element offset into the fp32 master arena */

@@ -544,3 +544,82 @@ def test_r50_32x224_features_against_reference_fixture(gpu, dtype):
     tol = max(3e-4, 4 * cond) if dtype == 'fp32' else 8e-2
     # (bf16, B = 1: single elements of the map are far noisier than their spatial mean -- 7.5x the pooled bound)
     assert e1 < tol and e2 < (2.5 if dtype == 'fp32' else 7.5) * tol
+
+
+def _fp8_emulated_oracle(P, x, net='r50'):
+    """what per-tensor e4m3 quantisation of the INPUTS and WEIGHTS of the bottlenecks' pointwise convs does to the oracle (fp32
+    everywhere else): the price of the number format alone"""
+    from oracle import torch_ref as O
+    o, _ = O.select_backbone(net)
+    P.procedural_init(o).train()
+
+    def qdq(t):
+        amax = t.abs().max().clamp_min(1e-30)
+        s = amax / 448.0
+        return (t / s).clamp(-448, 448).to(torch.float8_e4m3fn).float() * s
+    hooks = []
+    for name, mod in o.named_modules():
+        if isinstance(mod, torch.nn.Conv3d) and tuple(mod.kernel_size) == (1, 1, 1) and tuple(mod.stride) == (1, 1, 1) and \
+                ('.conv1' in name or '.conv3' in name):
+            def pre(m, inp):
+                m._w_keep = m.weight.data.clone()
+                m.weight.data = qdq(m.weight.data)
+                return (qdq(inp[0]),)
+
+            def post(m, inp, out):
+                m.weight.data = m._w_keep
+            hooks += [mod.register_forward_pre_hook(pre), mod.register_forward_hook(post)]
+    with torch.no_grad():
+        y = o(x)
+    for h in hooks:
+        h.remove()
+    return y, len(hooks) // 2
+
+
+def test_r50_fp8_pointwise_mode(gpu):
+    """BASELINE configs[4]: the 2D3D-ResNet-50 with its bottleneck 1x1x1 convs on the fp8 matrix cores ('fp8pw': bf16 storage,
+    e4m3 operands / fp32 accumulate in the pointwise forward, e5m2 x e4m3 in their data gradient).
+    TOLERANCE STATEMENT: pooled features within 2x of what the number formats alone do to the reference -- the oracle with
+    e4m3-quantised pointwise operands (the fp8 price) plus the bf16-storage bound of the bf16 mode (8e-2) -- and a full
+    training step that is finite and moves the loss like the bf16 mode's does."""
+    from dualvar_amd.backbone import select_backbone
+    from dualvar_amd import model as M
+    from dualvar_amd.optim import SGD
+    P = _P()
+    g = gold('backbones')
+    x = P.procedural_clips(4, 1, **CLIP)[:, 0]
+    emu, n_fp8 = _fp8_emulated_oracle(P, x)
+    e_emu = rel_err(emu.mean(dim=(2, 3, 4)).numpy(), g['r50/pooled'])
+    m, _ = select_backbone('r50')
+    P.procedural_init(m)
+    m.set_compute_dtype('fp8pw').train().to(gpu)
+    with torch.no_grad():
+        pooled = m.forward_pooled(x.to(gpu))
+    kn = [l.kname for pl in m._plans.values() for p_ in pl for l in p_.f_list]
+    assert sum('conv_gemm<fp8,FWD' in k for k in kn) == n_fp8 == 23, (sum('conv_gemm<fp8,FWD' in k for k in kn), n_fp8)
+    e = rel_err(pooled.cpu().numpy(), g['r50/pooled'])
+    print(f'r50 fp8pw: pooled rel err {e:.2e}; oracle with e4m3 pointwise operands {e_emu:.2e}; {n_fp8} fp8 GEMMs per pass')
+    assert e < 2 * e_emu + 8e-2
+    # one training step of the objective in this mode next to the bf16 one: same loss to the formats' accuracy, finite grads
+    losses = {}
+    for mode in ('bf16', 'fp8pw'):
+        torch.manual_seed(0)
+        sm = M.SimCLR_Naked('r50', 128, 0.07, False)
+        P.procedural_init(sm)
+        sm.set_compute_dtype(mode).train().to(gpu)
+        opt = SGD([p for p in sm.parameters() if p.requires_grad], lr=1e-4, momentum=0.9, weight_decay=1e-4, stores=sm.stores())
+        block = P.procedural_clips(4, 2, **CLIP).to(gpu)
+        ls = []
+        for _ in range(2):
+            ret = sm(block)
+            opt.zero_grad()
+            ret['clip_contrast_loss'].backward()
+            assert all(bool(torch.isfinite(st.grad).all()) for st in sm.stores())
+            opt.step()
+            ls.append(float(ret['clip_contrast_loss'].detach()))
+        if mode == 'fp8pw':
+            kb = [l.kname for mod in sm.modules() if hasattr(mod, '_plans') for pl in mod._plans.values() for p_ in pl for l in p_.b_list]
+            assert sum('conv_gemm<fp8,DGRAD' in k for k in kb) == 23
+        losses[mode] = ls
+    print('r50 SimCLR_Naked losses', losses)
+    assert abs(losses['fp8pw'][0] - losses['bf16'][0]) < 0.15 and abs(losses['fp8pw'][1] - losses['bf16'][1]) < 0.3

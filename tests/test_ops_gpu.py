@@ -882,3 +882,87 @@ def test_nn_retrieval_matches_the_reference_recipe(gpu):
         want = float((ytr[idx] == yte[:, None]).any(1).float().mean())
         assert abs(acc[k] - want) < 1e-6, (k, acc[k], want)
     assert 0.2 < acc[1] < 1.0 and acc[50] >= acc[1]           # a non-trivial case: neither chance nor saturated
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fp8 pointwise path (BASELINE configs[4])
+FP8_T = {0: (torch.float8_e4m3fn, 448.0), 1: (torch.float8_e5m2, 57344.0)}
+
+
+@pytest.mark.parametrize('fmt', [0, 1])
+@pytest.mark.parametrize('dtype', [DV_BF16, DV_F32])
+def test_quantize_fp8_against_torch(gpu, dtype, fmt):
+    """dv_quantize_fp8: per-tensor scale = amax / FMAX, q = fp8_rne(x / scale), byte for byte torch's OCP float8 cast"""
+    tdt = ops.TORCH_DTYPE[dtype]
+    M, Cn, ld = 700, 48, 80
+    wide = (rnd(M, ld, seed=21) * 3).to(tdt).to(gpu)
+    x = wide[:, 16:16 + Cn]                                                  # a channel slice of a wider buffer
+    q, scale = ops.quantize_fp8(x, M, Cn, ld, fmt, dtype)
+    torch.cuda.synchronize()
+    t8, fmax = FP8_T[fmt]
+    amax = float(x.float().abs().max())
+    assert abs(float(scale) - amax / fmax) <= 1e-6 * amax / fmax
+    ref = (x.float() / scale).clamp(-fmax, fmax).to(t8)
+    assert torch.equal(q.view(torch.uint8), ref.view(torch.uint8))
+    z, sz = ops.quantize_fp8(torch.zeros(64, 16, dtype=tdt, device=gpu), 64, 16, 16, fmt, dtype)     # all-zero tensor: scale 1
+    assert float(sz) == 1.0 and int(z.max()) == 0
+
+
+@pytest.mark.parametrize('case', [('pw_96_80', 3, 96, 2, 20, 25, 80), ('pw_256_64', 2, 256, 4, 14, 14, 64), ('pw_64_256', 1, 64, 8, 28, 28, 256)],
+                         ids=lambda c: c[0])
+def test_pointwise_conv_fp8_fwd_dgrad(gpu, case):
+    """dv_conv3d_fwd_fp8 / dv_conv3d_dgrad_fp8 against torch fp32 ON THE QUANTISED OPERANDS: the kernels are then exact up to
+    fp32 accumulation order and the bf16 rounding of the output -- what fp8 itself costs is priced separately, below:
+    tolerance statement of the fp8 mode = at most 2x the error e4m3 (e5m2 for gradients) rounding of the operands alone
+    causes in the fp32 product (printed)."""
+    name, N, Cin, T, H, W, Cout = case
+    x = q(rnd(N, Cin, T, H, W, seed=1).relu(), DV_BF16)
+    w = q(rnd(Cout, Cin, 1, 1, 1, seed=2, scale=Cin ** -0.5), DV_BF16)
+    gy = q(rnd(N, Cout, T, H, W, seed=3), DV_BF16)
+    xa = ops.act_from_ncdhw(x.to(gpu), DV_BF16)
+    dya = ops.act_from_ncdhw(gy.to(gpu), DV_BF16)
+    ya = ops.new_act(N, T, H, W, Cout, DV_BF16, gpu, zero=True)
+    M = xa.rows
+    assert xa.cpitch % 16 == 0 and ya.cpitch % 16 == 0
+    x8, sx = ops.quantize_fp8(xa, M, xa.cpitch, xa.ld, 0, DV_BF16)
+    wf = ops.pack_weight(w.to(gpu), xa.cpitch).to(torch.bfloat16).view(Cout, xa.cpitch)               # [Cout][CinP]
+    w8, sw = ops.quantize_fp8(wf, Cout, xa.cpitch, xa.cpitch, 0, DV_BF16)
+    d = ops.conv_desc(DV_BF16, xa, ya, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=ops.DV_STATS)
+    d.ldx = x8.stride(0)
+    tiles = ops.stat_tiles(d)
+    stats = torch.zeros(2, Cout, tiles, device=gpu)
+    ops.conv_fwd_fp8(d, x8, w8, sx, sw, ya, stats)
+    torch.cuda.synchronize()
+    xq = x8.view(torch.float8_e4m3fn).float() * sx
+    wq = w8.view(torch.float8_e4m3fn).float() * sw
+    ref = (xq @ wq.t())[:, :Cout]                                                                     # [M, Cout] fp32
+    got = ya.buf[:, :Cout].float()
+    exact = (xa.buf.float()[:, :xa.cpitch] @ wf.float().t())[:, :Cout]
+    e_kernel = float((got - ref).abs().max() / ref.abs().max())
+    e_fp8 = float((ref - exact).abs().max() / exact.abs().max())
+    print(f'{name}: fwd kernel vs fp32-on-quantised {e_kernel:.2e} (bf16 output), fp8 quantisation itself {e_fp8:.2e}')
+    assert e_kernel < 6e-3                                                                           # bf16 rounding of y
+    assert float((got - exact).abs().max() / exact.abs().max()) < 2 * e_fp8 + 6e-3
+    local = torch.zeros(2 * Cout + 1, device=gpu)
+    ops.call('dv_bn_reduce_stats', stats, tiles, ops.tile_rows(d), Cout, M, Cout, local)
+    close(local[:Cout] / M, got.mean(0), DV_F32, name + ' mean', factor=5)
+    # data gradient: dy e5m2 x w e4m3 (dgrad layout [Cin][CoutP])
+    dy8, sdy = ops.quantize_fp8(dya, M, dya.cpitch, dya.ld, 1, DV_BF16)
+    wd = torch.zeros(Cin, dya.cpitch, device=gpu, dtype=torch.bfloat16)
+    wd[:, :Cout] = w.view(Cout, Cin).t().to(gpu).to(torch.bfloat16)
+    wd8, swd = ops.quantize_fp8(wd, Cin, dya.cpitch, dya.cpitch, 0, DV_BF16)
+    dxa = xa.like()
+    dd = ops.conv_desc(DV_BF16, xa, dya, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    dd.ldy = dy8.stride(0)
+    ops.conv_dgrad_fp8(dd, dy8, wd8, sdy, swd, dxa)
+    torch.cuda.synchronize()
+    ref = ((dy8.view(torch.float8_e5m2).float() * sdy) @ (wd8.view(torch.float8_e4m3fn).float() * swd).t())[:, :Cin]
+    gotd = dxa.buf[:, :Cin].float()
+    e_k = float((gotd - ref).abs().max() / ref.abs().max())
+    print(f'{name}: dgrad kernel vs fp32-on-quantised {e_k:.2e}')
+    assert e_k < 6e-3
+    # accumulate form
+    ddacc = ops.conv_desc(DV_BF16, xa, dya, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=ops.DV_ACCUM)
+    ddacc.ldy = dy8.stride(0)
+    ops.conv_dgrad_fp8(ddacc, dy8, wd8, sdy, swd, dxa)
+    assert float((dxa.buf[:, :Cin].float() - 2 * ref).abs().max() / ref.abs().max()) < 1.5e-2
