@@ -30,9 +30,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# dense MFMA peaks (MI355X_MICROARCH.md).  fp32: the step's fp32 products run as six bf16 partial products (csrc/conv.hip: split3),
-# so the roof of ALGORITHMIC fp32 flops is the bf16 peak / 6; DUALVAR_F32_EXACT=1 (exact-f32 MFMA kernels) prices against 157.3.
-MFMA_PEAK_TF = {'bf16': 2500.0, 'fp32': 157.3 if os.environ.get('DUALVAR_F32_EXACT') == '1' else 2500.0 / 6, 'fp8pw': 2500.0}
+# dense MFMA peaks per dtype (MI355X_MICROARCH.md).  fp32 is priced against the guide's fp32 matrix peak, 157.3 TFLOP/s.  The
+# step's fp32 products actually run as six bf16 partial products on the bf16 matrix cores (csrc/conv.hip: split3), whose
+# roof for ALGORITHMIC fp32 flops is 2500 / 6 = 416.7 TFLOP/s: reported next to it as roofline.split_peak / frac_of_split_peak.
+MFMA_PEAK_TF = {'bf16': 2500.0, 'fp32': 157.3, 'fp8pw': 2500.0}
+F32_SPLIT_PEAK_TF = 2500.0 / 6
 
 
 def parse():
@@ -284,6 +286,11 @@ def run_leg(args, dtype, rank, world, distributed, dev):
     roof['isolated'] = {'avg_launch_us': round(cms / cn * 1e3, 2), 'GB/s': round(iso_bw, 1), 'TFLOP/s': round(iso_tf, 2),
                         'frac_hbm': round(iso_bw / HBM_PEAK_GBS, 4), 'frac_mfma': round(iso_tf / MFMA_PEAK_TF[dtype], 4)}
     roof['concurrent'] = bool(side_default and dominant.startswith('conv_wgrad'))
+    if dtype == 'fp32' and os.environ.get('DUALVAR_F32_EXACT') != '1':
+        roof['split_peak'] = round(F32_SPLIT_PEAK_TF, 1)
+        roof['frac_of_split_peak'] = round(tf / F32_SPLIT_PEAK_TF, 4)
+        roof['note'] = ('fp32 products = 6 bf16 MFMAs per 32x32x16 block (exact 3-way bf16 split of both operands): `peak` is the '
+                        'fp32 matrix peak of the guide, `split_peak` the bf16 dense peak / 6')
     roof.update({'traffic': traffic, 'kernel': dominant, 'launches_per_step': n // args.steps,
                  'avg_launch_us': round(avg_ms * 1e3, 2), 'share_of_kernel_time': round(csum[dominant][1] / tot_ms, 3),
                  'other_bound_frac': round(min(f_hbm, f_mfma), 4),

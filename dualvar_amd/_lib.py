@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'libdualvar_hip.so')
 
 DV_F32, DV_BF16 = 0, 1
 DV_BIAS, DV_RELU, DV_SIGMOID, DV_ACCUM, DV_STATS, DV_NO_RELU_MASK, DV_MASK_FROM_X = 1, 2, 4, 8, 16, 32, 64
+DV_W3 = 128                  # conv fwd / dgrad in DV_F32: weights pre-split in fragment order (dv_pack_w3)
 
 _ERR = {-1: 'DV_EINVAL (inconsistent shapes / unsupported parameter)',
         -2: 'DV_EALIGN (pointer or pitch misaligned)',
@@ -45,6 +46,10 @@ class BnItem(C.Structure):
                 [(n, C.c_int32) for n in ('blk_stats', 'blk_apply', 'blk_red', 'blk_bapply')])
 
 
+class W3Desc(C.Structure):
+    _fields_ = [('src_off', C.c_int64), ('dst_off', C.c_int64), ('N', C.c_int32), ('Ktot', C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('bias', C.c_void_p),
                 ('sam', C.c_int64), ('sak', C.c_int64), ('sbk', C.c_int64), ('sbn', C.c_int64), ('ldc', C.c_int64),
@@ -53,7 +58,7 @@ class GemmDesc(C.Structure):
 
 
 P, I32, I64, F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
-RETURNS_INT64 = ('dv_conv3d_wgrad_workspace',)       # everything else returns int
+RETURNS_INT64 = ('dv_conv3d_wgrad_workspace', 'dv_w3_bytes')       # everything else returns int
 CD, PD = C.POINTER(ConvDesc), C.POINTER(PoolDesc)
 
 # name -> argtypes, exactly as declared in include/dualvar_hip.h
@@ -72,6 +77,8 @@ SIGNATURES = {
     'dv_quantize_fp8': [I32, P, I64, I32, I32, I32, P, I32, P, P, P],
     'dv_conv3d_fwd_fp8': [CD, P, P, P, P, P, P, P],
     'dv_conv3d_dgrad_fp8': [CD, P, P, P, P, P, P],
+    'dv_w3_bytes': [I32, I32],
+    'dv_pack_w3': [P, P, P, P, I32, P],
     'dv_pack_dgrad_weights': [I32, P, P, P, P, I32, P],
     'dv_cast_arena': [I32, P, P, I64, P],
     'dv_ingest_ncdhw': [I32, P, P, I32, I32, I32, I32, I32, I64, I32, P, P, P, I32, P],

@@ -283,10 +283,16 @@ constexpr int conv_waves_per_simd(int es, int gvb, int bm, int bn) {
   return (es != 2 || gvb != 16) ? 1 : (bm * bn == 128 * 64) ? 6 : (bm == 128 && bn == 128) ? 3 : 1;
 }
 
-template <typename T, int MODE, int GVB, int BM, int BN, int WAVES_M, int WAVES_N, int GM, int NS = 2, bool SPLIT = false>
+// WF (fp32 split mode): the weights arrive PRE-SPLIT in fragment order (dv_pack_w3: [K tile][k half h][row][hi|mid|lo][8]
+// bf16, 48 bytes per (row, h)), so a B tile is two contiguous chunks that the DMA copies as they are and a lane's three
+// operand fragments are three conflict-free ds_read_b128 -- no vector instruction is spent on the weight operand; only
+// the activation fragments are split in the kernel (the kernel was bound by exactly those instructions).
+template <typename T, int MODE, int GVB, int BM, int BN, int WAVES_M, int WAVES_N, int GM, int NS = 2, bool SPLIT = false,
+          bool WF = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))) void conv_gemm_kernel(ConvArgs a) {
   static_assert(!SPLIT || sizeof(T) == 4, "the bf16 split is the fp32 mode's product");
+  static_assert(!WF || (SPLIT && GVB == 16), "pre-split weights belong to the fp32 split kernels");
   // DMA: 16-byte gathers go global -> LDS directly (buffer_load ... lds), no VGPR staging and no ds_write.  One wave
   // instruction fills 16 rows x 64 B = 1 KiB of a row-linear, UNPADDED tile; bank conflicts of the ds_read_b128 fragment
   // reads are avoided by XOR-swizzling the 16-byte slot with (row>>2)&3, applied on the source side (which k-slot a
@@ -306,14 +312,16 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
   static_assert(BN <= NT && BM % RPP == 0, "tile / thread layout");
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int A_G = DMA ? (BM / 16) / NW : A_PASSES;          // 16-row groups of the A tile per wave
-  constexpr int B_G = DMA ? ((BN / 16) + NW - 1) / NW : B_PASSES;
+  constexpr int BROWB = WF ? 96 : PITCH;                       // bytes of one B row in LDS (WF: hi|mid|lo of both k halves)
+  constexpr int BPC = (BN * BROWB + 1023) / 1024;              // 1 KiB DMA pieces of the B tile
+  constexpr int B_G = DMA ? (BPC + NW - 1) / NW : B_PASSES;
   static_assert(!DMA || (BM / 16) % NW == 0, "A groups per wave");
   static_assert(TM >= 1 && TN >= 1, "tile");
   typedef typename VecB<GVB>::type vec_t;
 
   static_assert(NS == 2 || GVB == 16, "deeper pipelines are DMA only");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (BM + BN) * PITCH];
-  constexpr int BUFB = (BM + BN) * PITCH;   // A tile then B tile, NS times
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (BM * PITCH + BPC * 1024)];
+  constexpr int BUFB = BM * PITCH + BPC * 1024;   // A tile then B tile, NS times
 
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x;
@@ -384,8 +392,15 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
   unsigned woff[B_G];
 #pragma unroll
   for (int p = 0; p < B_G; ++p) {
-    const int r = b_row_of(p), n = n0 + r;
-    woff[p] = (r < BN && n < a.N) ? (unsigned)n * (unsigned)a.ldw * ES : kOOB;
+    if constexpr (WF) {
+      // LDS byte o of the B region <- W3 byte (h * NPad + n0) * 48 + (o mod BN*48), h = o / (BN*48); a.ldw carries NPad
+      const unsigned o = (unsigned)(uwave + p * NW) * 1024u + (unsigned)lane * 16u;
+      const unsigned hh = o / (BN * 48u), rem = o - hh * (BN * 48u);
+      woff[p] = o < BN * 96u ? (hh * (unsigned)a.ldw + (unsigned)n0) * 48u + rem : kOOB;
+    } else {
+      const int r = b_row_of(p), n = n0 + r;
+      woff[p] = (r < BN && n < a.N) ? (unsigned)n * (unsigned)a.ldw * ES : kOOB;
+    }
   }
   // uniform-tap mode: wave-uniform K cursor (next tile to load) and per-row inverted tap masks
   int u_c0 = 0, u_tap = 0, u_dt = 0, u_dh = 0, u_dw = 0;
@@ -406,7 +421,7 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
     }
 #pragma unroll
     for (int p = 0; p < B_G; ++p)
-      if (woff[p] != kOOB) woff[p] += (unsigned)vslot * GVB;
+      if (!WF && woff[p] != kOOB) woff[p] += (unsigned)vslot * GVB;
   }
   __syncthreads();                             // taptab
 
@@ -425,8 +440,9 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
       const unsigned s_b = (unsigned)(u_otap * g.CP + u_c0) * ES;
 #pragma unroll
       for (int p = 0; p < B_G; ++p)
-        if (uwave + p * NW < BN / 16)
-          dma_load16(w_dma, smem_base + buf * BUFB + BM * PITCH + (uwave + p * NW) * 1024, woff[p] + s_b);
+        if (uwave + p * NW < BPC)
+          dma_load16(w_dma, smem_base + buf * BUFB + BM * PITCH + (uwave + p * NW) * 1024,
+                     WF ? (woff[p] == kOOB ? kOOB : woff[p] + (unsigned)kt_idx * (unsigned)a.ldw * 96u) : woff[p] + s_b);
       u_c0 += BKE;
       if (u_c0 >= g.CP) {
         u_c0 = 0;
@@ -466,9 +482,10 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
     const unsigned kb = tin ? (otap * (unsigned)g.CP + c) * ES : kOOB;      // weights sit at the original tap index
 #pragma unroll
     for (int p = 0; p < B_G; ++p) {
-      const unsigned off = (woff[p] | kb) >= kOOB ? kOOB : woff[p] + kb;
+      const unsigned off = WF ? (woff[p] == kOOB ? kOOB : woff[p] + (unsigned)kt_idx * (unsigned)a.ldw * 96u)
+                              : ((woff[p] | kb) >= kOOB ? kOOB : woff[p] + kb);
       if constexpr (DMA) {
-        if (uwave + p * NW < BN / 16)
+        if (uwave + p * NW < BPC)
           dma_load16(w_dma, smem_base + buf * BUFB + BM * PITCH + (uwave + p * NW) * 1024, off);
       } else if constexpr (GVB == 16) {
         u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off, 0, 0);
@@ -509,7 +526,16 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = split3_row(smem + buf * BUFB + (wm0 + i * 32 + l31) * PITCH, h, swz);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = split3_row(smem + buf * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, swz);
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (WF) {
+          const unsigned char* pb = smem + buf * BUFB + BM * PITCH + ((h * BN + wn0 + j * 32 + l31) * 3) * 16;
+          bf[j].hi = *reinterpret_cast<const bf16x8*>(pb);
+          bf[j].mid = *reinterpret_cast<const bf16x8*>(pb + 16);
+          bf[j].lo = *reinterpret_cast<const bf16x8*>(pb + 32);
+        } else {
+          bf[j] = split3_row(smem + buf * BUFB + (BM + wn0 + j * 32 + l31) * PITCH, h, swz);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -527,7 +553,7 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
     // pieces this wave issues per tile (the B groups may not divide evenly over the waves)
     int pieces = A_G;
 #pragma unroll
-    for (int p = 0; p < B_G; ++p) pieces += (uwave + p * NW < BN / 16) ? 1 : 0;
+    for (int p = 0; p < B_G; ++p) pieces += (uwave + p * NW < BPC) ? 1 : 0;
     constexpr int D = NS - 1;                  // prefetch distance
     for (int t = 0; t < D && t < nk; ++t) gload(t, t);
     int cur = 0, nxt = D % NS;                 // stage of tile k / of tile k + D
@@ -1297,6 +1323,41 @@ static int gather_bytes(int dtype, int cp) {
   return (cp % 8 == 0) ? 16 : 8;                    // bf16: 8 elements, or 4 for the padded RGB input
 }
 
+// ---- pre-split weights of the fp32 split mode (DV_W3) ---------------------------------------------------------------------
+static int w3_rows(int n) { return (n + 127) / 128 * 128; }                         // rows incl. padding (any tile fits)
+static int64_t w3_bytes(int n, int ktot) { return (int64_t)((ktot + 15) / 16) * 2 * w3_rows(n) * 48; }
+
+namespace {
+// one thread per (K tile, k half, row): 8 floats of W[row][kt*16 + 8h ..] -> hi | mid | lo, 48 bytes
+__global__ __launch_bounds__(256) void pack_w3_kernel(const float* __restrict__ base, unsigned char* __restrict__ out_base,
+                                                      const dv_w3_desc* __restrict__ descs, const int2* __restrict__ block_map) {
+  const int2 bm = block_map[blockIdx.x];                     // (descriptor, first unit of this block)
+  const dv_w3_desc d = descs[bm.x];
+  const int npad = (d.N + 127) / 128 * 128;
+  const long long unit = (long long)bm.y + threadIdx.x;      // unit = (kt * 2 + h) * npad + n
+  const long long units = (long long)((d.Ktot + 15) / 16) * 2 * npad;
+  if (unit >= units) return;
+  const int n = (int)(unit % npad);
+  const int kh = (int)(unit / npad), k0 = (kh >> 1) * 16 + (kh & 1) * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (n < d.N && k0 + e < d.Ktot) ? base[d.src_off + (long long)n * d.Ktot + k0 + e] : 0.f;
+  const Split3 s3 = split3(v);
+  bf16x8* o = reinterpret_cast<bf16x8*>(out_base + d.dst_off + unit * 48);
+  o[0] = s3.hi; o[1] = s3.mid; o[2] = s3.lo;
+}
+}  // namespace
+
+extern "C" int64_t dv_w3_bytes(int32_t rows, int32_t ktot) { return rows > 0 && ktot > 0 ? w3_bytes(rows, ktot) : 0; }
+
+extern "C" int dv_pack_w3(const float* base, void* out_base, const dv_w3_desc* descs, const int32_t* block_map, int32_t n_blocks,
+                          void* stream) {
+  if (!base || !out_base || !descs || !block_map || n_blocks <= 0) return DV_EINVAL;
+  hipLaunchKernelGGL(pack_w3_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, base, (unsigned char*)out_base, descs,
+                     reinterpret_cast<const int2*>(block_map));
+  return dv_launch_status();
+}
+
 static bool f32_exact() {
   static const bool v = getenv("DUALVAR_F32_EXACT") && atoi(getenv("DUALVAR_F32_EXACT")) != 0;
   return v;
@@ -1331,8 +1392,18 @@ static void pick_tile(int dtype, int M, int NP, int& bm, int& bn) {
   if (dtype == DV_F32 && !f32_exact() && big && bm == 128 && bn == 64 && (int64_t)((M + 255) / 256) * ntn >= 512) bm = 256;
 }
 
-template <typename T, int MODE, int GVB, int GM, int NS, bool SPLIT = false>
+template <typename T, int MODE, int GVB, int GM, int NS, bool SPLIT = false, bool WF = false>
 static void launch_gemm_ns(int bm, int bn, const ConvArgs& a, int grid, hipStream_t s) {
+  if constexpr (WF) {       // pre-split weights: the instantiations the fp32 split mode uses
+    if (bm == 256) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 256, 64, 4, 1, GM, NS, true, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (bm == 64 && bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 32, 2, 1, GM, NS, true, true>), dim3(grid), dim3(128), 0, s, a);
+    else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 64, 2, 2, GM, NS, true, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (bm == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 128, 2, 2, GM, NS, true, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 32, 4, 1, GM, NS, true, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 64, 4, 1, GM, NS, true, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 128, 128, 2, 2, GM, NS, true, true>), dim3(grid), dim3(256), 0, s, a);
+    return;
+  }
   if constexpr (SPLIT) {
     if (bm == 256) {
       hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 256, 64, 4, 1, GM, NS, SPLIT>), dim3(grid), dim3(256), 0, s, a);
@@ -1371,19 +1442,27 @@ static void launch_gemm_gm(int bm, int bn, const ConvArgs& a, int grid, hipStrea
     }
   }
   if constexpr (sizeof(T) == 4) {
-    if (!f32_exact()) {
-      launch_gemm_ns<T, MODE, GVB, GM, 2, true>(bm, bn, a, grid, s);
+    if constexpr (GM == 1) {                     // (only the pre-split-weight kernels are built with uniform-tap gathers)
+      launch_gemm_ns<T, MODE, GVB, 1, 2, true, true>(bm, bn, a, grid, s);
       return;
+    } else {
+      if (!f32_exact()) {
+        if (a.flags & DV_W3) launch_gemm_ns<T, MODE, GVB, 0, 2, true, true>(bm, bn, a, grid, s);
+        else launch_gemm_ns<T, MODE, GVB, 0, 2, true>(bm, bn, a, grid, s);
+        return;
+      }
     }
   }
-  launch_gemm_ns<T, MODE, GVB, GM, 2>(bm, bn, a, grid, s);
+  if constexpr (sizeof(T) != 4 || GM == 0) launch_gemm_ns<T, MODE, GVB, GM, 2>(bm, bn, a, grid, s);
 }
 
 template <typename T, int MODE, int GVB>
 static void launch_gemm(int bm, int bn, const ConvArgs& a, int grid, hipStream_t s) {
-  if constexpr (GVB == 16 && sizeof(T) == 2) {
-    // uniform-tap gathers: every 32-element K-step inside one tap, tap bit mask in one register
-    if (a.g.CP % 32 == 0 && a.g.kt * a.g.kh * a.g.kw <= 32) {
+  if constexpr (GVB == 16 && (sizeof(T) == 2 || sizeof(T) == 4)) {
+    // uniform-tap gathers: every K-step (64 bytes: 32 bf16 / 16 f32) inside one tap, tap bit mask in one register.
+    // f32: for the pre-split-weight kernels (the fp32 split mode's hot path; its K loop is bound by vector instructions)
+    constexpr int BKE_ = 64 / (int)sizeof(T);
+    if (a.g.CP % BKE_ == 0 && a.g.kt * a.g.kh * a.g.kw <= 32 && (sizeof(T) == 2 || ((a.flags & DV_W3) && !f32_exact()))) {
       launch_gemm_gm<T, MODE, GVB, 1>(bm, bn, a, grid, s);
       return;
     }
@@ -1437,11 +1516,14 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   a.N = d->Cout; a.NP = d->cout_pitch;
   a.lds_ = d->ldx; a.ldo = d->ldy; a.ldw = a.g.Ktot;
   a.flags = d->flags & (DV_BIAS | DV_RELU | DV_SIGMOID | DV_STATS);
+  const bool w3 = (d->flags & DV_W3) != 0;
+  if (w3 && (d->dtype != DV_F32 || f32_exact())) return DV_EUNSUPPORTED;
+  if (w3) { a.flags |= DV_W3; a.ldw = w3_rows(d->Cout); }
   a.cls_on = 0;
   {
     const int64_t es = d->dtype == DV_F32 ? 4 : 2;
     const int64_t sb = ((int64_t)d->N * d->Ti * d->Hi * d->Wi - 1) * d->ldx * es + (int64_t)d->cin_pitch * es;
-    const int64_t wb = (int64_t)d->Cout * a.g.Ktot * es;
+    const int64_t wb = w3 ? w3_bytes(d->Cout, a.g.Ktot) : (int64_t)d->Cout * a.g.Ktot * es;
     if (sb >= (1ll << 31) || wb >= (1ll << 31) || d->kt > 32 || d->kh > 32 || d->kw > 32 || d->kt * d->kh * d->kw > 256)
       return DV_EUNSUPPORTED;
     a.src_bytes = (int)sb; a.w_bytes = (int)wb;
@@ -1547,10 +1629,13 @@ extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void
   a.N = d->Cin; a.NP = d->cin_pitch;
   a.lds_ = d->ldy; a.ldo = d->ldx; a.ldw = a.g.Ktot;
   a.flags = d->flags & DV_ACCUM;
+  const bool w3 = (d->flags & DV_W3) != 0;
+  if (w3 && (d->dtype != DV_F32 || f32_exact() || d->st > 1 || d->sh > 1 || d->sw > 1)) return DV_EUNSUPPORTED;
+  if (w3) { a.flags |= DV_W3; a.ldw = w3_rows(d->Cin); }
   {
     const int64_t es = d->dtype == DV_F32 ? 4 : 2;
     const int64_t sb = ((int64_t)d->N * d->To * d->Ho * d->Wo - 1) * d->ldy * es + (int64_t)d->cout_pitch * es;
-    const int64_t wb = (int64_t)d->Cin * a.g.Ktot * es;
+    const int64_t wb = w3 ? w3_bytes(d->Cin, a.g.Ktot) : (int64_t)d->Cin * a.g.Ktot * es;
     if (sb >= (1ll << 31) || wb >= (1ll << 31) || d->kt > 32 || d->kh > 32 || d->kw > 32 || d->kt * d->kh * d->kw > 256)
       return DV_EUNSUPPORTED;
     a.src_bytes = (int)sb; a.w_bytes = (int)wb;

@@ -44,7 +44,7 @@ FUSE_BN_POOL = os.environ.get('DUALVAR_FUSE_BN_POOL', '1') != '0'
 
 class Slot:
     __slots__ = ('tensor', 'kind', 'off', 'size', 'Cout', 'Cin', 'taps', 'cin_pitch', 'cout_pitch', 'wd_off',
-                 'shape', 'strides', 'parts', 'kw_store')
+                 'shape', 'strides', 'parts', 'kw_store', 'w3_off', 'wd3_off')
 
 
 class ParamStore:
@@ -183,6 +183,7 @@ class ParamStore:
         self.master, self.grad, self.dtype = master, grad, dtype
         self.cc = master if dtype == DV_F32 else torch.zeros(off, dtype=torch.bfloat16, device=device)
         self.wd = torch.zeros(max(wd_off, 8), dtype=ops.TORCH_DTYPE[dtype], device=device)
+        self._w3_setup(device, dtype)
         # pack descriptors (device copies)
         packs = [s for s in self.slots + self.merged if s.kind in ('conv', 'merged') and s.wd_off >= 0]
         self._n_pack_blocks = 0
@@ -275,10 +276,46 @@ class ParamStore:
         if self._n_pack_blocks:
             ops.call('dv_pack_dgrad_weights', self.dtype, self.master, self.wd, self._pack_descs, self._pack_map,
                      self._n_pack_blocks)
+        self._refresh_w3()
         self._refresh_fp8()
         self._dirty = False
         self._cast_done = False
         self._versions = self._version_sum()
+
+    # ---- fp32 mode: weights pre-split into three bf16 in fragment order (include/dualvar_hip.h: dv_pack_w3, DV_W3)
+    def _w3_setup(self, device, dtype):
+        self.w3 = self.wd3 = None
+        self._w3_jobs = []
+        for s_ in self.slots + self.merged:
+            s_.w3_off = s_.wd3_off = -1
+        if dtype != DV_F32 or os.environ.get('DUALVAR_F32_EXACT') == '1' or os.environ.get('DUALVAR_F32_W3', '1') == '0':
+            return
+        lib = L.load()
+        convs = [s_ for s_ in self.slots + self.merged if s_.kind in ('conv', 'merged')]
+
+        def table(rows_k, src_of, attr):
+            arr, bmap, off = (L.W3Desc * len(rows_k))(), [], 0
+            for i, (s_, rows, ktot) in enumerate(rows_k):
+                setattr(s_, attr, off)
+                arr[i].src_off, arr[i].dst_off, arr[i].N, arr[i].Ktot = src_of(s_), off, rows, ktot
+                nbytes = int(lib.dv_w3_bytes(rows, ktot))
+                bmap += [(i, u) for u in range(0, nbytes // 48, 256)]
+                off += nbytes
+            return (torch.zeros(max(off, 16), dtype=torch.uint8, device=device),
+                    torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device),
+                    torch.tensor(bmap, dtype=torch.int32).to(device), len(bmap))
+        fwd = [(s_, s_.Cout, s_.taps * s_.cin_pitch) for s_ in convs]
+        self.w3, d1, m1, n1 = table(fwd, lambda s_: s_.off, 'w3_off')
+        self._w3_jobs.append(('master', self.w3, d1, m1, n1))
+        bwd = [(s_, s_.Cin, s_.taps * s_.cout_pitch) for s_ in convs if s_.wd_off >= 0]
+        if bwd:
+            self.wd3, d2, m2, n2 = table(bwd, lambda s_: s_.wd_off, 'wd3_off')
+            self._w3_jobs.append(('wd', self.wd3, d2, m2, n2))
+
+    def _refresh_w3(self):
+        for src, out, descs, bmap, n in getattr(self, '_w3_jobs', ()):
+            base = self.master if src == 'master' else self.wd
+            ops.call('dv_pack_w3', base, out, descs, bmap, n)
 
     def fp8_weights(self, s):
         """(w8 [Cout][CinP] e4m3, scale, wd8 [Cin][CoutP] e4m3, scale) of a 1x1x1 conv slot for the fp8 pointwise path; the
@@ -309,7 +346,10 @@ class ParamStore:
 
     # pointers
     def w_fwd(self, s):
-        return self.cc.data_ptr() + s.off * ops.ESIZE[self.dtype]
+        """-> (pointer, extra conv flags): the forward-layout weights of a slot for dv_conv3d_fwd"""
+        if getattr(s, 'w3_off', -1) is not None and getattr(s, 'w3_off', -1) >= 0 and self.w3 is not None:
+            return self.w3.data_ptr() + s.w3_off, L.DV_W3
+        return self.cc.data_ptr() + s.off * ops.ESIZE[self.dtype], 0
 
     def w_master(self, s):
         return self.master.data_ptr() + s.off * 4
@@ -317,8 +357,11 @@ class ParamStore:
     def w_grad(self, s):
         return self.grad.data_ptr() + s.off * 4
 
-    def w_dgrad(self, s):
-        return self.wd.data_ptr() + s.wd_off * ops.ESIZE[self.dtype]
+    def w_dgrad(self, s, strided=False):
+        """-> (pointer, extra conv flags) for dv_conv3d_dgrad (the pre-split form serves stride-1 problems only)"""
+        if not strided and getattr(s, 'wd3_off', -1) is not None and getattr(s, 'wd3_off', -1) >= 0 and self.wd3 is not None:
+            return self.wd3.data_ptr() + s.wd3_off, L.DV_W3
+        return self.wd.data_ptr() + s.wd_off * ops.ESIZE[self.dtype], 0
 
     def bump_bn_counters(self):
         if self.nbt:
@@ -700,7 +743,8 @@ class ConvOp(Op):
         self.y = out if out is not None else plan.act(x.N, To, Ho, Wo, slot.Cout)
         assert x.cpitch == slot.cin_pitch, (x.cpitch, slot.cin_pitch)
         stats = stats and plan.training              # eval-mode BatchNorm needs no batch statistics
-        self.d = ops.conv_desc(self.dtype, x, self.y, k, s, p, flags=DV_STATS if stats else 0)
+        self._wf, wflag = plan.store.w_fwd(slot)
+        self.d = ops.conv_desc(self.dtype, x, self.y, k, s, p, flags=(DV_STATS if stats else 0) | wflag)
         self.tiles = ops.stat_tiles(self.d)
         self.tile_rows = ops.tile_rows(self.d)
         self.stats = plan.f32(2, slot.Cout, self.tiles) if stats else None
@@ -726,7 +770,7 @@ class ConvOp(Op):
         kf = 'conv_gemm<%s,FWD,%d,%d,%d>' % ((_dt(self.dtype), gv) + _tile_shape(lib, self.d, 0))
         shp = 'M%d Cin%d Cout%d k%s s%s' % (y.rows, sl.Cin, sl.Cout, 'x'.join(map(str, self.k)), 'x'.join(map(str, self.s)))
         f = [Launch('conv_fwd', kf, lib.dv_conv3d_fwd,
-                    (C.byref(self.d), x.ptr, st.w_fwd(sl), 0, y.ptr, self.stats.data_ptr() if self.stats is not None else 0),
+                    (C.byref(self.d), x.ptr, self._wf, 0, y.ptr, self.stats.data_ptr() if self.stats is not None else 0),
                     _abytes(x) + wbytes + _abytes(y), flops, shp)]
         if self.fp8:
             f = self._fp8_forward(shp, flops, wbytes)
@@ -750,9 +794,10 @@ class ConvOp(Op):
                 b += self._fp8_dgrad(shp, flops, wbytes)
             elif self.need_dx:
                 acc = bool(self.acc.get('x'))
-                self.d_g = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=DV_ACCUM if acc else 0)
+                wdp, wdflag = st.w_dgrad(sl, strided=max(self.s) > 1)
+                self.d_g = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=(DV_ACCUM if acc else 0) | wdflag)
                 b.append(Launch('conv_dgrad', 'conv_gemm<%s,DGRAD,16,%d,%d>' % ((_dt(self.dtype),) + _tile_shape(lib, self.d_g, 1)),
-                                lib.dv_conv3d_dgrad, (C.byref(self.d_g), y.grad.ptr, st.w_dgrad(sl), x.grad.ptr),
+                                lib.dv_conv3d_dgrad, (C.byref(self.d_g), y.grad.ptr, wdp, x.grad.ptr),
                                 _abytes(y) + wbytes + _abytes(x) * (2 if acc else 1), flops, shp))
         return f, b
 

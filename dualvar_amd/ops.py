@@ -128,6 +128,20 @@ def conv_dgrad_fp8(d, dy8, wd8, sdy, sw, dx):
     L.check(L.load().dv_conv3d_dgrad_fp8(C.byref(d), _p(dy8), _p(wd8), _p(sdy), _p(sw), _p(dx), stream_ptr()), 'dv_conv3d_dgrad_fp8')
 
 
+def pack_w3(w):
+    """fp32 [rows, Ktot] (contiguous) -> the pre-split fragment-order copy dv_conv3d_fwd / dgrad take with DV_W3 (uint8 tensor)"""
+    lib = L.load()
+    rows, ktot = w.shape
+    nbytes = int(lib.dv_w3_bytes(rows, ktot))
+    out = torch.zeros(nbytes, dtype=torch.uint8, device=w.device)
+    d = (L.W3Desc * 1)()
+    d[0].src_off, d[0].dst_off, d[0].N, d[0].Ktot = 0, 0, rows, ktot
+    descs = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8).to(w.device)
+    bmap = torch.tensor([(0, u) for u in range(0, nbytes // 48, 256)], dtype=torch.int32, device=w.device)
+    call('dv_pack_w3', w.contiguous(), out, descs, bmap, bmap.shape[0])
+    return out
+
+
 def stat_tiles(d):
     return L.load().dv_conv3d_stat_tiles(C.byref(d))
 

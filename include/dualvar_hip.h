@@ -51,8 +51,9 @@ enum {
   DV_ACCUM = 8,        /* out += result (dgrad into a shared input)       */
   DV_STATS = 16,       /* conv fwd: also emit per-tile BatchNorm partials */
   DV_NO_RELU_MASK = 32, /* bn backward: activation was identity            */
-  DV_MASK_FROM_X = 64   /* bn backward (multi-tensor forms, no residual): recompute the ReLU mask from x with the item's
+  DV_MASK_FROM_X = 64,  /* bn backward (multi-tensor forms, no residual): recompute the ReLU mask from x with the item's
                            scale / shift -- relu(x*scale+shift) exactly as the forward -- instead of reading y */
+  DV_W3 = 128           /* conv fwd / stride-1 dgrad, DV_F32: the weight pointer is the PRE-SPLIT layout of dv_pack_w3 */
 };
 
 int dv_abi_version(void);
@@ -124,6 +125,23 @@ int dv_conv3d_fwd_fp8(const dv_conv_desc* d, const void* x8, const void* w8, con
                       void* y, float* stats, void* stream);
 int dv_conv3d_dgrad_fp8(const dv_conv_desc* d, const void* dy8, const void* wd8, const float* scale_dy, const float* scale_w,
                         void* dx, void* stream);
+
+/* ---- fp32 products on the bf16 matrix cores.  gfx950 has no TF32 path and its f32-input MFMA runs at 1/16 of the bf16 rate,
+ * so DV_F32 convolutions split every fp32 operand EXACTLY into three bf16 (hi + mid + lo, 8 significant bits each) and
+ * accumulate the six partial products of weight >= 2^-16 in fp32 (error at fp32 rounding level; DUALVAR_F32_EXACT=1 in the
+ * environment selects exact-f32 MFMA kernels instead).  Activations are split inside the kernels; the WEIGHTS can be handed
+ * over already split and in fragment order (flag DV_W3 on dv_conv3d_fwd / stride-1 dv_conv3d_dgrad), made by dv_pack_w3 for
+ * many tensors in one launch: [K tile of 16][k half][rows padded to 128][hi|mid|lo][8] bf16 = dv_w3_bytes(rows, Ktot) bytes
+ * per tensor (rows = Cout of the forward layout [Cout][Ktot], Cin of the dgrad layout [Cin][Ktot]). */
+typedef struct dv_w3_desc {
+  int64_t src_off;   /* element offset of the fp32 [rows][Ktot] tensor from `base` */
+  int64_t dst_off;   /* BYTE offset of its split copy from `out_base` (multiple of 16) */
+  int32_t N, Ktot;   /* rows, K */
+} dv_w3_desc;
+int64_t dv_w3_bytes(int32_t rows, int32_t ktot);
+/* block_map (device): [n_blocks][2] = (descriptor, first 48-byte unit of the block); a block converts 256 units */
+int dv_pack_w3(const float* base, void* out_base, const dv_w3_desc* descs /*device*/, const int32_t* block_map /*device*/,
+               int32_t n_blocks, void* stream);
 
 /* master fp32 [Cout][taps][CinP] -> compute-dtype [Cin][taps][CoutP] for n_desc tensors at once */
 typedef struct dv_pack_desc {

@@ -133,6 +133,19 @@ def test_conv_fwd_dgrad_wgrad(gpu, dtype, case):
     close(local[Cout:2 * Cout] / M, var_ref, DV_F32, name + ' var', factor=20)
     assert float(local[2 * Cout]) == M
 
+    if dtype == DV_F32:
+        # the same forward with the weights handed over pre-split in fragment order (DV_W3, dv_pack_w3): the engine's fp32 path
+        from dualvar_amd._lib import DV_W3
+        wide3 = ops.new_act(N, To, Ho, Wo, ops.cp8(Cout) + 16, dtype, gpu, zero=True)
+        y3 = wide3.slice(8, Cout)
+        d3 = ops.conv_desc(dtype, xa, y3, k, s, p, flags=ops.DV_STATS | DV_W3)
+        stats3 = torch.zeros(2, Cout, tiles, device=gpu)
+        ops.conv_fwd(d3, xa, ops.pack_w3(wp.view(Cout, -1)), None, y3, stats3)
+        torch.cuda.synchronize()
+        close(ops.act_to_ncdhw(y3), yr, dtype, name + ' fwd (pre-split weights)')
+        assert float((ops.act_to_ncdhw(y3) - ops.act_to_ncdhw(ya)).abs().max()) <= 2e-6 * float(yr.abs().max())
+        assert torch.allclose(stats3, stats, rtol=1e-4, atol=1e-5)
+
     # wgrad
     dya = ops.act_from_ncdhw(gy.to(gpu), dtype)
     d2 = ops.conv_desc(dtype, xa, dya, k, s, p)
@@ -156,6 +169,11 @@ def test_conv_fwd_dgrad_wgrad(gpu, dtype, case):
         d3 = ops.conv_desc(dtype, xa, dya, k, s, p, flags=ops.DV_ACCUM)
         ops.conv_dgrad(d3, dya, wd, dxa)
         close(ops.act_to_ncdhw(dxa), 2 * xr.grad, dtype, name + ' dgrad accum', factor=2)
+        if dtype == DV_F32 and max(s) == 1:
+            from dualvar_amd._lib import DV_W3
+            dx3 = ops.new_act(N, T, H, W, Cin, dtype, gpu, zero=True)
+            ops.conv_dgrad(ops.conv_desc(dtype, xa, dya, k, s, p, flags=DV_W3), dya, ops.pack_w3(wd.view(Cin, -1)), dx3)
+            close(ops.act_to_ncdhw(dx3), xr.grad, dtype, name + ' dgrad (pre-split weights)')
 
 
 def test_pack_dgrad_and_cast(gpu):

@@ -17,32 +17,44 @@ import re
 import sys
 
 
+def _dt(n):
+    """element type of a kernel instantiation from its (mangled or demangled) name"""
+    if re.search(r'fp8e4_t', n):
+        return 'fp8'
+    if re.search(r'fp8e5_t', n):
+        return 'fp8'
+    if re.search(r'IDF16b|<__bf16|<bf16|bool _Accum', n):          # (rocprof's demangler garbles <__bf16, ...>)
+        return 'bf16'
+    return 'f32'
+
+
 def short(name):
     """map a (mangled or rocprof-demangled) kernel name to the label dualvar_amd.engine gives the launch"""
     n = name
-    m = re.search(r'conv_wgrad_dma_kernelILi(\d+)ELi(\d+)E', n) or re.search(r'conv_wgrad_dma_kernel<(\d+), (\d+)(?:, \d+)?>', n)
+    m = re.search(r'conv_wgrad_dma_kernelI(?:DF16b|f)Li(\d+)ELi(\d+)E', n) or re.search(r'conv_wgrad_dma_kernel<[^,]+, (\d+), (\d+)', n)
     if m:
-        return 'conv_wgrad<bf16,16,%s,%s>' % m.groups()[:2]
-    m = re.search(r'conv_wgrad_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)E', n)
+        return 'conv_wgrad<%s,16,%s,%s>' % (_dt(n), m.group(1), m.group(2))
+    m = re.search(r'conv_wgrad_kernelI(?:DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)E', n) or re.search(r'conv_wgrad_kernel<[^,]+, (\d+), (\d+), (\d+)', n)
     if m:
-        return 'conv_wgrad<%s,%s,%s,%s>' % ((('bf16' if m.group(1) == 'DF16b' else 'f32'),) + m.groups()[1:])
-    m = re.search(r'conv_gemm_kernelI(DF16b|f)Li(\d)ELi(\d+)ELi(\d+)ELi(\d+)E', n)
+        return 'conv_wgrad<%s,%s,%s,%s>' % ((_dt(n),) + m.groups())
+    m = re.search(r'conv_gemm_kernelI(?:DF16b|f|\d+fp8e\d_t)Li(\d)ELi(\d+)ELi(\d+)ELi(\d+)E', n) or \
+        re.search(r'conv_gemm_kernel<[^,]+, (\d), (\d+), (\d+), (\d+)', n) or \
+        re.search(r'conv_gemm_kernel<bool _Accum, int, E, (\d+), (\d+), (\d+)', n)
     if m:
-        return 'conv_gemm<%s,%s,%s,%s,%s>' % ('bf16' if m.group(1) == 'DF16b' else 'f32', 'DGRAD' if m.group(2) == '1' else 'FWD',
-                                             m.group(3), m.group(4), m.group(5))
-    m = re.search(r'conv_gemm_kernel<bool _Accum, int, E, (\d+), (\d+), (\d+)', n)      # rocprof's demangler on <__bf16, 1, ...>
-    if m:
-        return 'conv_gemm<bf16,DGRAD,%s,%s,%s>' % m.groups()
-    m = re.search(r'conv_gemm_kernel<float, (\d), (\d+), (\d+), (\d+)', n)
-    if m:
-        return 'conv_gemm<f32,%s,%s,%s,%s>' % ((('DGRAD' if m.group(1) == '1' else 'FWD'),) + m.groups()[1:])
-    for key, pat in (('bn_bwd_reduce_multi<bf16>', r'bn_bwd_reduce_multi'), ('bn_bwd_apply_multi<bf16>', r'bn_bwd_apply_multi'),
-                     ('bn_apply_multi<bf16>', r'bn_apply_multi'), ('bn_stats_multi', r'bn_stats_multi'),
-                     ('bn_bwd_reduce<bf16>', r'bn_bwd_reduce_kernel'), ('bn_bwd_apply<bf16>', r'bn_bwd_apply_kernel'),
-                     ('bn_apply<bf16>', r'bn_apply_kernel'), ('maxpool_fwd<bf16>', r'maxpool(333)?_fwd'),
-                     ('maxpool_bwd<bf16>', r'maxpool_bwd')):
+        g = m.groups()
+        if len(g) == 3:                                             # garbled bf16 dgrad form
+            g = ('1',) + g
+        return 'conv_gemm<%s,%s,%s,%s,%s>' % (_dt(n), 'DGRAD' if g[0] == '1' else 'FWD', g[1], g[2], g[3])
+    for key, pat in (('bn_bwd_reduce_multi', r'bn_bwd_reduce_multi'), ('bn_bwd_apply_multi', r'bn_bwd_apply_multi'),
+                     ('bn_apply_multi', r'bn_apply_multi'), ('bn_bwd_reduce', r'bn_bwd_reduce_kernel'),
+                     ('bn_bwd_apply', r'bn_bwd_apply_kernel'), ('bn_apply_maxpool', r'bn_apply_maxpool'), ('bn_apply', r'bn_apply_kernel'),
+                     ('maxpool_fwd', r'maxpool(333)?_fwd'), ('maxpool_bwd', r'maxpool_bwd')):
         if re.search(pat, n):
-            return key
+            return '%s<%s>' % (key, _dt(n))
+    if re.search(r'bn_stats_multi', n):
+        return 'bn_stats_multi'
+    if re.search(r'wgrad_reduce_kernel', n):
+        return 'wgrad_reduce'
     return None
 
 
