@@ -25,4 +25,4 @@ for DT in fp32 bf16; do
   find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
   rm -rf $O/pmc_f $O/pmc_w $O/stats
 done
-tail -c 600 $OUT/bench_full.log
+grep -h "^{\"metric" $OUT/bench_full.log | tail -c 600
