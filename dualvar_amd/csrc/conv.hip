@@ -15,6 +15,7 @@
 // both share the 32x32 C/D layout  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include "common.hpp"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace {
@@ -621,78 +622,71 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
       st_s2[j] = fmaf(d, d, st_s2[j]);
     }
   };
-  if constexpr (sizeof(OT) == 2) {
-    // bf16: each wave stages a 32-row strip of its tile in LDS ([row][col], 2-byte writes at immediate offsets) and
-    // writes it out as 16-byte vectors, eight lanes per 128-byte row segment -- instead of one 2-byte global store and
-    // a 64-bit address computation per element (the old epilogue was ~1/3 of all instructions a workgroup issued).
-    constexpr int SP = WN * 2 + 16;                  // staging row pitch (bytes)
-    constexpr int STG = 32 * SP;
-    constexpr int CPR = WN / 8;                      // 16-byte chunks per strip row
-    static_assert(NW * STG <= (int)sizeof(smem), "staging fits the tile buffers");
+  {
+    // Each wave stages a strip of its tile in LDS ([row][col], element writes at immediate offsets) and writes it out as
+    // 16-byte vectors, a row segment per group of lanes -- instead of one element store and a 64-bit address computation per
+    // element (the per-element form was ~1/3 of all instructions of the bf16 kernel, and for f32 -- 64 dword stores, 64
+    // address chains and the row-mapping divisions per lane -- more than the K loop of the 1x1x1 layers).
+    constexpr int EO = (int)sizeof(OT);
+    constexpr int SP = WN * EO + 16;                 // staging row pitch (bytes)
+    constexpr int CPR = WN * EO / 16;                // 16-byte chunks per strip row
+    constexpr int EPC = 16 / EO;                     // elements per chunk
+    constexpr int SROWS = (NW * 32 * SP <= (int)sizeof(smem)) ? 32 : 16;   // strip height that fits the tile buffers
+    static_assert(NW * SROWS * SP <= (int)sizeof(smem), "staging fits the tile buffers");
+    constexpr int RPS = SROWS / 2;                   // accumulator registers per strip (16 cover 32 rows)
     __syncthreads();                                 // every wave is done reading the last K tile
-    unsigned char* stg = smem + wave * STG;
-    const bool plain = !(flags & (DV_BIAS | DV_RELU | DV_SIGMOID));
+    unsigned char* stg = smem + wave * (SROWS * SP);
+    const bool plain = EO == 2 && !(flags & (DV_BIAS | DV_RELU | DV_SIGMOID));
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn0 + j * 32 + l31;
-        const float bv = ((flags & DV_BIAS) && col < a.N) ? a.bias[col] : 0.f;
+      for (int sub = 0; sub < 32 / SROWS; ++sub) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-          float v = acc[i][j][r];
-          if (!plain) {                              // (plain: rows >= M and columns >= N are exact zeros already)
-            v = act_apply(v + bv, flags);
-            if (col >= a.N || m0 + wm0 + i * 32 + rl >= a.M) v = 0.f;
+        for (int j = 0; j < TN; ++j) {
+          const int col = n0 + wn0 + j * 32 + l31;
+          const float bv = ((flags & DV_BIAS) && col < a.N) ? a.bias[col] : 0.f;
+#pragma unroll
+          for (int rr = 0; rr < RPS; ++rr) {
+            const int r = sub * RPS + rr;
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;          // row inside the 32-row block
+            float v = acc[i][j][r];
+            if (!plain) {                            // (plain: rows >= M and columns >= N are exact zeros already)
+              v = act_apply(v + bv, flags);
+              if (col >= a.N || m0 + wm0 + i * 32 + rl >= a.M) v = 0.f;
+            }
+            const OT tv = DT<OT>::from_f(v);
+            *reinterpret_cast<OT*>(stg + (rl - sub * SROWS) * SP + (j * 32 + l31) * EO) = tv;
+            if constexpr (EO == 2) {
+              if (do_stats) stat_acc(i, j, r, DT<OT>::to_f(tv), rl);
+            } else {
+              acc[i][j][r] = v;                      // as stored (0 outside the valid region): feeds the two-pass statistics
+            }
           }
-          const OT tv = DT<OT>::from_f(v);
-          *reinterpret_cast<OT*>(stg + rl * SP + (j * 32 + l31) * 2) = tv;
-          if (do_stats) stat_acc(i, j, r, DT<OT>::to_f(tv), rl);
         }
-      }
 #pragma unroll
-      for (int it = 0; it < (32 * CPR) / 64; ++it) {
-        const int idx = it * 64 + lane;
-        const int rl = idx / CPR, ch = idx % CPR;
-        const int row = m0 + wm0 + i * 32 + rl, col0 = n0 + wn0 + ch * 8;
-        if (row < a.M && col0 < a.NP) {
-          bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + rl * SP + ch * 16);
-          OT* p = out + out_row(row) * a.ldo + col0;
-          if (flags & DV_ACCUM) {
-            const bf16x8 o = *reinterpret_cast<const bf16x8*>(p);
+        for (int it = 0; it < (SROWS * CPR) / 64; ++it) {
+          const int idx = it * 64 + lane;
+          const int rl = idx / CPR, ch = idx % CPR;
+          const int row = m0 + wm0 + i * 32 + sub * SROWS + rl, col0 = n0 + wn0 + ch * EPC;
+          if (row < a.M && col0 < a.NP) {
+            OT* p = out + out_row(row) * a.ldo + col0;
+            if constexpr (EO == 2) {
+              bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + rl * SP + ch * 16);
+              if (flags & DV_ACCUM) {
+                const bf16x8 o = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)o[e]);
+                for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)o[e]);
+              }
+              *reinterpret_cast<bf16x8*>(p) = v;
+            } else {
+              f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * SP + ch * 16);
+              if (flags & DV_ACCUM) v += *reinterpret_cast<const f32x4*>(p);
+              *reinterpret_cast<f32x4*>(p) = v;
+            }
           }
-          *reinterpret_cast<bf16x8*>(p) = v;
         }
       }
     }
-  } else {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn0 + j * 32 + l31;
-        const float bv = ((flags & DV_BIAS) && col < a.N) ? a.bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int row = m0 + wm0 + i * 32 + rl;
-          float v = act_apply(acc[i][j][r] + bv, flags);
-          if (col >= a.N) v = 0.f;
-          if (row < a.M && col < a.NP) {
-            OT* p = out + out_row(row) * a.ldo + col;
-            if (flags & DV_ACCUM) v += DT<OT>::to_f(*p);
-            OT tv = DT<OT>::from_f(v);
-            *p = tv;
-            v = DT<OT>::to_f(tv);
-          } else {
-            v = 0.f;
-          }
-          acc[i][j][r] = v;   // as stored (0 outside the valid region): feeds the two-pass statistics below
-        }
-      }
   }
 
   if constexpr (STATS_MODE && sizeof(T) == 4) {
@@ -1759,6 +1753,17 @@ static WgradPlan plan_wgrad(const dv_conv_desc* d) {
   int splits = tgt / tiles;                          // round down: never more workgroups than fit at once
   const int max_splits = (M + minrows - 1) / minrows;
   if (splits > max_splits) splits = max_splits;
+  // ... and not more than pays: every split writes (and the reduce re-reads) a whole partial dW.  With S splits a workgroup
+  // runs M/(32 S) steps of ~t_step and the slabs cost 2 S |W| 4 bytes at ~4 TB/s: the sum is least at
+  // S = sqrt(M/32 * t_step / (8 |W| / 4e6 us)).  (Layers with few rows and a large dW -- Mixed_4/5 -- had slab traffic of
+  // 3x their operands.)
+  {
+    static const int no_opt = env_int("DUALVAR_WGRAD_NO_SPLIT_MODEL", 0);
+    const double t_step = d->dtype == DV_F32 ? 1.5 : 0.7;                        // us per 32-row step of one workgroup
+    const double slab_us = 8.0 * d->Cout * (double)J / 4e6;
+    const int s_opt = (int)(std::sqrt(M / 32.0 * t_step / slab_us) + 0.5);
+    if (!no_opt && splits > s_opt) splits = s_opt;
+  }
   if (splits < 1) splits = 1;
   p.rows_per_split = ((M + splits - 1) / splits + 31) / 32 * 32;
   p.splits = (M + p.rows_per_split - 1) / p.rows_per_split;

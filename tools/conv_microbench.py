@@ -55,6 +55,7 @@ def main():
     ap.add_argument('--passes', default='fwd,dgrad,wgrad')
     ap.add_argument('--no-stats', action='store_true', help='forward without the fused BatchNorm partials')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--w3', action='store_true', help='fp32: weights pre-split in fragment order (DV_W3), as the engine runs them')
     args = ap.parse_args()
     L.require_device()
     dev = torch.device('cuda:0')
@@ -81,9 +82,21 @@ def main():
         flops = 2.0 * y.rows * Co * Ci * taps
         bx, by = x.rows * x.cpitch * es, y.rows * y.cpitch * es
         ws = torch.empty(max(ops.wgrad_workspace_bytes(dd), 16), dtype=torch.uint8, device=dev)
+        if args.w3:
+            import ctypes as C
+            d3 = ops.conv_desc(DT, x, y, k, s, p, flags=(0 if args.no_stats else L.DV_STATS) | L.DV_W3)
+            dd3 = ops.conv_desc(DT, x, y, k, s, p, flags=L.DV_W3)
+            w3, wd3 = ops.pack_w3(w.float().view(Co, -1)), ops.pack_w3(wd.float().view(Ci, -1))
+            lib = L.load()
+            fwd3 = lambda: L.check(lib.dv_conv3d_fwd(C.byref(d3), x.ptr, w3.data_ptr(), 0, y.ptr, stats.data_ptr(), ops.stream_ptr()), 'fwd3')
+            dg3 = lambda: L.check(lib.dv_conv3d_dgrad(C.byref(dd3), dy.ptr, wd3.data_ptr(), dx.ptr, ops.stream_ptr()), 'dgrad3')
         jobs = {'fwd': (lambda: ops.conv_fwd(d, x, w, None, y, stats), bx + by),
                 'dgrad': (lambda: ops.conv_dgrad(dd, dy, wd, dx), bx + by),
                 'wgrad': (lambda: ops.conv_wgrad(dd, x, dy, dw, workspace=ws), bx + by)}
+        if args.w3:
+            jobs['fwd'] = (fwd3, bx + by)
+            if max(s) == 1:
+                jobs['dgrad'] = (dg3, bx + by)
         for ps in args.passes.split(','):
             fn, nbytes = jobs[ps]
             us = timed(fn, args.reps)
