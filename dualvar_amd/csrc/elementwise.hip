@@ -2,6 +2,7 @@
 // apply / backward, MaxPool3d, spatial mean, self-gating scale, optimizer.  NDHWC, 16-byte vector
 // accesses along the channel axis, fp32 math, wavefront(64)-shuffle + LDS reductions.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -514,6 +515,12 @@ __global__ void bn_bwd_apply_multi_kernel(const dv_bn_item* __restrict__ items, 
 }
 
 // ------------------------------------------------------------------ MaxPool3d
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  With a grid that is a multiple of 8, this gives
+// XCD x the logical blocks [x * grid/8, (x+1) * grid/8): neighbouring windows share an L2 instead of each XCD fetching
+// every plane.
+__device__ __forceinline__ uint32_t xcd_block() { return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+static inline int grid8_for(int64_t work_items, int max_blocks) { return (grid_for(work_items, max_blocks) + 7) & ~7; }
+
 struct PoolArgs {
   int N, Ti, Hi, Wi, C, CP;
   int To, Ho, Wo;
@@ -527,7 +534,7 @@ __global__ void maxpool_fwd_kernel(PoolArgs a, const T* __restrict__ x, T* __res
   constexpr int V = DT<T>::VEC;
   const uint32_t CV = a.fcv.d;
   const uint32_t total = (uint32_t)a.N * a.To * a.Ho * a.Wo * CV;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (uint32_t i = xcd_block() * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     uint32_t m, cvi, q, wo_, ho_, to_, n_;
     fd_divmod(i, a.fcv, m, cvi);
     const int c0 = (int)cvi * V;
@@ -566,47 +573,26 @@ __global__ void maxpool_fwd_kernel(PoolArgs a, const T* __restrict__ x, T* __res
 }
 
 template <typename T>
+__device__ __forceinline__ void pool_gather(const PoolArgs& a, const T* __restrict__ dyp, const uint8_t* __restrict__ idx,
+                                            uint32_t m_in, int c0, float (&g)[DT<T>::VEC]);
+
+template <typename T>
 __global__ void maxpool_bwd_kernel(PoolArgs a, const T* __restrict__ dy, const uint8_t* __restrict__ idx,
                                    T* __restrict__ dx, int accumulate) {
   constexpr int V = DT<T>::VEC;
   const uint32_t CV = a.fcv.d;
   const uint32_t total = (uint32_t)a.N * a.Ti * a.Hi * a.Wi * CV;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    uint32_t m, cvi, q, wi_, hi_, ti_, n_;
+  for (uint32_t i = xcd_block() * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    uint32_t m, cvi;
     fd_divmod(i, a.fcv, m, cvi);
     const int c0 = (int)cvi * V;
-    fd_divmod(m, a.fWi, q, wi_);
-    fd_divmod(q, a.fHi, q, hi_);
-    fd_divmod(q, a.fTi, n_, ti_);
-    const int wi = (int)wi_, hi = (int)hi_, ti = (int)ti_, n = (int)n_;
     float acc[V];
     if (accumulate) Pack16<T>::load(dx + (size_t)m * a.ldx + c0, acc);
     else {
 #pragma unroll
       for (int e = 0; e < V; ++e) acc[e] = 0.f;
     }
-    int tap = 0;
-    for (int dt = 0; dt < a.kt; ++dt) {
-      const int tn = ti + a.pt - dt;
-      for (int dh = 0; dh < a.kh; ++dh) {
-        const int hn = hi + a.ph - dh;
-        for (int dw = 0; dw < a.kw; ++dw, ++tap) {
-          const int wn = wi + a.pw - dw;
-          if ((tn | hn | wn) < 0) continue;
-          // strides are 1 or 2 (checked on the host)
-          if ((tn & (a.st - 1)) | (hn & (a.sh - 1)) | (wn & (a.sw - 1))) continue;
-          const int to = tn >> (a.st - 1), ho = hn >> (a.sh - 1), wo = wn >> (a.sw - 1);
-          if (to >= a.To || ho >= a.Ho || wo >= a.Wo) continue;
-          const int64_t mo = (int64_t)((n * a.To + to) * a.Ho + ho) * a.Wo + wo;
-          float g[V];
-          Pack16<T>::load(dy + mo * a.ldy + c0, g);
-          const uint8_t* ip = idx + mo * a.CP + c0;
-#pragma unroll
-          for (int e = 0; e < V; ++e)
-            if (ip[e] == tap) acc[e] += g[e];
-        }
-      }
-    }
+    pool_gather<T>(a, dy, idx, m, c0, acc);
     Pack16<T>::store(dx + (size_t)m * a.ldx + c0, acc);
   }
 }
@@ -670,7 +656,9 @@ __global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(PoolArgs a, const
   }
 }
 
-// g[e] = dL/dy of input element (row m_in, channels c0..c0+V) = sum of the pooled gradients of the windows that chose it
+// g[e] += dL/dy of input element (row m_in, channels c0..c0+V): the pooled gradients of the windows that chose it.  Only
+// the windows that contain the element are visited (o*s - p <= i < o*s - p + k per dimension: 3.4 of the 27 taps of a
+// 3x3x3 / stride 2 pool on average), in ascending tap order, which fixes the order of the fp32 sums.
 template <typename T>
 __device__ __forceinline__ void pool_gather(const PoolArgs& a, const T* __restrict__ dyp, const uint8_t* __restrict__ idx,
                                             uint32_t m_in, int c0, float (&g)[DT<T>::VEC]) {
@@ -679,20 +667,19 @@ __device__ __forceinline__ void pool_gather(const PoolArgs& a, const T* __restri
   fd_divmod(m_in, a.fWi, q, wi_);
   fd_divmod(q, a.fHi, q, hi_);
   fd_divmod(q, a.fTi, n_, ti_);
-  const int wi = (int)wi_, hi = (int)hi_, ti = (int)ti_, n = (int)n_;
-#pragma unroll
-  for (int e = 0; e < V; ++e) g[e] = 0.f;
-  int tap = 0;
-  for (int dt = 0; dt < a.kt; ++dt) {
-    const int tn = ti + a.pt - dt;
-    for (int dh = 0; dh < a.kh; ++dh) {
-      const int hn = hi + a.ph - dh;
-      for (int dw = 0; dw < a.kw; ++dw, ++tap) {
-        const int wn = wi + a.pw - dw;
-        if ((tn | hn | wn) < 0) continue;
-        if ((tn & (a.st - 1)) | (hn & (a.sh - 1)) | (wn & (a.sw - 1))) continue;       // strides are 1 or 2
-        const int to = tn >> (a.st - 1), ho = hn >> (a.sh - 1), wo = wn >> (a.sw - 1);
-        if (to >= a.To || ho >= a.Ho || wo >= a.Wo) continue;
+  const int n = (int)n_;
+  // strides are 1 or 2 (checked on the host): division by the stride is a shift, ceil(x / s) = (x + s - 1) >> (s - 1)
+  const int st1 = a.st - 1, sh1 = a.sh - 1, sw1 = a.sw - 1;
+  const int tn = (int)ti_ + a.pt, hn = (int)hi_ + a.ph, wn = (int)wi_ + a.pw;
+  const int t_hi = min(tn >> st1, a.To - 1), t_lo = max((tn - a.kt + 1 + st1) >> st1, 0);
+  const int h_hi = min(hn >> sh1, a.Ho - 1), h_lo = max((hn - a.kh + 1 + sh1) >> sh1, 0);
+  const int w_hi = min(wn >> sw1, a.Wo - 1), w_lo = max((wn - a.kw + 1 + sw1) >> sw1, 0);
+  for (int to = t_hi; to >= t_lo; --to) {
+    const int dt = tn - to * a.st;
+    for (int ho = h_hi; ho >= h_lo; --ho) {
+      const int dh = hn - ho * a.sh;
+      for (int wo = w_hi; wo >= w_lo; --wo) {
+        const uint32_t tap = (uint32_t)((dt * a.kh + dh) * a.kw + wn - wo * a.sw);
         const int64_t mo = (int64_t)((n * a.To + to) * a.Ho + ho) * a.Wo + wo;
         float d[V];
         Pack16<T>::load(dyp + mo * a.ldy + c0, d);
@@ -720,6 +707,8 @@ __global__ void bn_bwd_reduce_maxpool_kernel(PoolArgs a, const T* __restrict__ d
       r0, r1, CP,
       [&](int64_t r, int c0, float(&acc)[2][V]) {
         float g[V], xx[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) g[e] = 0.f;
         pool_gather<T>(a, dyp, idx, (uint32_t)r, c0, g);
         Pack16<T>::load(x + r * a.ldx + c0, xx);
 #pragma unroll
@@ -780,6 +769,8 @@ __global__ void bn_bwd_apply_maxpool_kernel(PoolArgs a, const T* __restrict__ dy
     fd_divmod(i, a.fcv, row, cvi);
     const int c0 = (int)cvi * V;
     float g[V], xx[V], o[V], k1[V], k2[V], k3[V], sc[V], sh[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) g[e] = 0.f;
     pool_gather<T>(a, dyp, idx, row, c0, g);
     Pack16<T>::load(x + (size_t)row * a.ldx + c0, xx);
     load_params<V>(coef, c0, k1);
@@ -798,102 +789,349 @@ __global__ void bn_bwd_apply_maxpool_kernel(PoolArgs a, const T* __restrict__ dy
   (void)CV;
 }
 
-// ------------------------------------------------------------------ MaxPool3d 3x3x3, stride 1, padding 1, bf16
-// (the pool branch of every Inception block, s3dg.py:105).  The generic kernels above spend ~6 VALU instructions per
-// tap and element on convert / compare / select-value / select-index and are VALU bound (~1 TB/s).  Here a thread
-// owns FOUR consecutive outputs along W (6 input columns per (dt, dh): half the loads), and value and position are
-// ONE sortable 32-bit key per loaded element,
-//     key = [bf16 bits made order-preserving : 16][63 - position inside the thread's 3x3x6 input block : 6 .. 0]
-// so "larger value, earlier tap on ties" (PyTorch's first-max rule) is a plain unsigned max (v_max_u32)
-// over the three windows a column belongs to.  NaNs with the sign bit clear win as in PyTorch; -0.0 orders below +0.0 (a
-// tie in PyTorch) -- inputs here are post-ReLU.  Same outputs (values, uint8 tap index) as the generic kernel.
-struct Pool3Args {
+// ------------------------------------------------------------------ MaxPool3d 3x3x3 / stride 1 / padding 1, LDS-staged
+// The gather kernels above read every window element through L1 / L2 (27 taps): with workgroups dealt round-robin to
+// the 8 XCDs, neighbouring windows land in different L2s and each of them fetches the whole tensor (PMC: 7.2x the
+// algorithmic bytes forward, 8.8x backward on the 14x14 fp32 pools).  Here a workgroup owns a TH x TW spatial tile of
+// one clip and a chunk of CV 16-byte channel vectors, and walks the T planes once: plane t+1 is in flight to
+// registers while plane t-1 is computed from a three-slot ring in LDS that holds planes t-2 .. t with a one-pixel
+// halo, so every element leaves L2 once (1.29x with the halo rows) and the 27 taps are LDS reads.  Workgroup order
+// is XCD-aware: consecutive tiles of a clip go to the same XCD, so halo rows and the other channel chunks of a
+// 128-byte line are L2 hits.
+//   forward : values are staged as order-preserving 32-bit keys (key_f32: a plain unsigned compare orders them, padding
+//             is key 0 below every real value, a NaN with the sign bit clear wins as in PyTorch; -0.0 orders below
+//             +0.0, a tie in PyTorch -- inputs are post-ReLU).  Taps are scanned in PyTorch's order with a strict
+//             compare: first maximum wins, same values and uint8 tap index as maxpool_fwd_kernel.
+//   backward: (dy, idx) staged with idx = 0xff outside the tensor; an input element adds dy of the windows that chose it
+//             in the tap order of maxpool_bwd_kernel, so the fp32 sums are bit-identical to that kernel's.
+struct PoolTileArgs {
   int N, T, H, W, C, CP, ldx, ldy;
-  uint32_t total;           // N*T*H*ceil(W/4)*CV work items
-  FastDiv fcv, fWr, fH, fT;
+  int nth, ntw, ncc, cpv;              // tiles along H and W, channel chunks, 16-byte vectors per pixel
+  uint32_t groups, per_xcd;            // workgroups with work; ceil(groups / 8)
+  FastDiv fcc, ftw, fth;
+  int accumulate;
 };
 
-__device__ __forceinline__ uint32_t pool_key(uint32_t x /* bf16 in the top half, low half zero */, uint32_t code) {
-  const uint32_t m = (uint32_t)((int32_t)x >> 31);
-  return x ^ ((m & 0x7fff0000u) | (0x80000000u | code));
-}
+__device__ __forceinline__ uint32_t key_f32(uint32_t x) { return x ^ ((uint32_t)((int32_t)x >> 31) | 0x80000000u); }
+__device__ __forceinline__ uint32_t unkey_f32(uint32_t k) { return (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k; }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void maxpool333_fwd_kernel(Pool3Args a, const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
-                                                              uint8_t* __restrict__ idx) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.total; i += gridDim.x * blockDim.x) {
-    uint32_t q, cvi, run, h_, t_, n_;
-    fd_divmod(i, a.fcv, q, cvi);
-    fd_divmod(q, a.fWr, q, run);
-    fd_divmod(q, a.fH, q, h_);
-    fd_divmod(q, a.fT, n_, t_);
-    const int c0 = (int)cvi * 8, w0 = (int)run * 4, ho = (int)h_, to = (int)t_, n = (int)n_;
-    uint32_t best[4][8];
+// CV 16-byte global vectors per pixel and workgroup; Q = 4-channel quads per global vector (1 for fp32, 2 for bf16).  LDS
+// holds one uint4 of 32-bit entries per quad (bf16 is widened while staging), and a work item is one quad of one pixel.
+template <int TH, int TW, int CV, int Q>
+struct PoolTile {
+  static constexpr int HW = TW + 2, NPX = (TH + 2) * HW, NST = NPX * CV, SR = (NST + kThreads - 1) / kThreads;
+  static constexpr int QV = CV * Q, NLE = NPX * QV, NIT = TH * TW * QV, R = (NIT + kThreads - 1) / kThreads;
+  int n, h0, w0, cv0;
+  __device__ __forceinline__ bool locate(const PoolTileArgs& a) {
+    const uint32_t lb = (blockIdx.x & 7u) * a.per_xcd + (blockIdx.x >> 3);
+    if (lb >= a.groups) return false;
+    uint32_t q, cc, tw, th, nn;
+    fd_divmod(lb, a.fcc, q, cc);
+    fd_divmod(q, a.ftw, q, tw);
+    fd_divmod(q, a.fth, nn, th);
+    n = (int)nn; h0 = (int)th * TH; w0 = (int)tw * TW; cv0 = (int)cc * CV;
+    return true;
+  }
+  // staged vector i of a plane -> halo pixel (h, w) and channel vector cv; false when nothing is to be fetched
+  __device__ __forceinline__ bool stage_src(const PoolTileArgs& a, int i, int& h, int& w, int& cv) const {
+    const int px = i / CV;
+    cv = cv0 + (i - px * CV);
+    const int hh = px / HW;
+    h = h0 - 1 + hh; w = w0 - 1 + (px - hh * HW);
+    return i < NST && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && cv < a.cpv;
+  }
+  // item it of the tile -> pixel (ph, pw) inside the tile and quad ql of the chunk; false for lanes without an output
+  __device__ __forceinline__ bool item(const PoolTileArgs& a, int it, int& ph, int& pw, int& ql) const {
+    const int px = it / QV;
+    ql = it - px * QV;
+    ph = px / TW; pw = px - ph * TW;
+    return it < NIT && h0 + ph < a.H && w0 + pw < a.W && cv0 * Q + ql < a.cpv * Q;
+  }
+};
+
+// the two quads of a 16-byte vector of bf16, widened to fp32 bit patterns
+__device__ __forceinline__ void widen_bf16x8(const uint4& v, uint4& q0, uint4& q1) {
+  q0 = make_uint4(v.x << 16, v.x & 0xffff0000u, v.y << 16, v.y & 0xffff0000u);
+  q1 = make_uint4(v.z << 16, v.z & 0xffff0000u, v.w << 16, v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 key_quad(const uint4& v) { return make_uint4(key_f32(v.x), key_f32(v.y), key_f32(v.z), key_f32(v.w)); }
+
+template <typename T, int TH, int TW, int CV>
+__global__ __launch_bounds__(kThreads) void pool333_fwd_tile_kernel(PoolTileArgs a, const T* __restrict__ x,
+                                                                    T* __restrict__ y, uint8_t* __restrict__ idx) {
+  constexpr int V = DT<T>::VEC, Q = V / 4;
+  using PT = PoolTile<TH, TW, CV, Q>;
+  __shared__ uint4 slots[2][PT::NLE];
+  PT tl;
+  if (!tl.locate(a)) return;
+  const int tid = threadIdx.x;
+  const int64_t plane = (int64_t)a.H * a.W * a.ldx;
+  int64_t soff[PT::SR];
+  bool sval[PT::SR];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+  for (int s = 0; s < PT::SR; ++s) {
+    int h, w, cv;
+    sval[s] = tl.stage_src(a, s * kThreads + tid, h, w, cv);
+    soff[s] = ((int64_t)(tl.n * a.T) * a.H * a.W + (int64_t)h * a.W + w) * a.ldx + cv * V;
+  }
+  uint4 pre[PT::SR];
+  auto prefetch = [&](int t) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) best[j][e] = 0u;
-    // One (dt, dh) row of the window per iteration, NOT unrolled: unrolled, the compiler hoists all 54 loads and the
-    // kernel needs 175+ VGPRs (2 waves per SIMD, slower than the generic kernel); software-pipelining the rows by
-    // hand (114 VGPRs) was slower too -- resident waves hide the latency better than either.
-#pragma unroll 1
-    for (int cmb = 0; cmb < 9; ++cmb) {
-      const int dt = cmb / 3, dh = cmb - dt * 3;
-      const int t = to - 1 + dt, hh = ho - 1 + dh;
-      if ((unsigned)t >= (unsigned)a.T || (unsigned)hh >= (unsigned)a.H) continue;
-      const bf16_t* rowp = x + ((int64_t)((n * a.T + t) * a.H + hh) * a.W) * a.ldx + c0;
+    for (int s = 0; s < PT::SR; ++s)
+      pre[s] = sval[s] ? *reinterpret_cast<const uint4*>(x + soff[s] + t * plane) : make_uint4(0u, 0u, 0u, 0u);
+  };
+  auto commit = [&](int slot) {
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-      for (int jj = 0; jj < 6; ++jj) {
-        const int w = w0 - 1 + jj;
-        if ((unsigned)w >= (unsigned)a.W) continue;                // padding: below every real key, nothing to do
-        const uint32_t code = 63u - (uint32_t)(cmb * 6 + jj);
-        const uint4 v = *reinterpret_cast<const uint4*>(rowp + (int64_t)w * a.ldx);
-        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const uint32_t key = pool_key((e & 1) ? (d[e >> 1] & 0xffff0000u) : (d[e >> 1] << 16), code);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (jj - j >= 0 && jj - j <= 2) best[j][e] = max(best[j][e], key);     // column jj feeds outputs jj-2 .. jj
-        }
+    for (int s = 0; s < PT::SR; ++s) {
+      const int i = s * kThreads + tid;
+      if (i >= PT::NST) break;
+      if constexpr (Q == 1) {
+        slots[slot][i] = sval[s] ? key_quad(pre[s]) : zero;
+      } else {
+        uint4 q0, q1;
+        widen_bf16x8(pre[s], q0, q1);
+        slots[slot][2 * i] = sval[s] ? key_quad(q0) : zero;
+        slots[slot][2 * i + 1] = sval[s] ? key_quad(q1) : zero;
       }
     }
+  };
+  // The window maximum is taken plane by plane: the first maximum of the 3x3 spatial window of one plane (key and spatial
+  // tap 0..8) is kept in registers for the two previous planes; an output is the first maximum of its three plane maxima in
+  // plane order -- the element PyTorch's (dt, dh, dw) scan with a strict compare picks, with 9 + 3 compares, not 27.
+  uint32_t k2[PT::R][4], c2[PT::R][4], k1[PT::R][4], c1[PT::R][4], k0[PT::R][4], c0[PT::R][4];
+  bool live[PT::R];
+  int base[PT::R];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int wo = w0 + j;
-      if (wo >= a.W) break;
-      const int64_t m = (int64_t)((n * a.T + to) * a.H + ho) * a.W + wo;
-      uint32_t ov[4];
-      uint32_t ib[2] = {0u, 0u};
+  for (int r = 0; r < PT::R; ++r) {
+    int ph, pw, ql;
+    live[r] = tl.item(a, r * kThreads + tid, ph, pw, ql);
+    base[r] = (ph * PT::HW + pw) * PT::QV + ql;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const uint32_t key = best[j][e];
-        const uint32_t s16 = key >> 16;
-        const uint32_t bits = (s16 & 0x8000u) ? (s16 ^ 0x8000u) : (~s16 & 0xffffu);
-        const uint32_t pos = 63u - (key & 63u);                 // (dt*3+dh)*6 + jj
-        const uint32_t dtdh = (pos * 43u) >> 8;                 // pos / 6 for pos < 64
-        const uint32_t tap = dtdh * 3u + (pos - dtdh * 6u) - (uint32_t)j;
-        if (e & 1) ov[e >> 1] |= bits << 16; else ov[e >> 1] = bits;
-        ib[e >> 2] |= (tap & 0xffu) << (8 * (e & 3));
+    for (int e = 0; e < 4; ++e) { k1[r][e] = 0u; c1[r][e] = 0u; k0[r][e] = 0u; c0[r][e] = 0u; }
+  }
+  prefetch(0);
+  for (int t = 0; t <= a.T; ++t) {
+    if (t < a.T) {
+      commit(t & 1);
+      if (t + 1 < a.T) prefetch(t + 1);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < PT::R; ++r) {
+      if (!live[r]) continue;
+      const int it = r * kThreads + tid, px = it / PT::QV, ph = px / TW, pw = px - ph * TW;
+      const int h = tl.h0 + ph, w = tl.w0 + pw;
+      const uint32_t code0 = (h == 0 ? 3u : 0u) + (w == 0 ? 1u : 0u);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { k2[r][e] = k1[r][e]; c2[r][e] = c1[r][e]; k1[r][e] = k0[r][e]; c1[r][e] = c0[r][e]; }
+      if (t < a.T) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { k0[r][e] = 0u; c0[r][e] = code0; }
+        const uint4* pl = slots[t & 1] + base[r];
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+          for (int dw = 0; dw < 3; ++dw) {
+            const uint4 k = pl[(dh * PT::HW + dw) * PT::QV];
+            const uint32_t kk[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (kk[e] > k0[r][e]) { k0[r][e] = kk[e]; c0[r][e] = (uint32_t)(dh * 3 + dw); }
+          }
       }
-      *reinterpret_cast<uint4*>(y + m * a.ldy + c0) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
-      *reinterpret_cast<uint2*>(idx + m * a.CP + c0) = make_uint2(ib[0], ib[1]);
+      if (t == 0) continue;
+      const int to = t - 1;
+      uint32_t best[4], bi[4];
+      // planes to-1 (k2), to (k1), to+1 (k0); k2 / k0 are absent at the ends of the clip
+      if (to >= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { best[e] = k2[r][e]; bi[e] = c2[r][e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k1[r][e] > best[e]) { best[e] = k1[r][e]; bi[e] = 9u + c1[r][e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { best[e] = k1[r][e]; bi[e] = 9u + c1[r][e]; }
+      }
+      if (t < a.T) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k0[r][e] > best[e]) { best[e] = k0[r][e]; bi[e] = 18u + c0[r][e]; }
+      }
+      const int cc0 = (tl.cv0 * Q + (it - px * PT::QV)) * 4;
+      uint32_t ov[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = (cc0 + e < a.C) ? unkey_f32(best[e]) : 0u;
+      const int64_t m = ((int64_t)(tl.n * a.T + to) * a.H + h) * a.W + w;
+      if constexpr (Q == 1)
+        *reinterpret_cast<uint4*>(y + m * a.ldy + cc0) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+      else
+        *reinterpret_cast<uint2*>(y + m * a.ldy + cc0) = make_uint2((ov[0] >> 16) | (ov[1] & 0xffff0000u), (ov[2] >> 16) | (ov[3] & 0xffff0000u));
+      *reinterpret_cast<uint32_t*>(idx + m * a.CP + cc0) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
     }
   }
 }
 
-static bool pool333(const dv_pool_desc* d) {
-  return d->dtype == DV_BF16 && d->kt == 3 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 &&
-         d->pt == 1 && d->ph == 1 && d->pw == 1;
+// acc[e] += g[e] for the elements whose tap byte in iw equals tap.  v_cmpx leaves the compare in EXEC, the add runs on the
+// lanes it kept and EXEC comes back from a scalar copy: two vector instructions per element where the compiler's
+// and / compare / add / select sequence takes four.
+__device__ __forceinline__ void add_if_tap4(float (&acc)[4], const uint4& g, uint32_t iw, uint32_t tap) {
+  uint64_t sv;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "v_cmpx_eq_u32_sdwa vcc, %[iw], %[tap] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_add_f32_e32 %[a0], %[a0], %[g0]\n\t"
+      "s_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_eq_u32_sdwa vcc, %[iw], %[tap] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_add_f32_e32 %[a1], %[a1], %[g1]\n\t"
+      "s_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_eq_u32_sdwa vcc, %[iw], %[tap] src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_add_f32_e32 %[a2], %[a2], %[g2]\n\t"
+      "s_mov_b64 exec, %[sv]\n\t"
+      "v_cmpx_eq_u32_sdwa vcc, %[iw], %[tap] src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "v_add_f32_e32 %[a3], %[a3], %[g3]\n\t"
+      "s_mov_b64 exec, %[sv]\n\t"
+      : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [sv] "=&s"(sv)
+      : [iw] "v"(iw), [tap] "s"(tap), [g0] "v"(g.x), [g1] "v"(g.y), [g2] "v"(g.z), [g3] "v"(g.w)
+      : "vcc");
 }
-static bool pool333_args(const PoolArgs& p, Pool3Args& a) {
+
+template <typename T, int TH, int TW, int CV>
+__global__ __launch_bounds__(kThreads) void pool333_bwd_tile_kernel(PoolTileArgs a, const T* __restrict__ dy,
+                                                                    const uint8_t* __restrict__ idx, T* __restrict__ dx) {
+  constexpr int V = DT<T>::VEC, Q = V / 4;
+  using PT = PoolTile<TH, TW, CV, Q>;
+  __shared__ uint4 gring[3][PT::NLE];
+  __shared__ uint32_t iring[3][PT::NLE];
+  PT tl;
+  if (!tl.locate(a)) return;
+  const int tid = threadIdx.x;
+  const int64_t plane = (int64_t)a.H * a.W;
+  int64_t srow[PT::SR];
+  int scv[PT::SR];
+  bool sval[PT::SR];
+#pragma unroll
+  for (int s = 0; s < PT::SR; ++s) {
+    int h, w;
+    sval[s] = tl.stage_src(a, s * kThreads + tid, h, w, scv[s]);
+    srow[s] = (int64_t)(tl.n * a.T) * a.H * a.W + (int64_t)h * a.W + w;
+  }
+  uint4 pre[PT::SR];
+  uint32_t prei[PT::SR][Q];
+  auto prefetch = [&](int t) {
+#pragma unroll
+    for (int s = 0; s < PT::SR; ++s) {
+      const int64_t m = srow[s] + t * plane;
+      pre[s] = sval[s] ? *reinterpret_cast<const uint4*>(dy + m * a.ldy + scv[s] * V) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int j = 0; j < Q; ++j)
+        prei[s][j] = sval[s] ? reinterpret_cast<const uint32_t*>(idx + m * a.CP + scv[s] * V)[j] : 0xffffffffu;
+    }
+  };
+  auto commit = [&](int slot) {
+#pragma unroll
+    for (int s = 0; s < PT::SR; ++s) {
+      const int i = s * kThreads + tid;
+      if (i >= PT::NST) break;
+      if constexpr (Q == 1) {
+        gring[slot][i] = pre[s];
+        iring[slot][i] = prei[s][0];
+      } else {
+        uint4 q0, q1;
+        widen_bf16x8(pre[s], q0, q1);
+        gring[slot][2 * i] = q0; gring[slot][2 * i + 1] = q1;
+        iring[slot][2 * i] = prei[s][0]; iring[slot][2 * i + 1] = prei[s][1];
+      }
+    }
+  };
+  auto compute = [&](int ti) {
+#pragma unroll
+    for (int r = 0; r < PT::R; ++r) {
+      int ph, pw, ql;
+      if (!tl.item(a, r * kThreads + tid, ph, pw, ql)) continue;
+      const int c0 = (tl.cv0 * Q + ql) * 4;
+      const int64_t m = ((int64_t)(tl.n * a.T + ti) * a.H + tl.h0 + ph) * a.W + tl.w0 + pw;
+      T* dst = dx + m * a.ldx + c0;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.accumulate) {
+        if constexpr (Q == 1) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(dst);
+          acc[0] = v.x; acc[1] = v.y; acc[2] = v.z; acc[3] = v.w;
+        } else {
+          const uint2 v = *reinterpret_cast<const uint2*>(dst);
+          acc[0] = __uint_as_float(v.x << 16); acc[1] = __uint_as_float(v.x & 0xffff0000u);
+          acc[2] = __uint_as_float(v.y << 16); acc[3] = __uint_as_float(v.y & 0xffff0000u);
+        }
+      }
+      // window (dh, dw) of this input pixel is the output at tile offset (ph + 1 - dh, pw + 1 - dw), i.e. halo pixel
+      // (ph + 2 - dh, pw + 2 - dw): offsets from the tile-corner base stay non-negative (immediate LDS offsets)
+      const int base = (ph * PT::HW + pw) * PT::QV + ql;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) {
+        const int to = ti + 1 - dt;
+        if (to < 0 || to >= a.T) continue;
+        const uint4* gs = gring[to % 3] + base;
+        const uint32_t* is = iring[to % 3] + base;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+          for (int dw = 0; dw < 3; ++dw) {
+            const int o = ((2 - dh) * PT::HW + (2 - dw)) * PT::QV;
+            add_if_tap4(acc, gs[o], is[o], (uint32_t)(dt * 9 + dh * 3 + dw));
+          }
+      }
+      if constexpr (Q == 1) {
+        f32x4 v = {acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 v = {(bf16_t)acc[0], (bf16_t)acc[1], (bf16_t)acc[2], (bf16_t)acc[3]};
+        *reinterpret_cast<bf16x4*>(dst) = v;
+      }
+    }
+  };
+  prefetch(0);
+  for (int t = 0; t <= a.T; ++t) {
+    if (t < a.T) commit(t % 3);
+    if (t + 1 < a.T) prefetch(t + 1);
+    __syncthreads();
+    if (t >= 1) compute(t - 1);
+    __syncthreads();
+  }
+}
+
+static bool pool333_shape(const dv_pool_desc* d) {
+  return d->kt == 3 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 1 && d->ph == 1 &&
+         d->pw == 1;
+}
+// tile geometry for a staged launch; false when the plane is too small to be worth a tile (the gather kernels run then)
+static bool pool_tile_args(const PoolArgs& p, int V, int TH, int TW, int CV, int accumulate, PoolTileArgs& a) {
+  if (p.Hi * p.Wi < 25) return false;
   a.N = p.N; a.T = p.Ti; a.H = p.Hi; a.W = p.Wi; a.C = p.C; a.CP = p.CP; a.ldx = p.ldx; a.ldy = p.ldy;
-  const int runs = (p.Wi + 3) / 4, cv = p.CP / 8;
-  const int64_t total = (int64_t)p.N * p.Ti * p.Hi * runs * cv;
-  if (total >= (1ll << 31)) return false;
-  a.total = (uint32_t)total;
-  a.fcv = make_fastdiv((uint32_t)cv); a.fWr = make_fastdiv((uint32_t)runs);
-  a.fH = make_fastdiv((uint32_t)p.Hi); a.fT = make_fastdiv((uint32_t)p.Ti);
+  a.nth = (p.Hi + TH - 1) / TH; a.ntw = (p.Wi + TW - 1) / TW; a.cpv = p.CP / V; a.ncc = (a.cpv + CV - 1) / CV;
+  const int64_t groups = (int64_t)p.N * a.nth * a.ntw * a.ncc;
+  if (groups >= (1ll << 28)) return false;
+  a.groups = (uint32_t)groups; a.per_xcd = (uint32_t)((groups + 7) / 8);
+  a.fcc = make_fastdiv((uint32_t)a.ncc); a.ftw = make_fastdiv((uint32_t)a.ntw); a.fth = make_fastdiv((uint32_t)a.nth);
+  a.accumulate = accumulate;
   return true;
+}
+static int pool_tile_cv(int dflt) {
+  static const char* e = getenv("DUALVAR_POOL_CV");
+  return e ? atoi(e) : dflt;
+}
+// Tile width / channel vectors per workgroup.  Measured on the 14x14 and 7x7 pools of S3D-G (tools/pool_sweep.sh): the
+// backward is occupancy-bound (three-plane ring of dy + idx), so it takes the 7-wide tile and 64 bytes of dy per pixel; the
+// forward (two single-plane slots) is flat between the shapes.  DUALVAR_POOL_TW / DUALVAR_POOL_CV override (experiments).
+static int pool_tile_tw(int W, bool narrow) {
+  static const char* e = getenv("DUALVAR_POOL_TW");
+  const int forced = e ? atoi(e) : 0;
+  return (forced == 7 || forced == 14) ? forced : ((W <= 7 || narrow) ? 7 : 14);
+}
+static bool pool_tile_off() {
+  static const char* e = getenv("DUALVAR_POOL_GATHER");
+  return e && atoi(e) != 0;
 }
 
 // ------------------------------------------------------------------ spatial mean / gating
@@ -1383,15 +1621,24 @@ extern "C" int dv_maxpool3d_fwd(const dv_pool_desc* d, const void* x, void* y, u
   if (rc) return rc;
   if (!x || !y || !idx) return DV_EINVAL;
   if (!aligned16(x) || !aligned16(y) || (reinterpret_cast<uintptr_t>(idx) & 7)) return DV_EALIGN;
-  Pool3Args a3;
-  if (pool333(d) && pool333_args(a, a3)) {
-    hipLaunchKernelGGL(maxpool333_fwd_kernel, dim3(grid_for(a3.total, 16384)), dim3(kThreads), 0, ST(stream), a3,
-                       (const bf16_t*)x, (bf16_t*)y, idx);
-    return dv_launch_status();
+  PoolTileArgs ta;
+  if (pool333_shape(d) && !pool_tile_off()) {
+    const int cv = pool_tile_cv(4), tw = pool_tile_tw(a.Wi, d->dtype == DV_BF16);
+#define POOL_FWD_TILE(TW_, CV_)                                                                                             \
+  DISPATCH_T(d->dtype, {                                                                                                     \
+    if (cv == CV_ && tw == TW_ && pool_tile_args(a, DT<T>::VEC, 7, TW_, CV_, 0, ta)) {                                       \
+      hipLaunchKernelGGL((pool333_fwd_tile_kernel<T, 7, TW_, CV_>), dim3(8 * ta.per_xcd), dim3(kThreads), 0, ST(stream), ta, \
+                         (const T*)x, (T*)y, idx);                                                                           \
+      return dv_launch_status();                                                                                             \
+    }                                                                                                                        \
+  })
+    POOL_FWD_TILE(7, 2); POOL_FWD_TILE(7, 4); POOL_FWD_TILE(7, 8);
+    POOL_FWD_TILE(14, 2); POOL_FWD_TILE(14, 4); POOL_FWD_TILE(14, 8);
+#undef POOL_FWD_TILE
   }
   DISPATCH_T(d->dtype, {
     const int64_t total = (int64_t)a.N * a.To * a.Ho * a.Wo * (a.CP / DT<T>::VEC);
-    hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(total, 16384)), dim3(kThreads), 0, ST(stream), a, (const T*)x,
+    hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid8_for(total, 16384)), dim3(kThreads), 0, ST(stream), a, (const T*)x,
                        (T*)y, idx);
   });
   return dv_launch_status();
@@ -1404,9 +1651,25 @@ extern "C" int dv_maxpool3d_bwd(const dv_pool_desc* d, const void* dy, const uin
   if (rc) return rc;
   if (!dy || !dx || !idx) return DV_EINVAL;
   if (!aligned16(dy) || !aligned16(dx)) return DV_EALIGN;
+  PoolTileArgs ta;
+  if (pool333_shape(d) && !pool_tile_off() && (reinterpret_cast<uintptr_t>(idx) & 7) == 0) {
+    const int cv = pool_tile_cv(d->dtype == DV_BF16 ? 2 : 4), tw = pool_tile_tw(a.Wi, true);
+    const int acc = (flags & DV_ACCUM) ? 1 : 0;
+#define POOL_BWD_TILE(TW_, CV_)                                                                                             \
+  DISPATCH_T(d->dtype, {                                                                                                     \
+    if (cv == CV_ && tw == TW_ && pool_tile_args(a, DT<T>::VEC, 7, TW_, CV_, acc, ta)) {                                     \
+      hipLaunchKernelGGL((pool333_bwd_tile_kernel<T, 7, TW_, CV_>), dim3(8 * ta.per_xcd), dim3(kThreads), 0, ST(stream), ta, \
+                         (const T*)dy, idx, (T*)dx);                                                                         \
+      return dv_launch_status();                                                                                             \
+    }                                                                                                                        \
+  })
+    POOL_BWD_TILE(7, 2); POOL_BWD_TILE(7, 4); POOL_BWD_TILE(7, 8);
+    POOL_BWD_TILE(14, 2); POOL_BWD_TILE(14, 4); POOL_BWD_TILE(14, 8);
+#undef POOL_BWD_TILE
+  }
   DISPATCH_T(d->dtype, {
     const int64_t total = (int64_t)a.N * a.Ti * a.Hi * a.Wi * (a.CP / DT<T>::VEC);
-    hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total, 16384)), dim3(kThreads), 0, ST(stream), a, (const T*)dy,
+    hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid8_for(total, 16384)), dim3(kThreads), 0, ST(stream), a, (const T*)dy,
                        idx, (T*)dx, (flags & DV_ACCUM) ? 1 : 0);
   });
   return dv_launch_status();

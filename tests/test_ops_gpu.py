@@ -588,8 +588,8 @@ def test_maxpool(gpu, dtype, k, s, p):
 
 @pytest.mark.parametrize('W', [3, 7, 14])
 def test_maxpool_333_fast_path_signed_values(gpu, W):
-    """the bf16 3x3x3 / stride 1 / padding 1 kernel orders values through integer keys: negative values, every
-    run-length remainder of W (runs of four outputs) and the uint8 tap index all have to agree with PyTorch"""
+    """3x3x3 / stride 1 / padding 1 in bf16 orders values through integer keys (staged kernel; W = 3 takes the gather
+    kernel): negative values and the uint8 tap index have to agree with PyTorch"""
     N, C_, T, H = 2, 40, 3, 5
     x = q(rnd(N, C_, T, H, W, seed=71) * 3 - 1, DV_BF16)
     x[:, :8] = -x[:, :8].abs()                                      # windows whose maximum is negative
@@ -614,6 +614,43 @@ def test_maxpool_333_fast_path_signed_values(gpu, W):
     dxa = ops.new_act(N, T, H, W, C_, DV_BF16, gpu)
     ops.call('dv_maxpool3d_bwd', d, dya, idx, dxa, 0)
     close(ops.act_to_ncdhw(dxa), q(xr.grad, DV_BF16), DV_BF16, 'maxpool333 bwd')
+
+
+@pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
+@pytest.mark.parametrize('shape', [(3, 40, 4, 14, 14), (2, 72, 2, 7, 7), (2, 24, 1, 16, 30), (1, 36, 5, 9, 8), (2, 8, 3, 5, 5)])
+def test_maxpool_333_staged_tiles(gpu, dtype, shape):
+    """the LDS-staged 3x3x3 / stride 1 / padding 1 kernels (planes of 25 pixels and more): values, PyTorch's first-maximum
+    tap index and the gathered gradient, on whole tiles, ragged tiles, several tiles per plane, partial channel chunks,
+    T = 1 and T > 3 (ring wrap); the gradient sums run in the gather kernel's tap order, so DV_ACCUM on zeros is
+    bit-identical to the plain call"""
+    N, C_, T, H, W = shape
+    x = q(rnd(N, C_, T, H, W, seed=81) * 3 - 1, dtype)
+    x[:, :4] = -x[:, :4].abs()
+    x[:, 4:8] = F.relu(x[:, 4:8])                                   # exact ties at 0
+    xr = x.clone().requires_grad_(True)
+    yr, ir = F.max_pool3d(xr, 3, 1, 1, return_indices=True)
+    gy = q(rnd(*yr.shape, seed=82), dtype)
+    yr.backward(gy)
+    xa = ops.act_from_ncdhw(x.to(gpu), dtype)
+    ya = ops.new_act(N, T, H, W, C_, dtype, gpu)
+    idx = torch.full((ya.rows, ops.cp8(C_)), 77, dtype=torch.uint8, device=gpu)
+    d = ops.pool_desc(dtype, xa, ya, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    ops.call('dv_maxpool3d_fwd', d, xa, ya, idx)
+    assert torch.equal(ops.act_to_ncdhw(ya).cpu(), yr.detach())
+    tap = idx.view(N, T, H, W, -1)[..., :C_].permute(0, 4, 1, 2, 3).long().cpu()
+    dt, dh, dw = tap // 9, tap // 3 % 3, tap % 3
+    tt = torch.arange(T).view(1, 1, T, 1, 1) - 1 + dt
+    hh = torch.arange(H).view(1, 1, 1, H, 1) - 1 + dh
+    ww = torch.arange(W).view(1, 1, 1, 1, W) - 1 + dw
+    assert torch.equal((tt * H + hh) * W + ww, ir)
+    dya = ops.act_from_ncdhw(gy.to(gpu), dtype)
+    dxa = ops.new_act(N, T, H, W, C_, dtype, gpu)
+    dxa.buf.fill_(float('nan'))
+    ops.call('dv_maxpool3d_bwd', d, dya, idx, dxa, 0)
+    close(ops.act_to_ncdhw(dxa), q(xr.grad, dtype), dtype, 'staged maxpool bwd')
+    dxb = ops.new_act(N, T, H, W, C_, dtype, gpu, zero=True)
+    ops.call('dv_maxpool3d_bwd', d, dya, idx, dxb, ops.DV_ACCUM)
+    assert torch.equal(dxa.buf[:, :C_], dxb.buf[:, :C_])
 
 
 @pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])

@@ -48,7 +48,7 @@ def short(name):
     for key, pat in (('bn_bwd_reduce_multi', r'bn_bwd_reduce_multi'), ('bn_bwd_apply_multi', r'bn_bwd_apply_multi'),
                      ('bn_apply_multi', r'bn_apply_multi'), ('bn_bwd_reduce', r'bn_bwd_reduce_kernel'),
                      ('bn_bwd_apply', r'bn_bwd_apply_kernel'), ('bn_apply_maxpool', r'bn_apply_maxpool'), ('bn_apply', r'bn_apply_kernel'),
-                     ('maxpool_fwd', r'maxpool(333)?_fwd'), ('maxpool_bwd', r'maxpool_bwd')):
+                     ('maxpool_fwd', r'maxpool_fwd|pool333_fwd_tile'), ('maxpool_bwd', r'maxpool_bwd|pool333_bwd_tile')):
         if re.search(pat, n):
             return '%s<%s>' % (key, _dt(n))
     if re.search(r'bn_stats_multi', n):
