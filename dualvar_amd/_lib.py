@@ -46,6 +46,12 @@ class BnItem(C.Structure):
                 [(n, C.c_int32) for n in ('blk_stats', 'blk_apply', 'blk_red', 'blk_bapply')])
 
 
+class BnReduce(C.Structure):
+    """dv_bn_reduce: the BatchNorm in front of a conv, for dv_conv3d_dgrad_bn"""
+    _fields_ = ([(n, C.c_void_p) for n in ('x', 'mean', 'invstd', 'scale', 'shift', 'sums')] +
+                [(n, C.c_int32) for n in ('ldx', 'n_rep', 'flags', '_pad')])
+
+
 class W3Desc(C.Structure):
     _fields_ = [('src_off', C.c_int64), ('dst_off', C.c_int64), ('N', C.c_int32), ('Ktot', C.c_int32)]
 
@@ -70,6 +76,7 @@ SIGNATURES = {
     'dv_conv3d_tile_shape': [CD, I32, P, P],
     'dv_conv3d_fwd': [CD, P, P, P, P, P, P],
     'dv_conv3d_dgrad': [CD, P, P, P, P],
+    'dv_conv3d_dgrad_bn': [CD, P, P, P, P, P],
     'dv_conv3d_wgrad_workspace': [CD],
     'dv_conv3d_wgrad_tile': [CD, P, P, P],
     'dv_conv3d_wgrad': [CD, P, P, P, P, I64, P],

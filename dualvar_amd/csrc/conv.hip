@@ -55,6 +55,14 @@ struct ConvArgs {
   // all taps and multiplying zeros for the (st*sh*sw - 1)/(st*sh*sw) that miss.  The weights are not repacked: a class tap
   // reads the ORIGINAL tap ((crt+cst*jt)*oKH + crh+csh*jh)*oKW + crw+csw*jw; output rows map back to the full input.
   int cls_on, cst, csh, csw, cot, coh, cow, crt, crh, crw, oKH, oKW, oT, oH, oW;
+  // dgrad whose output is dL/dy of y = relu(x_bn * scale + shift), the BatchNorm in front of this conv, and is that
+  // gradient's only contribution (dv_conv3d_dgrad_bn): the epilogue also accumulates the BatchNorm backward's
+  // sum(g), sum(g * xhat) into bn_sums[tile_m % bn_rep][2][CP] -- what dv_bn_bwd_reduce would compute from a second read of
+  // dL/dy.  bn_x == nullptr: plain dgrad.
+  const void* bn_x;
+  const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
+  float* bn_sums;
+  int bn_ldx, bn_rep, bn_mask;
 };
 
 template <int BYTES> struct VecB;
@@ -684,6 +692,63 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
               *reinterpret_cast<f32x4*>(p) = v;
             }
           }
+        }
+      }
+    }
+    // BatchNorm-backward reduce fused into the data gradient (ConvArgs::bn_x, dv_conv3d_dgrad_bn).  A pass of its own over the
+    // tile this workgroup has just written (read back from L2) and the matching tile of the BatchNorm's input: at this point
+    // the accumulators are dead, so it costs the kernel no registers -- inside the store loop it took 20-30 VGPRs and a
+    // resident workgroup per CU from every data gradient, fused or not.
+    constexpr int CPT = BN * EO / 16;                // 16-byte chunks per tile row
+    constexpr bool BNRED = (MODE == MODE_DGRAD) && sizeof(T) != 1 && (NT % CPT == 0);
+    if constexpr (BNRED) {
+      if (a.bn_x != nullptr) {
+        constexpr int RG = NT / CPT;                 // row groups: thread = (row group, chunk), the chunk is fixed
+        static_assert(RG * 2 * BN * 4 <= (int)sizeof(smem), "bn reduce scratch");
+        const int ch = tid % CPT, rg = tid / CPT, col0 = n0 + ch * EPC;
+        float mu[EPC], is[EPC], sc[EPC], sh[EPC], s1[EPC], s2[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const bool ok = col0 + e < a.N;
+          mu[e] = ok ? a.bn_mean[col0 + e] : 0.f;
+          is[e] = ok ? a.bn_invstd[col0 + e] : 0.f;
+          sc[e] = (ok && a.bn_mask) ? a.bn_scale[col0 + e] : 0.f;
+          sh[e] = (ok && a.bn_mask) ? a.bn_shift[col0 + e] : 0.f;
+          s1[e] = s2[e] = 0.f;
+        }
+        __syncthreads();                             // the tile's stores are visible to the whole workgroup
+        if (col0 < a.NP) {
+          const int rows_here = min(BM, a.M - m0);
+          for (int r = rg; r < rows_here; r += RG) {
+            const size_t orow = out_row(m0 + r);
+            float gq[EPC], xq[EPC];
+            Pack16<OT>::load(out + orow * a.ldo + col0, gq);
+            Pack16<OT>::load(reinterpret_cast<const OT*>(a.bn_x) + orow * a.bn_ldx + col0, xq);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+              const float act = xq[e] * sc[e] + sh[e];          // the forward's expression (dv_bn_apply), same rounding
+              const float gg = (a.bn_mask && !(act > 0.f)) ? 0.f : gq[e];
+              s1[e] += gg;
+              s2[e] += gg * (xq[e] - mu[e]) * is[e];
+            }
+          }
+        }
+        float* red = reinterpret_cast<float*>(smem);            // [RG][2][BN]
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          red[(rg * 2 + 0) * BN + ch * EPC + e] = s1[e];
+          red[(rg * 2 + 1) * BN + ch * EPC + e] = s2[e];
+        }
+        __syncthreads();
+        // the row groups of a column in a fixed order; one atomic per column and sum into replica tile_m % bn_rep
+        // (dv_bn_bwd_reduce's layout, read by dv_bn_bwd_apply)
+        if (tid < BN && n0 + tid < a.N) {
+          float t1 = 0.f, t2 = 0.f;
+          for (int w = 0; w < RG; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
+          const int cpb = (a.N + 7) & ~7;
+          float* dst = a.bn_sums + (size_t)(tile_m % a.bn_rep) * 2 * cpb + n0 + tid;
+          atomicAdd(dst, t1);
+          atomicAdd(dst + cpb, t2);
         }
       }
     }
@@ -1505,7 +1570,7 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   if (!aligned16(w) || !aligned16(y) || (reinterpret_cast<uintptr_t>(x) & 7)) return DV_EALIGN;
   ConvArgs a;
   fill_geom(d, MODE_FWD, a.g);
-  a.src = x; a.w = w; a.out = y; a.bias = bias; a.stats = stats; a.sc_a = a.sc_b = nullptr;
+  a.src = x; a.w = w; a.out = y; a.bias = bias; a.stats = stats; a.sc_a = a.sc_b = nullptr; a.bn_x = nullptr;
   a.M = d->N * d->To * d->Ho * d->Wo;
   a.N = d->Cout; a.NP = d->cout_pitch;
   a.lds_ = d->ldx; a.ldo = d->ldy; a.ldw = a.g.Ktot;
@@ -1565,7 +1630,7 @@ extern "C" int dv_conv3d_fwd_fp8(const dv_conv_desc* d, const void* x8, const vo
   if (!aligned16(x8) || !aligned16(w8) || !aligned16(y) || d->ldx % 16 || (d->ldy * 2) % 16) return DV_EALIGN;
   ConvArgs a;
   fill_geom(d, MODE_FWD, a.g);
-  a.src = x8; a.w = w8; a.out = y; a.bias = nullptr; a.stats = stats; a.sc_a = scale_x; a.sc_b = scale_w;
+  a.src = x8; a.w = w8; a.out = y; a.bias = nullptr; a.stats = stats; a.sc_a = scale_x; a.sc_b = scale_w; a.bn_x = nullptr;
   a.M = d->N * d->To * d->Ho * d->Wo;
   a.N = d->Cout; a.NP = d->cout_pitch;
   a.lds_ = d->ldx; a.ldo = d->ldy; a.ldw = a.g.Ktot;
@@ -1590,7 +1655,7 @@ extern "C" int dv_conv3d_dgrad_fp8(const dv_conv_desc* d, const void* dy8, const
   if (!aligned16(dy8) || !aligned16(wd8) || !aligned16(dx) || d->ldy % 16 || (d->ldx * 2) % 16) return DV_EALIGN;
   ConvArgs a;
   fill_geom(d, MODE_DGRAD, a.g);
-  a.src = dy8; a.w = wd8; a.out = dx; a.bias = nullptr; a.stats = nullptr; a.sc_a = scale_dy; a.sc_b = scale_w;
+  a.src = dy8; a.w = wd8; a.out = dx; a.bias = nullptr; a.stats = nullptr; a.sc_a = scale_dy; a.sc_b = scale_w; a.bn_x = nullptr;
   a.M = d->N * d->Ti * d->Hi * d->Wi;
   a.N = d->Cin; a.NP = d->cin_pitch;
   a.lds_ = d->ldy; a.ldo = d->ldx; a.ldw = a.g.Ktot;
@@ -1607,10 +1672,15 @@ extern "C" int dv_conv3d_dgrad_fp8(const dv_conv_desc* d, const void* dy8, const
   return dv_launch_status();
 }
 
-extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void* wd, void* dx, void* stream) {
+static int dgrad_impl(const dv_conv_desc* d, const void* dy, const void* wd, void* dx, const dv_bn_reduce* bnr, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!dy || !wd || !dx) return DV_EINVAL;
+  if (bnr) {
+    if (!bnr->x || !bnr->mean || !bnr->invstd || !bnr->sums || bnr->n_rep <= 0 || (d->flags & DV_ACCUM)) return DV_EINVAL;
+    if (!(bnr->flags & DV_NO_RELU_MASK) && (!bnr->scale || !bnr->shift)) return DV_EINVAL;
+    if (!aligned16(bnr->x) || bnr->ldx < d->cin_pitch || (bnr->ldx * (d->dtype == DV_F32 ? 4 : 2)) % 16) return DV_EALIGN;
+  }
   if (d->st > 2 || d->sh > 2 || d->sw > 2) return DV_EUNSUPPORTED;
   if (d->cin_pitch % 8) return DV_EUNSUPPORTED;      // the RGB input never needs a data gradient
   if (!aligned16(dy) || !aligned16(wd) || !aligned16(dx)) return DV_EALIGN;
@@ -1623,6 +1693,11 @@ extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void
   a.N = d->Cin; a.NP = d->cin_pitch;
   a.lds_ = d->ldy; a.ldo = d->ldx; a.ldw = a.g.Ktot;
   a.flags = d->flags & DV_ACCUM;
+  a.bn_x = nullptr;
+  if (bnr) {
+    a.bn_x = bnr->x; a.bn_ldx = bnr->ldx; a.bn_mean = bnr->mean; a.bn_invstd = bnr->invstd; a.bn_scale = bnr->scale;
+    a.bn_shift = bnr->shift; a.bn_sums = bnr->sums; a.bn_rep = bnr->n_rep; a.bn_mask = (bnr->flags & DV_NO_RELU_MASK) ? 0 : 1;
+  }
   const bool w3 = (d->flags & DV_W3) != 0;
   if (w3 && (d->dtype != DV_F32 || f32_exact() || d->st > 1 || d->sh > 1 || d->sw > 1)) return DV_EUNSUPPORTED;
   if (w3) { a.flags |= DV_W3; a.ldw = w3_rows(d->Cin); }
@@ -1675,6 +1750,16 @@ extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void
   if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, a, grid, s);
   else launch_gemm<bf16_t, MODE_DGRAD, 16>(bm, bn, a, grid, s);
   return dv_launch_status();
+}
+
+extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void* wd, void* dx, void* stream) {
+  return dgrad_impl(d, dy, wd, dx, nullptr, stream);
+}
+
+extern "C" int dv_conv3d_dgrad_bn(const dv_conv_desc* d, const void* dy, const void* wd, void* dx, const dv_bn_reduce* bn,
+                                  void* stream) {
+  if (!bn) return DV_EINVAL;
+  return dgrad_impl(d, dy, wd, dx, bn, stream);
 }
 
 // Tile / row-split plan of a weight-gradient problem (shared by the launch and by dv_conv3d_wgrad_workspace).

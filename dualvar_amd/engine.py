@@ -40,6 +40,11 @@ SIDE_LAUNCHES = ('conv_wgrad', 'gate_db')
 WGRAD_BATCH = int(os.environ.get('DUALVAR_WGRAD_BATCH', '4'))
 # BatchNorm + ReLU whose only consumer is a max-pool (the stems) run fused with it; '0' keeps the separate passes
 FUSE_BN_POOL = os.environ.get('DUALVAR_FUSE_BN_POOL', '1') != '0'
+# conv -> BatchNorm -> conv with a single reader: the BatchNorm-backward reduce can run in the second conv's data-gradient
+# epilogue (dv_conv3d_dgrad_bn).  OFF by default -- measured on the S3D-G step (MI355X, fp32 / bf16): the reduce launches shrink
+# 1.36 -> 0.66 / 1.07 -> 0.55 ms per step, but the data gradients that carry them grow by 0.62 / 0.52 ms (a serial tail per
+# workgroup that re-reads its tile and the BatchNorm input), and they sit on the critical path: 20.47 -> 20.77 / 9.79 -> 9.98 ms.
+FUSE_BN_REDUCE = os.environ.get('DUALVAR_FUSE_BN_REDUCE', '0') == '1'
 
 
 class Slot:
@@ -575,6 +580,30 @@ class Plan:
                 key = (g.buf.data_ptr(), g.off)
                 op.acc[name] = key in seen
                 seen.add(key)
+        # conv -> BatchNorm(+ReLU) -> conv chains: when the second conv is the only reader of the BatchNorm's output, its
+        # data gradient IS dL/dy of that BatchNorm, complete after one launch -- the BatchNorm backward's reduce (sum g,
+        # sum g*xhat) runs in that launch's epilogue (dv_conv3d_dgrad_bn) instead of re-reading dL/dy in a pass of its own
+        if self.with_grad and self.training and FUSE_BN_REDUCE:
+            writers = {}
+            for op in self.ops:
+                for name, a in op.grad_targets():
+                    g = a.grad if a.grad is not None else a
+                    writers.setdefault((g.buf.data_ptr(), g.off), []).append((op, a))
+            for op in self.ops:
+                if not isinstance(op, BNGroupOp):
+                    continue
+                for m in op.members:
+                    y = m.y
+                    if y.grad is None or m.res is not None or m.fused_pool is not None or (m.relu and not m.mask_from_x):
+                        continue
+                    w = writers.get((y.grad.buf.data_ptr(), y.grad.off), [])
+                    if len(w) != 1 or not isinstance(w[0][0], ConvOp):
+                        continue
+                    cop, a = w[0]
+                    if (cop.fp8 or not cop.need_dx or cop.acc.get('x') or a.buf is not y.buf or a.off != y.off or a.C != y.C
+                            or a.rows != y.rows or cop.bn_fuse is not None):
+                        continue
+                    cop.bn_fuse, m.reduce_fused = m, True
         # scratch of the deterministic weight gradients (row-split partial tiles): ONE buffer per plan, sized for the
         # largest layer -- the plan's weight gradients all run on one stream (the side stream), each followed by its
         # reduce, so they can share it
@@ -751,6 +780,7 @@ class ConvOp(Op):
         self.need_dx = plan.with_grad and x.grad is not None and slot.wd_off >= 0
         self.alg_k = None
         self.zero_pad_taps = None
+        self.bn_fuse = None          # BNMember whose backward reduce this conv's data gradient carries (Plan.finalize)
 
     def grad_targets(self):
         return [('x', self.x)] if self.need_dx else []
@@ -796,9 +826,18 @@ class ConvOp(Op):
                 acc = bool(self.acc.get('x'))
                 wdp, wdflag = st.w_dgrad(sl, strided=max(self.s) > 1)
                 self.d_g = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=(DV_ACCUM if acc else 0) | wdflag)
-                b.append(Launch('conv_dgrad', 'conv_gemm<%s,DGRAD,16,%d,%d>' % ((_dt(self.dtype),) + _tile_shape(lib, self.d_g, 1)),
-                                lib.dv_conv3d_dgrad, (C.byref(self.d_g), y.grad.ptr, wdp, x.grad.ptr),
-                                _abytes(y) + wbytes + _abytes(x) * (2 if acc else 1), flops, shp))
+                kd = 'conv_gemm<%s,DGRAD,16,%d,%d>' % ((_dt(self.dtype),) + _tile_shape(lib, self.d_g, 1))
+                if self.bn_fuse is not None:
+                    m = self.bn_fuse
+                    r = self._bn_reduce = L.BnReduce()
+                    r.x, r.ldx = m.x.ptr, m.x.ld
+                    r.mean, r.invstd, r.scale, r.shift = (t.data_ptr() for t in (m.mean, m.invstd, m.scale, m.shift))
+                    r.sums, r.n_rep, r.flags = p.zero_ptr(m.sums_off), BN_REPLICAS, (0 if m.relu else DV_NO_RELU_MASK)
+                    b.append(Launch('conv_dgrad', kd, lib.dv_conv3d_dgrad_bn, (C.byref(self.d_g), y.grad.ptr, wdp, x.grad.ptr, C.byref(r)),
+                                    _abytes(y) + wbytes + _abytes(x) * 2, flops, shp + ' +bn_reduce'))
+                else:
+                    b.append(Launch('conv_dgrad', kd, lib.dv_conv3d_dgrad, (C.byref(self.d_g), y.grad.ptr, wdp, x.grad.ptr),
+                                    _abytes(y) + wbytes + _abytes(x) * (2 if acc else 1), flops, shp))
         return f, b
 
 
@@ -866,6 +905,7 @@ class BNMember:
         # xhat anyway) with the forward's expression and never touches y -- 5 tensor passes per BatchNorm instead of 7
         self.conv_bias = None        # Plan.bn(conv_bias=...)
         self.fused_pool = None       # the PoolOp that consumes y on the fly (Plan.maxpool(sole_consumer=True))
+        self.reduce_fused = False    # the backward reduce runs in the epilogue of the consuming conv's data gradient
         self.mask_from_x = bool(relu) and residual is None
         self.sums_off = plan.reserve_zero(BN_REPLICAS * 2 * self.CP) if plan.with_grad else 0
         self.sums_len = BN_REPLICAS * 2 * self.CP
@@ -929,7 +969,7 @@ class BNGroupOp(Op):
                 it.dgamma, it.dbeta = st.w_grad(gs), st.w_grad(bs)
                 it.inv_count, it.dparam_scale = 1.0 / (m.M * R), 1.0 / R
                 it.bwd_flags = mflag | (DV_ACCUM if (dres is not None and self.acc.get('res%d' % i)) else 0)
-                ends[2] += lib.dv_bn_bwd_blocks(m.M, m.C)
+                ends[2] += 0 if m.reduce_fused else lib.dv_bn_bwd_blocks(m.M, m.C)
                 ends[3] += max(1, min(2048, (total + 255) // 256))
                 it.blk_red, it.blk_bapply = ends[2], ends[3]
         self._items = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(p.device)
@@ -948,7 +988,7 @@ class BNGroupOp(Op):
                                   self.gathered.data_ptr(), R, self.width))
         if p.with_grad:
             b_red = [Launch('bn_bwd_reduce_multi', 'bn_bwd_reduce_multi<%s>' % dt, lib.dv_bn_bwd_reduce_multi,
-                            (p.dtype, tab, n, ends[2]), tot(b_red, 'bytes'))]
+                            (p.dtype, tab, n, ends[2]), tot(b_red, 'bytes'))] if ends[2] else []
             b_app = [Launch('bn_bwd_apply_multi', 'bn_bwd_apply_multi<%s>' % dt, lib.dv_bn_bwd_apply_multi,
                             (p.dtype, tab, n, ends[3], max(m.C for m in self.members)), tot(b_app, 'bytes'))]
             b_app[0].gend = _gend(*[st.slot(t) for m in self.members for t in (m.bn.weight, m.bn.bias)])
@@ -1015,9 +1055,10 @@ class BNGroupOp(Op):
                 mflag = 0 if m.relu else DV_NO_RELU_MASK
                 nact = 3 if (m.relu and not m.mask_from_x) else 2
                 sums = p.zero_ptr(m.sums_off)
-                b_red.append(Launch('bn_bwd_reduce', 'bn_bwd_reduce<%s>' % dt, lib.dv_bn_bwd_reduce,
-                                    (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, m.mean.data_ptr(), m.invstd.data_ptr(),
-                                     M, Cn, mflag, sums, BN_REPLICAS), _abytes(x) * nact, 0, 'M%d C%d' % (M, Cn)))
+                if not m.reduce_fused:
+                    b_red.append(Launch('bn_bwd_reduce', 'bn_bwd_reduce<%s>' % dt, lib.dv_bn_bwd_reduce,
+                                        (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, m.mean.data_ptr(), m.invstd.data_ptr(),
+                                         M, Cn, mflag, sums, BN_REPLICAS), _abytes(x) * nact, 0, 'M%d C%d' % (M, Cn)))
                 dres = res.grad if (res is not None and res.grad is not None) else None
                 bflags = mflag | (DV_ACCUM if (dres is not None and self.acc.get('res%d' % i)) else 0)
                 nres = 0 if dres is None else (2 if bflags & DV_ACCUM else 1)

@@ -93,6 +93,21 @@ def conv_dgrad(d, dy, wd, dx):
     L.check(lib.dv_conv3d_dgrad(C.byref(d), _p(dy), _p(wd), _p(dx), stream_ptr()), 'dv_conv3d_dgrad')
 
 
+def bn_reduce_desc(x, mean, invstd, scale, shift, sums, n_rep, flags=0):
+    """dv_bn_reduce for dv_conv3d_dgrad_bn: the BatchNorm (input activation x, statistics, affine map of the forward) in front
+    of the conv whose data gradient is being computed"""
+    r = L.BnReduce()
+    r.x, r.ldx = _p(x), x.ld
+    r.mean, r.invstd, r.scale, r.shift, r.sums = (_p(t) for t in (mean, invstd, scale, shift, sums))
+    r.n_rep, r.flags = n_rep, flags
+    return r
+
+
+def conv_dgrad_bn(d, dy, wd, dx, bn):
+    lib = L.load()
+    L.check(lib.dv_conv3d_dgrad_bn(C.byref(d), _p(dy), _p(wd), _p(dx), C.byref(bn), stream_ptr()), 'dv_conv3d_dgrad_bn')
+
+
 def wgrad_workspace_bytes(d):
     return int(L.load().dv_conv3d_wgrad_workspace(C.byref(d)))
 

@@ -98,6 +98,24 @@ int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w_fwd, const
                   void* y, float* stats, void* stream);
 /* dx (+)= conv_transpose(dy, w).  strides must be 1 or 2. */
 int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, void* stream);
+/* The same data gradient when dx is dL/dy of y = relu(BatchNorm(x_bn)) -- the layer in front of this conv
+ * (backbone/s3dg.py:24-28,58-65: conv -> bn -> relu -> conv) -- and this conv is y's ONLY consumer: the epilogue also adds
+ * the BatchNorm backward's two sums over the rows it writes, sums[tile % n_rep][0][c] += sum g, [1][c] += sum g*xhat with
+ * g = dx masked by (x_bn*scale + shift > 0) (flags: DV_NO_RELU_MASK for a BatchNorm without ReLU), i.e. exactly what
+ * dv_bn_bwd_reduce(DV_MASK_FROM_X) computes from a second read of dx; dv_bn_bwd_apply then reads `sums` as usual.
+ * x_bn has d->dtype, the dims of dx and pitch ldx (elements); sums is [n_rep][2][cp8(Cin)] fp32, zeroed by the caller.
+ * DV_ACCUM is not allowed (the sums must see the complete gradient). */
+typedef struct dv_bn_reduce {
+  const void* x;
+  const float* mean;
+  const float* invstd;
+  const float* scale;
+  const float* shift;
+  float* sums;
+  int32_t ldx, n_rep, flags, _pad;
+} dv_bn_reduce;
+int dv_conv3d_dgrad_bn(const dv_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const dv_bn_reduce* bn,
+                       void* stream);
 /* dw += x^T * dy into the fp32 gradient arena (caller zeroes at zero_grad).  Deterministic: the rows are split over
  * workgroups whose partial tiles go to `workspace` ([splits][Cout][taps*CinP] fp32, plain stores) and are then added to dw
  * in a fixed order -- no float atomics, so two runs on the same inputs give the same bits.  dv_conv3d_wgrad_workspace

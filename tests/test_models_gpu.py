@@ -623,3 +623,33 @@ def test_r50_fp8_pointwise_mode(gpu):
         losses[mode] = ls
     print('r50 SimCLR_Naked losses', losses)
     assert abs(losses['fp8pw'][0] - losses['bf16'][0]) < 0.15 and abs(losses['fp8pw'][1] - losses['bf16'][1]) < 0.3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# optional plan: BatchNorm-backward reduce inside the consuming conv's data gradient (engine.FUSE_BN_REDUCE)
+@pytest.mark.parametrize('net,dtype', [('r3d', 'fp32'), ('r21d', 'fp32'), ('s3dg', 'bf16')])
+def test_fused_bn_reduce_plan_gives_the_same_gradients(gpu, monkeypatch, net, dtype):
+    """DUALVAR_FUSE_BN_REDUCE=1 moves the reduce of every conv -> BatchNorm -> conv chain with a single reader into
+    dv_conv3d_dgrad_bn.  Same step, same gradients up to the order of the fp32 sums (both forms end in float atomics)."""
+    from dualvar_amd import engine, model as M
+    block = torch.randn(4, 2, 3, 8, 64, 64, generator=torch.Generator().manual_seed(3)).to(gpu)
+    grads, fused = [], []
+    for on in (False, True):
+        monkeypatch.setattr(engine, 'FUSE_BN_REDUCE', on)
+        torch.manual_seed(0)
+        m = M.SimCLR_Naked(net, 128, 0.07, False)
+        m.set_compute_dtype(dtype).train().to(gpu)
+        ret = m(block)
+        for st in m.stores():
+            st.zero_grad()
+        ret['clip_contrast_loss'].backward()
+        grads.append(torch.cat([st.grad.detach().float().flatten().clone() for st in m.stores()]))
+        plans = [pl for lst in m.encoder_q[0]._plans.values() for pl in lst]
+        fused.append(sum(1 for pl in plans for op in pl.ops if getattr(op, 'bn_fuse', None) is not None))
+    assert fused[0] == 0 and fused[1] >= 3, fused
+    a, b = grads
+    assert bool(torch.isfinite(b).all())
+    err = float((a - b).abs().max())
+    tol = (2e-4 if dtype == 'fp32' else 3e-2) * float(a.abs().max())
+    print(net, dtype, 'fused convs', fused[1], 'max grad diff', err, 'of', float(a.abs().max()))
+    assert err <= tol, (err, tol)

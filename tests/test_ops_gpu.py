@@ -174,6 +174,33 @@ def test_conv_fwd_dgrad_wgrad(gpu, dtype, case):
             dx3 = ops.new_act(N, T, H, W, Cin, dtype, gpu, zero=True)
             ops.conv_dgrad(ops.conv_desc(dtype, xa, dya, k, s, p, flags=DV_W3), dya, ops.pack_w3(wd.view(Cin, -1)), dx3)
             close(ops.act_to_ncdhw(dx3), xr.grad, dtype, name + ' dgrad (pre-split weights)')
+        # the data gradient with the BatchNorm-backward reduce of the layer in front fused into its epilogue
+        # (dv_conv3d_dgrad_bn): dx bit-identical to the plain call, sums == dv_bn_bwd_reduce(DV_MASK_FROM_X) on that dx
+        from dualvar_amd._lib import DV_NO_RELU_MASK
+        CPi = ops.cp8(Cin)
+        xb = ops.act_from_ncdhw(q(rnd(N, Cin, T, H, W, seed=5) + 0.2, dtype).to(gpu), dtype)     # the BatchNorm's input
+
+        def padded(t):
+            o = torch.zeros(CPi, device=gpu)
+            o[:Cin] = t.to(gpu)
+            return o
+        mean, invstd = padded(0.1 * rnd(Cin, seed=6)), padded(1 + 0.1 * rnd(Cin, seed=7).abs())
+        scale, shift = padded(1 + 0.2 * rnd(Cin, seed=8)), padded(0.1 * rnd(Cin, seed=9))
+        for bflag in (0, DV_NO_RELU_MASK):
+            dxp = ops.new_act(N, T, H, W, Cin, dtype, gpu, zero=True)
+            ops.conv_dgrad(d2, dya, wd, dxp)
+            gx, xx = dxp.buf[:, :CPi].float(), xb.buf[:, :CPi].float()
+            act = xx * scale                                     # two roundings, as the kernels compute it (no fma)
+            act = act + shift
+            gg = gx if bflag else torch.where(act > 0, gx, torch.zeros_like(gx))
+            want = torch.stack([gg.double().sum(0), (gg * (xx - mean) * invstd).double().sum(0)]).float()[None]
+            dxf = ops.new_act(N, T, H, W, Cin, dtype, gpu, zero=True)
+            sums = torch.zeros(3, 2, CPi, device=gpu)
+            ops.conv_dgrad_bn(d2, dya, wd, dxf, ops.bn_reduce_desc(xb, mean, invstd, scale, shift, sums, 3, bflag))
+            assert torch.equal(dxf.buf, dxp.buf)
+            got = sums.sum(0)
+            tol = (2e-5 if dtype == DV_F32 else 2e-5) * float(want.abs().max()) + 1e-6
+            assert float((got - want[0]).abs().max()) <= tol, (name, float((got - want[0]).abs().max()), float(want.abs().max()))
 
 
 def test_pack_dgrad_and_cast(gpu):
