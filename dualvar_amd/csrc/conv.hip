@@ -1449,6 +1449,13 @@ static void pick_tile(int dtype, int M, int NP, int& bm, int& bn) {
   bm = pick_bm(M, ntn);
   static const int big = getenv("DUALVAR_F32_BM256") ? atoi(getenv("DUALVAR_F32_BM256")) : 1;
   if (dtype == DV_F32 && !f32_exact() && big && bm == 128 && bn == 64 && (int64_t)((M + 255) / 256) * ntn >= 512) bm = 256;
+  // Few rows (the 1 152-row layers of Mixed_5b/5c: 18 row tiles): 128-column tiles leave three quarters of the CUs without a
+  // workgroup while each busy CU runs one latency-bound K loop -- narrower tiles until the grid covers the chip
+  static const int fill = getenv("DUALVAR_CONV_FILL") ? atoi(getenv("DUALVAR_CONV_FILL")) : 256;
+  if (fill > 0 && bm == 64) {
+    const int64_t mt = (M + 63) / 64;
+    while (bn > 32 && mt * ((NP + bn - 1) / bn) < fill) bn >>= 1;
+  }
 }
 
 template <typename T, int MODE, int GVB, int GM, int NS, bool SPLIT = false, bool WF = false>
@@ -1502,6 +1509,8 @@ static void launch_gemm_gm(int bm, int bn, const ConvArgs& a, int grid, hipStrea
   }
   if constexpr (sizeof(T) == 4) {
     if constexpr (GM == 1) {                     // (only the pre-split-weight kernels are built with uniform-tap gathers)
+      // (four or six stages for the small grids, as for bf16, were measured SLOWER here: Mixed_5c 1x3x3 forward 57 -> 68 -> 71 us;
+      // with one workgroup per CU the K step is bound by its own ds_read -> split -> MFMA chain, not by the DMA round trip)
       launch_gemm_ns<T, MODE, GVB, 1, 2, true, true>(bm, bn, a, grid, s);
       return;
     } else {
