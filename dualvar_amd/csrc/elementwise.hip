@@ -597,6 +597,90 @@ __global__ void maxpool_bwd_kernel(PoolArgs a, const T* __restrict__ dy, const u
   }
 }
 
+// Backward of the pools with a 3x3 window, stride 2, padding 1 in (h, w) -- the stem pools (s3dg.py:139,145, 1x3x3 / 1x2x2;
+// resnet_2d3d.py:130) and MaxPool_4a (3x3x3 / 2x2x2) -- with any window along t.  A thread owns a 2x2 QUAD of input pixels:
+// together they are covered by the four windows (hq, wq) .. (hq+1, wq+1) only, so a thread loads four (dy, idx) vectors per
+// t-window and applies them to its pixels in nine compares, the same count for every thread -- the per-pixel gather has 1, 2,
+// 2 or 4 windows depending on the parity of the pixel (divergent trip counts) and loads every window vector four times.
+// Same sums, same (ascending tap) order as pool_gather.
+template <typename T>
+__global__ void maxpool_bwd_quad_kernel(PoolArgs a, FastDiv fWq, FastDiv fHq, const T* __restrict__ dy,
+                                        const uint8_t* __restrict__ idx, T* __restrict__ dx, int accumulate) {
+  constexpr int V = DT<T>::VEC;
+  const uint32_t CV = a.fcv.d;
+  const uint32_t total = (uint32_t)a.N * a.Ti * fHq.d * fWq.d * CV;
+  const int st1 = a.st - 1;
+  for (uint32_t i = xcd_block() * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    uint32_t q, cvi, wq_, hq_, ti_, n_;
+    fd_divmod(i, a.fcv, q, cvi);
+    fd_divmod(q, fWq, q, wq_);
+    fd_divmod(q, fHq, q, hq_);
+    fd_divmod(q, a.fTi, n_, ti_);
+    const int c0 = (int)cvi * V, wq = (int)wq_, hq = (int)hq_, ti = (int)ti_, n = (int)n_;
+    float acc[2][2][V];
+    bool pix[2][2];
+#pragma unroll
+    for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        pix[pa][pb] = 2 * hq + pa < a.Hi && 2 * wq + pb < a.Wi;
+        const size_t m = ((size_t)(n * a.Ti + ti) * a.Hi + 2 * hq + pa) * a.Wi + 2 * wq + pb;
+        if (accumulate && pix[pa][pb]) Pack16<T>::load(dx + m * a.ldx + c0, acc[pa][pb]);
+        else {
+#pragma unroll
+          for (int e = 0; e < V; ++e) acc[pa][pb][e] = 0.f;
+        }
+      }
+    const int tn = ti + a.pt;
+    const int t_hi = min(tn >> st1, a.To - 1), t_lo = max((tn - a.kt + 1 + st1) >> st1, 0);
+    for (int to = t_hi; to >= t_lo; --to) {
+      const int dt = tn - to * a.st;
+      float g[2][2][V];
+      uint32_t iw[2][2][V / 4];
+#pragma unroll
+      for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+        for (int wx = 0; wx < 2; ++wx) {
+          const bool ok = hq + wy < a.Ho && wq + wx < a.Wo;
+          const int64_t mo = (int64_t)((n * a.To + to) * a.Ho + hq + wy) * a.Wo + wq + wx;
+          if (ok) {
+            Pack16<T>::load(dy + mo * a.ldy + c0, g[wy][wx]);
+#pragma unroll
+            for (int j = 0; j < V / 4; ++j) iw[wy][wx][j] = reinterpret_cast<const uint32_t*>(idx + mo * a.CP + c0)[j];
+          } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) g[wy][wx][e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < V / 4; ++j) iw[wy][wx][j] = 0xffffffffu;
+          }
+        }
+      // pixel (pa, pb) lies in window (wy, wx) iff wy <= pa and wx <= pb, at tap (dh, dw) = (pa + 1 - 2 wy, pb + 1 - 2 wx)
+#pragma unroll
+      for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+          for (int wy = 1; wy >= 0; --wy)
+#pragma unroll
+            for (int wx = 1; wx >= 0; --wx) {
+              if (wy > pa || wx > pb) continue;
+              const uint32_t tap = (uint32_t)((dt * 3 + pa + 1 - 2 * wy) * 3 + pb + 1 - 2 * wx);
+#pragma unroll
+              for (int e = 0; e < V; ++e)
+                if (((iw[wy][wx][e >> 2] >> (8 * (e & 3))) & 0xffu) == tap) acc[pa][pb][e] += g[wy][wx][e];
+            }
+    }
+#pragma unroll
+    for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        if (!pix[pa][pb]) continue;
+        const size_t m = ((size_t)(n * a.Ti + ti) * a.Hi + 2 * hq + pa) * a.Wi + 2 * wq + pb;
+        Pack16<T>::store(dx + m * a.ldx + c0, acc[pa][pb]);
+      }
+  }
+}
+
 // ------------------------------------------------------------------ BatchNorm + ReLU + MaxPool3d as one pass each way
 // A pool that is the ONLY consumer of y = relu(x*scale + shift) (the stems: s3dg.py:138-151, resnet_2d3d.py:128-131) never
 // needs y in memory: the backward of that BatchNorm rebuilds the ReLU mask from x (DV_MASK_FROM_X) and the pool's own
@@ -1666,6 +1750,16 @@ extern "C" int dv_maxpool3d_bwd(const dv_pool_desc* d, const void* dy, const uin
     POOL_BWD_TILE(7, 2); POOL_BWD_TILE(7, 4); POOL_BWD_TILE(7, 8);
     POOL_BWD_TILE(14, 2); POOL_BWD_TILE(14, 4); POOL_BWD_TILE(14, 8);
 #undef POOL_BWD_TILE
+  }
+  static const bool no_quad = getenv("DUALVAR_POOL_NO_QUAD") && atoi(getenv("DUALVAR_POOL_NO_QUAD")) != 0;
+  if (!no_quad && a.kh == 3 && a.kw == 3 && a.sh == 2 && a.sw == 2 && a.ph == 1 && a.pw == 1 && (reinterpret_cast<uintptr_t>(idx) & 7) == 0) {
+    const int Hq = (a.Hi + 1) / 2, Wq = (a.Wi + 1) / 2;
+    DISPATCH_T(d->dtype, {
+      const int64_t total = (int64_t)a.N * a.Ti * Hq * Wq * (a.CP / DT<T>::VEC);
+      hipLaunchKernelGGL((maxpool_bwd_quad_kernel<T>), dim3(grid8_for(total, 16384)), dim3(kThreads), 0, ST(stream), a,
+                         make_fastdiv((uint32_t)Wq), make_fastdiv((uint32_t)Hq), (const T*)dy, idx, (T*)dx, (flags & DV_ACCUM) ? 1 : 0);
+    });
+    return dv_launch_status();
   }
   DISPATCH_T(d->dtype, {
     const int64_t total = (int64_t)a.N * a.Ti * a.Hi * a.Wi * (a.CP / DT<T>::VEC);

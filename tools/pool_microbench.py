@@ -18,6 +18,8 @@ from dualvar_amd import ops                # noqa: E402
 
 # (N, T, H, W, C, k, s, p)
 POOLS = {
+    'pool2a': (128, 4, 56, 56, 64, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    'pool3a': (128, 4, 28, 28, 192, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     'p3b': (128, 4, 14, 14, 192, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     'p3c': (128, 4, 14, 14, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     'pool4a': (128, 4, 14, 14, 480, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
