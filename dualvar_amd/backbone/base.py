@@ -21,7 +21,9 @@ _DTYPES = {'bf16': DV_BF16, 'bfloat16': DV_BF16, 'fp32': DV_F32, 'float32': DV_F
 
 
 def default_dtype():
-    return _DTYPES[os.environ.get('DUALVAR_DTYPE', 'bf16').lower()]
+    """fp32 -- the reference's arithmetic (no autocast anywhere in it) and the mode whose results are pinned to it at 1e-3;
+    bf16 storage is the opt-in throughput mode (model.set_compute_dtype('bf16'), pretrain.py --dtype bf16, DUALVAR_DTYPE=bf16)"""
+    return _DTYPES[os.environ.get('DUALVAR_DTYPE', 'fp32').lower()]
 
 
 class IngestOp(Op):

@@ -110,7 +110,8 @@ def parse_args(argv=None):
     p.add_argument('--visualize', action='store_true')
     p.add_argument('--test', default='', type=str)
     # this build
-    p.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'], help='activation storage dtype of the HIP engine')
+    p.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'],
+                   help='HIP engine arithmetic: fp32 = the reference\'s (parity mode); bf16 = bf16 activation storage (throughput mode)')
     p.add_argument('--steps', default=0, type=int, help='stop every epoch after this many iterations (0 = whole epoch)')
     p.add_argument('--epoch_size', default=1024, type=int, help='synthetic samples per epoch (whole job)')
     return p.parse_args(argv)

@@ -199,7 +199,9 @@ def test_full_size_16_frame_step_bf16(gpu):
     perm = torch.randperm(64, generator=g).to(gpu)
     with torch.no_grad():
         r1, r2 = m(block), m(block[perm])
-    assert abs(float(r1['clip_contrast_loss']) - float(r2['clip_contrast_loss'])) < 5e-2
+    # (bf16 storage after one SGD step on the random-init net: a permutation regroups the statistics' partial sums, and bf16
+    # rounding of the activations amplifies that to a few 1e-2 on a loss of ~4.8 -- observed 0.02 .. 0.055 from run to run)
+    assert abs(float(r1['clip_contrast_loss']) - float(r2['clip_contrast_loss'])) < 0.1
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
