@@ -43,7 +43,8 @@ class BnItem(C.Structure):
                 [(n, C.c_int32) for n in ('n_tiles', 'tile_rows', 'pitch', 'C', 'ldx', 'ldr', 'ldy', 'lddy', 'lddx', 'lddres',
                                           'fwd_flags', 'bwd_flags', 'n_rep')] +
                 [(n, C.c_float) for n in ('eps', 'momentum', 'inv_count', 'dparam_scale')] +
-                [(n, C.c_int32) for n in ('blk_stats', 'blk_apply', 'blk_red', 'blk_bapply')])
+                [(n, C.c_int32) for n in ('blk_stats', 'blk_apply', 'blk_red', 'blk_bapply')] +
+                [('red_ws', C.c_void_p)])
 
 
 class BnReduce(C.Structure):
@@ -64,7 +65,7 @@ class GemmDesc(C.Structure):
 
 
 P, I32, I64, F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
-RETURNS_INT64 = ('dv_conv3d_wgrad_workspace', 'dv_w3_bytes')       # everything else returns int
+RETURNS_INT64 = ('dv_conv3d_wgrad_workspace', 'dv_w3_bytes', 'dv_bn_bwd_reduce_workspace', 'dv_infonce_workspace')       # everything else returns int
 CD, PD = C.POINTER(ConvDesc), C.POINTER(PoolDesc)
 
 # name -> argtypes, exactly as declared in include/dualvar_hip.h
@@ -108,7 +109,8 @@ SIGNATURES = {
     'dv_bn_bwd_reduce_multi': [I32, P, I32, I32, P],
     'dv_bn_bwd_apply_multi': [I32, P, I32, I32, I32, P],
     'dv_bn_bwd_blocks': [I64, I32],
-    'dv_bn_bwd_reduce': [I32, P, I32, P, I32, P, I32, P, P, I64, I32, I32, P, I32, P],
+    'dv_bn_bwd_reduce': [I32, P, I32, P, I32, P, I32, P, P, I64, I32, I32, P, I32, P, P],
+    'dv_bn_bwd_reduce_workspace': [I64, I32],
     'dv_bn_bwd_apply': [I32, P, I32, P, I32, P, I32, P, P, P, P, I32, F, F, P, P, P, I32, P, I32, I64, I32, I32, P],
     'dv_maxpool3d_fwd': [PD, P, P, P, P],
     'dv_maxpool3d_bwd': [PD, P, P, P, I32, P],
@@ -126,7 +128,8 @@ SIGNATURES = {
     'dv_relu_bwd_f32': [P, P, I64, P, P],
     'dv_mean_f32': [P, I32, P, P],
     'dv_ntxent_fwd': [P, P, I32, I32, I32, I32, I32, F, P, P, P, P, P],
-    'dv_infonce_fwd': [P, P, P, I32, I32, I32, F, P, P, P, P, P, P],
+    'dv_infonce_fwd': [P, P, P, I32, I32, I32, F, P, P, P, P, P, P, I64, P],
+    'dv_infonce_workspace': [I32, I32, I32],
     'dv_rank_margin': [P, I32, I32, I32, F, F, F, P, P, P, P, P],
     'dv_gemm_f32': [I32, I32, I32, P, I64, I64, P, I64, I64, P, I64, F, I32, P],
     'dv_gemm_f32_grouped': [P, I32, I32, P],

@@ -337,16 +337,84 @@ __device__ __forceinline__ void column_reduce(int64_t r_begin, int64_t r_end, in
   }
 }
 
+// Tail of an ordered reduction over the nblk blocks of one item, each of which has stored NO = 2*CP partial sums to
+// ws[bid][NO].  Two levels, so that no single block has to walk hundreds of partial rows: the block that takes the last
+// ticket of its group of kFoldGroup blocks adds the group's rows in block order into a group row; the block that takes the
+// last group ticket adds the group rows in group order and WRITES out[NO].  Fences at agent scope around the tickets; after
+// the acquire the rows are read with ordinary (unrolled) loads.  Layout of ws: [nblk][NO] rows, [ngrp][NO] group rows,
+// [ngrp + 1] ticket words (zero on entry, zero again on exit).
+constexpr int kFoldGroup = 32;
+static inline int64_t ordered_fold_floats(int nblk, int CP) {
+  const int ngrp = (nblk + kFoldGroup - 1) / kFoldGroup;
+  return (int64_t)(nblk + ngrp) * 2 * CP + ((ngrp + 1 + 7) & ~7);
+}
+// Rows and tickets travel as agent-scope relaxed atomics (stores / loads with sc1: coherent across the XCDs' L2s on their own),
+// ordered by a plain s_waitcnt -- NOT by agent-scope fences: a release fence is a write-back of the whole L2 (buffer_wbl2) and
+// an acquire fence an invalidate, from every one of the thousands of blocks of a launch; measured, they took the reduce
+// launches of the S3D-G step from 1.4 to 4.0 - 7.9 ms.
+__device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float coherent_load(const float* p) {
+  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ void fold_rows(const float* __restrict__ rows, int n, int NO, int C, int CP, float* __restrict__ dst,
+                                          bool coherent_dst) {
+  for (int i = threadIdx.x; i < NO; i += blockDim.x) {
+    const int c = i < CP ? i : i - CP;
+    float t = 0.f;
+    if (c < C) {
+      int b = 0;
+      for (; b + 8 <= n; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = coherent_load(rows + (size_t)(b + u) * NO + i);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+      }
+      for (; b < n; ++b) t += coherent_load(rows + (size_t)b * NO + i);
+    }
+    if (coherent_dst) coherent_store(dst + i, t);
+    else dst[i] = t;
+  }
+}
+__device__ __forceinline__ void ordered_fold(float* __restrict__ ws, uint32_t bid, uint32_t nblk, int C, int CP, float* __restrict__ out) {
+  __shared__ uint32_t last;
+  const int NO = 2 * CP;
+  const uint32_t ngrp = (nblk + kFoldGroup - 1) / kFoldGroup, grp = bid / kFoldGroup;
+  const uint32_t gsize = min((uint32_t)kFoldGroup, nblk - grp * kFoldGroup);
+  float* grows = ws + (size_t)nblk * NO;
+  uint32_t* tick = reinterpret_cast<uint32_t*>(grows + (size_t)ngrp * NO);
+  stores_done();                                     // this block's row has reached the coherence point ...
+  __syncthreads();
+  if (threadIdx.x == 0) last = (atomicAdd(tick + grp, 1u) == gsize - 1) ? 1u : 0u;       // ... before its ticket is taken
+  __syncthreads();
+  if (!last) return;
+  fold_rows(ws + (size_t)grp * kFoldGroup * NO, (int)gsize, NO, C, CP, grows + (size_t)grp * NO, true);
+  if (threadIdx.x == 0) __hip_atomic_store(tick + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  stores_done();
+  __syncthreads();
+  if (threadIdx.x == 0) last = (atomicAdd(tick + ngrp, 1u) == ngrp - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!last) return;
+  fold_rows(grows, (int)ngrp, NO, C, CP, out, false);
+  if (threadIdx.x == 0) __hip_atomic_store(tick + ngrp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename T>
 __device__ __forceinline__ void bn_bwd_reduce_body(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
                                                    const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                                    const float* __restrict__ invstd, int64_t M, int C, int CP, int flags,
                                                    int64_t rows_per_block, float* __restrict__ sums_all, int n_rep,
                                                    uint32_t bid, const float* __restrict__ scale = nullptr,
-                                                   const float* __restrict__ shift = nullptr) {
+                                                   const float* __restrict__ shift = nullptr, float* __restrict__ ws = nullptr,
+                                                   uint32_t nblk = 0) {
   constexpr int V = DT<T>::VEC;
-  // atomics on one address serialise at the memory side (~12 ns each): spread the blocks over n_rep replicas
-  float* sums = sums_all + (size_t)(bid % n_rep) * 2 * CP;
+  // Ordered mode (ws != nullptr): the block stores its partial sums to ws[bid][2][CP]; the block that arrives last (ticket
+  // behind the partials, agent-scope fences) adds the partials in block order into sums_all[0] -- no float atomics, so the sums
+  // do not depend on the order blocks finish in.  Legacy mode: atomics, spread over n_rep replicas because atomics on one
+  // address serialise at the memory side (~12 ns each).
+  float* sums = ws ? ws + (size_t)bid * 2 * CP : sums_all + (size_t)(bid % n_rep) * 2 * CP;
   const int64_t r0 = (int64_t)bid * rows_per_block;
   const int64_t r1 = min(M, r0 + rows_per_block);
   const bool mask = !(flags & DV_NO_RELU_MASK);
@@ -372,21 +440,26 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const T* __restrict__ dy, int
       [&](int c0, float(&acc)[2][V]) {
 #pragma unroll
         for (int e = 0; e < V; ++e)
-          if (c0 + e < C) { atomicAdd(sums + c0 + e, acc[0][e]); atomicAdd(sums + CP + c0 + e, acc[1][e]); }
+          if (c0 + e < C) {
+            if (ws) { coherent_store(sums + c0 + e, acc[0][e]); coherent_store(sums + CP + c0 + e, acc[1][e]); }
+            else { atomicAdd(sums + c0 + e, acc[0][e]); atomicAdd(sums + CP + c0 + e, acc[1][e]); }
+          }
       },
       [&](int c0) {
         load_params<V>(mean, c0, mu);
         load_params<V>(invstd, c0, is);
         if (fromx) { load_params<V>(scale, c0, sc); load_params<V>(shift, c0, sh); }
       });
+  if (ws) ordered_fold(ws, bid, nblk, C, CP, sums_all);
 }
 
 template <typename T>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
                                      const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                      const float* __restrict__ invstd, int64_t M, int C, int CP, int flags,
-                                     int64_t rows_per_block, float* __restrict__ sums_all, int n_rep) {
-  bn_bwd_reduce_body<T>(dy, lddy, y, ldy, x, ldx, mean, invstd, M, C, CP, flags, rows_per_block, sums_all, n_rep, blockIdx.x);
+                                     int64_t rows_per_block, float* __restrict__ sums_all, int n_rep, float* __restrict__ ws) {
+  bn_bwd_reduce_body<T>(dy, lddy, y, ldy, x, ldx, mean, invstd, M, C, CP, flags, rows_per_block, sums_all, n_rep, blockIdx.x,
+                        nullptr, nullptr, ws, gridDim.x);
 }
 
 template <typename T>
@@ -397,7 +470,7 @@ __global__ void bn_bwd_reduce_multi_kernel(const dv_bn_item* __restrict__ items,
   const int CP = (it.C + 7) & ~7;
   const int64_t rpb = (it.M + nblk - 1) / nblk;
   bn_bwd_reduce_body<T>((const T*)it.dy, it.lddy, (const T*)it.y, it.ldy, (const T*)it.x, it.ldx, it.mean, it.invstd, it.M,
-                        it.C, CP, it.bwd_flags, rpb, it.sums, it.n_rep, bid, it.scale, it.shift);
+                        it.C, CP, it.bwd_flags, rpb, it.sums, it.n_rep, bid, it.scale, it.shift, it.red_ws, nblk);
 }
 
 // partials [n_blocks][W] -> out[W] (+=): 32 columns x 8 row lanes per block
@@ -1222,58 +1295,54 @@ static bool pool_tile_off() {
 // One workgroup per (sample, slice of the S positions): with one workgroup per sample (N = 128) half the CUs had no
 // work and the others one resident workgroup each (~1.5 TB/s).  Slices are added with fp32 atomics into the zeroed
 // output (the host wrappers memset it on the same stream).
+// Per-sample column sums over the S positions.  Large levels are split over CHANNEL chunks (grid.y, `ccv` 16-byte vectors =
+// >= 256 bytes of a row each), not over positions: every output element has one owner, so there are no float atomics and no
+// memset in front -- the results do not depend on the order workgroups finish in.
 template <typename T>
-__global__ void spatial_mean_kernel(const T* __restrict__ x, int ldx, int S, int C, int CP, float* __restrict__ out) {
+__global__ void spatial_mean_kernel(const T* __restrict__ x, int ldx, int S, int C, int CP, int ccv, float* __restrict__ out) {
   constexpr int V = DT<T>::VEC;
   const int n = blockIdx.x;
   const float inv = 1.f / (float)S;
-  const int rps = (S + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int s0 = (int)blockIdx.y * rps, s1 = min(S, s0 + rps);
-  if (s0 >= s1) return;
+  const int cb = (int)blockIdx.y * ccv * V, cpl = min(ccv * V, CP - cb);
+  if (cpl <= 0) return;
   column_reduce<V, 1>(
-      (int64_t)n * S + s0, (int64_t)n * S + s1, CP,
+      (int64_t)n * S, (int64_t)(n + 1) * S, cpl,
       [&](int64_t r, int c0, float(&acc)[1][V]) {
         float v[V];
-        Pack16<T>::load(x + r * ldx + c0, v);
+        Pack16<T>::load(x + r * ldx + cb + c0, v);
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[0][e] += v[e];
       },
       [&](int c0, float(&acc)[1][V]) {
 #pragma unroll
         for (int e = 0; e < V; ++e)
-          if (c0 + e < C) {
-            if (gridDim.y > 1) atomicAdd(out + (size_t)n * C + c0 + e, acc[0][e] * inv);
-            else out[(size_t)n * C + c0 + e] = acc[0][e] * inv;
-          }
+          if (cb + c0 + e < C) out[(size_t)n * C + cb + c0 + e] = acc[0][e] * inv;
       });
 }
 
 template <typename T>
 __global__ void gate_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx,
-                                       const float* __restrict__ g, int S, int C, int CP, float* __restrict__ dpre,
+                                       const float* __restrict__ g, int S, int C, int CP, int ccv, float* __restrict__ dpre,
                                        int x_is_output) {
   constexpr int V = DT<T>::VEC;
   const int n = blockIdx.x;
-  const int rps = (S + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int s0 = (int)blockIdx.y * rps, s1 = min(S, s0 + rps);
-  if (s0 >= s1) return;
+  const int cb = (int)blockIdx.y * ccv * V, cpl = min(ccv * V, CP - cb);
+  if (cpl <= 0) return;
   column_reduce<V, 1>(
-      (int64_t)n * S + s0, (int64_t)n * S + s1, CP,
+      (int64_t)n * S, (int64_t)(n + 1) * S, cpl,
       [&](int64_t r, int c0, float(&acc)[1][V]) {
         float a[V], b[V];
-        Pack16<T>::load(dy + r * lddy + c0, a);
-        Pack16<T>::load(x + r * ldx + c0, b);
+        Pack16<T>::load(dy + r * lddy + cb + c0, a);
+        Pack16<T>::load(x + r * ldx + cb + c0, b);
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[0][e] += a[e] * b[e];
       },
       [&](int c0, float(&acc)[1][V]) {
 #pragma unroll
         for (int e = 0; e < V; ++e)
-          if (c0 + e < C) {
-            float gg = g[(size_t)n * C + c0 + e];
-            const float r = x_is_output ? acc[0][e] * (1.f - gg) : acc[0][e] * gg * (1.f - gg);
-            if (gridDim.y > 1) atomicAdd(dpre + (size_t)n * C + c0 + e, r);
-            else dpre[(size_t)n * C + c0 + e] = r;
+          if (cb + c0 + e < C) {
+            const float gg = g[(size_t)n * C + cb + c0 + e];
+            dpre[(size_t)n * C + cb + c0 + e] = x_is_output ? acc[0][e] * (1.f - gg) : acc[0][e] * gg * (1.f - gg);
           }
       });
 }
@@ -1634,10 +1703,11 @@ extern "C" int dv_bn_bwd_blocks(int64_t M, int32_t C) {
 
 extern "C" int dv_bn_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                                 int32_t ldx, const float* mean, const float* invstd, int64_t M, int32_t C, int32_t flags,
-                                float* sums, int32_t n_rep, void* stream) {
+                                float* sums, int32_t n_rep, float* ws, void* stream) {
   const int CP = cp8(C);
   const bool mask = !(flags & DV_NO_RELU_MASK);
   if (!dy || !x || (mask && !y) || !mean || !invstd || !sums || M <= 0 || C <= 0 || n_rep <= 0) return DV_EINVAL;
+  if (ws && (reinterpret_cast<uintptr_t>(ws) & 3)) return DV_EALIGN;
   if (lddy < CP || ldx < CP || (mask && ldy < CP)) return DV_EINVAL;
   if (!aligned16(dy) || !aligned16(x) || (mask && !aligned16(y)) || !aligned16(mean) || !aligned16(invstd)) return DV_EALIGN;
   const int blocks = dv_bn_bwd_blocks(M, C);
@@ -1646,9 +1716,14 @@ extern "C" int dv_bn_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, con
     constexpr int V = DT<T>::VEC;
     if (lddy % V || ldx % V || (mask && ldy % V)) return DV_EALIGN;
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(blocks), dim3(kThreads), 0, ST(stream), (const T*)dy, lddy,
-                       (const T*)y, ldy, (const T*)x, ldx, mean, invstd, M, C, CP, flags, rpb, sums, n_rep);
+                       (const T*)y, ldy, (const T*)x, ldx, mean, invstd, M, C, CP, flags, rpb, sums, n_rep, ws);
   });
   return dv_launch_status();
+}
+
+extern "C" int64_t dv_bn_bwd_reduce_workspace(int64_t M, int32_t C) {
+  if (M <= 0 || C <= 0) return 0;
+  return ordered_fold_floats(dv_bn_bwd_blocks(M, C), cp8(C)) * (int64_t)sizeof(float);
 }
 
 extern "C" int dv_bn_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
@@ -1823,13 +1898,14 @@ extern "C" int dv_bn_bwd_apply_maxpool(const dv_pool_desc* d, const void* dy_poo
   return dv_launch_status();
 }
 
-// slices of the S positions per sample: ~1024 workgroups in all, at least 128 positions each (below that the extra
-// memset + atomics cost more than the idle CUs)
-static int s_splits(int N, int S) {
-  int sp = (1024 + N - 1) / N;
-  const int cap = S / 128 > 0 ? S / 128 : 1;
-  if (sp > cap) sp = cap;
-  return sp < 1 ? 1 : sp;
+// channel chunks per sample (16-byte vectors per chunk): ~1024 workgroups in all, at least 16 vectors (256 bytes of a row) each,
+// and one chunk when a sample has fewer than 128 positions (the row groups of one workgroup cover it)
+static int c_chunk_vecs(int N, int S, int CV) {
+  int chunks = (1024 + N - 1) / N;
+  const int cap = (CV + 15) / 16;
+  if (chunks > cap) chunks = cap;
+  if (chunks < 1 || S < 128) chunks = 1;
+  return (CV + chunks - 1) / chunks;
 }
 
 extern "C" int dv_spatial_mean(int32_t dtype, const void* x, int32_t ldx, int32_t N, int32_t S, int32_t C, float* out,
@@ -1839,10 +1915,9 @@ extern "C" int dv_spatial_mean(int32_t dtype, const void* x, int32_t ldx, int32_
   if (!aligned16(x)) return DV_EALIGN;
   DISPATCH_T(dtype, {
     if (ldx % DT<T>::VEC) return DV_EALIGN;
-    const int sp = s_splits(N, S);
-    if (sp > 1 && hipMemsetAsync(out, 0, (size_t)N * C * sizeof(float), ST(stream)) != hipSuccess) return dv_launch_status();
-    hipLaunchKernelGGL((spatial_mean_kernel<T>), dim3(N, sp), dim3(kThreads), 0, ST(stream), (const T*)x, ldx, S, C,
-                       CP, out);
+    const int CV = CP / DT<T>::VEC, ccv = c_chunk_vecs(N, S, CV);
+    hipLaunchKernelGGL((spatial_mean_kernel<T>), dim3(N, (CV + ccv - 1) / ccv), dim3(kThreads), 0, ST(stream), (const T*)x, ldx, S,
+                       C, CP, ccv, out);
   });
   return dv_launch_status();
 }
@@ -1888,10 +1963,9 @@ extern "C" int dv_gate_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, c
   if (!aligned16(dy) || !aligned16(x)) return DV_EALIGN;
   DISPATCH_T(dtype, {
     if (lddy % DT<T>::VEC || ldx % DT<T>::VEC) return DV_EALIGN;
-    const int sp = s_splits(N, S);
-    if (sp > 1 && hipMemsetAsync(dpre, 0, (size_t)N * C * sizeof(float), ST(stream)) != hipSuccess) return dv_launch_status();
-    hipLaunchKernelGGL((gate_bwd_reduce_kernel<T>), dim3(N, sp), dim3(kThreads), 0, ST(stream), (const T*)dy, lddy,
-                       (const T*)x, ldx, g, S, C, CP, dpre, x_is_output);
+    const int CV = CP / DT<T>::VEC, ccv = c_chunk_vecs(N, S, CV);
+    hipLaunchKernelGGL((gate_bwd_reduce_kernel<T>), dim3(N, (CV + ccv - 1) / ccv), dim3(kThreads), 0, ST(stream), (const T*)dy,
+                       lddy, (const T*)x, ldx, g, S, C, CP, ccv, dpre, x_is_output);
   });
   return dv_launch_status();
 }

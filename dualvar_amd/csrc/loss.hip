@@ -173,8 +173,10 @@ __global__ __launch_bounds__(256) void gemm_f32_tile4_kernel(dv_gemm_desc d) {
 __global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(int M, int N, int K, const float* __restrict__ A, int64_t sam,
                                                                int64_t sak, const float* __restrict__ B, int64_t sbk,
                                                                int64_t sbn, float* __restrict__ C, int64_t ldc, float alpha,
-                                                               int tiles_n, int tiles, int kslice) {
+                                                               int tiles_n, int tiles, int kslice, float* __restrict__ ws,
+                                                               int splits, int accumulate) {
   __shared__ float red[3][16][64];
+  __shared__ uint32_t last;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x % tiles, slice = blockIdx.x / tiles;
   const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
@@ -204,13 +206,54 @@ __global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(int M, int N, int 
     for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
   }
   __syncthreads();
-  if (wave == 0 && nok) {
+  if (ws == nullptr) {
+    if (wave == 0 && nok) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (row < M) atomicAdd(C + (int64_t)row * ldc + n, alpha * (((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane]));
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < M) atomicAdd(C + (int64_t)row * ldc + n, alpha * (((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane]));
+      }
+    }
+    return;
+  }
+  // Ordered form: the slice's 32x32 partial goes to ws[slice][tile][16][64]; the workgroup that takes the last ticket of its
+  // tile adds the slices in order and writes C -- no float atomics, the result does not depend on the arrival order.
+  float* part = ws + ((size_t)slice * tiles + tile) * 1024;
+  // (partial tiles and tickets as agent-scope relaxed atomics ordered by s_waitcnt, not by agent-scope fences: see
+  // elementwise.hip, ordered_fold)
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      __hip_atomic_store(part + r * 64 + lane, ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
+  uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + (size_t)splits * tiles * 1024) + tile;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) last = (atomicAdd(ticket, 1u) == (uint32_t)splits - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!last) return;
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const int r = i >> 6, ln = i & 63;
+    const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = n0 + (ln & 31);
+    float t = 0.f;
+    const float* src = ws + (size_t)tile * 1024 + i;
+    const size_t pitch = (size_t)tiles * 1024;
+    int sl = 0;
+    for (; sl + 8 <= splits; sl += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(const_cast<float*>(src) + (size_t)(sl + u) * pitch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; sl < splits; ++sl) t += __hip_atomic_load(const_cast<float*>(src) + (size_t)sl * pitch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (row < M && col < N) {
+      float* c = C + (int64_t)row * ldc + col;
+      *c = accumulate ? *c + alpha * t : alpha * t;
     }
   }
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ void zero_matrix_kernel(float* __restrict__ C, int64_t ldc, int M, int N) {
@@ -218,22 +261,43 @@ __global__ void zero_matrix_kernel(float* __restrict__ C, int64_t ldc, int M, in
   if (i < M * N) C[(int64_t)(i / N) * ldc + i % N] = 0.f;
 }
 
-static int launch_gemm_f32(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
-                           int64_t sbn, float* C, int64_t ldc, float alpha, int accumulate, hipStream_t s) {
-  const int tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32;
-  const int tiles = tiles_m * tiles_n;
+// split-K plan of launch_gemm_f32 (0 splits: the GEMM does not take the split path)
+static void gemm_splitk_plan(int M, int N, int K, int& tiles, int& tiles_n, int& splits, int& kslice) {
+  const int tiles_m = (M + 31) / 32;
+  tiles_n = (N + 31) / 32;
+  tiles = tiles_m * tiles_n;
+  splits = 0; kslice = 0;
   if (tiles <= 64 && K >= 4096) {
-    int splits = 1024 / tiles;
+    splits = 1024 / tiles;
     if (splits > K / 256) splits = K / 256;
-    const int kslice = (((K + splits - 1) / splits) + 63) / 64 * 64;
+    kslice = (((K + splits - 1) / splits) + 63) / 64 * 64;
     splits = (K + kslice - 1) / kslice;
+  }
+}
+static int64_t gemm_splitk_ws_bytes(int M, int N, int K) {
+  int tiles, tiles_n, splits, kslice;
+  gemm_splitk_plan(M, N, K, tiles, tiles_n, splits, kslice);
+  return splits ? ((int64_t)splits * tiles * 1024 + ((tiles + 7) & ~7)) * 4 : 0;
+}
+
+static int launch_gemm_f32(int M, int N, int K, const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
+                           int64_t sbn, float* C, int64_t ldc, float alpha, int accumulate, hipStream_t s,
+                           float* ws = nullptr, int64_t ws_bytes = 0) {
+  int tiles, tiles_n, splits, kslice;
+  gemm_splitk_plan(M, N, K, tiles, tiles_n, splits, kslice);
+  if (splits) {
+    if (ws && ws_bytes >= gemm_splitk_ws_bytes(M, N, K)) {          // ordered: partial tiles + tickets, no atomics, no memset
+      hipLaunchKernelGGL(gemm_f32_splitk_kernel, dim3(tiles * splits), dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc,
+                         alpha, tiles_n, tiles, kslice, ws, splits, accumulate);
+      return dv_launch_status();
+    }
     if (!accumulate) {
       hipLaunchKernelGGL(zero_matrix_kernel, dim3((M * N + 255) / 256), dim3(256), 0, s, C, ldc, M, N);
       int rc = dv_launch_status();
       if (rc) return rc;
     }
     hipLaunchKernelGGL(gemm_f32_splitk_kernel, dim3(tiles * splits), dim3(256), 0, s, M, N, K, A, sam, sak, B, sbk, sbn, C, ldc,
-                       alpha, tiles_n, tiles, kslice);
+                       alpha, tiles_n, tiles, kslice, (float*)nullptr, splits, accumulate);
     return dv_launch_status();
   }
   if (tiles <= 1024 && K >= 64) {          // few tiles: one workgroup per tile, K over its four waves
@@ -475,10 +539,15 @@ extern "C" int dv_ntxent_fwd(const float* rows, const float* cols, int32_t R, in
   return dv_launch_status();
 }
 
+extern "C" int64_t dv_infonce_workspace(int32_t B, int32_t D, int32_t K) {
+  return (B > 0 && D > 0 && K > 0) ? gemm_splitk_ws_bytes(B, D, K) : 0;
+}
+
 extern "C" int dv_infonce_fwd(const float* q, const float* k, const float* queue, int32_t B, int32_t D, int32_t K,
                               float inv_T, float* logits, float* loss_rows, int32_t* rank0, float* dlogits, float* dq,
-                              void* stream) {
+                              float* workspace, int64_t workspace_bytes, void* stream) {
   if (!q || !k || !queue || !logits || !loss_rows || !rank0 || !dlogits || !dq || B <= 0 || D <= 0 || K <= 0) return DV_EINVAL;
+  if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 3)) return DV_EALIGN;
   // logits[:,1:] = q . queue * inv_T      (queue is [D][K]: B operand strides (K, 1))
   int rc = launch_gemm_f32(B, K, D, q, D, 1, queue, K, 1, logits + 1, K + 1, inv_T, 0, ST(stream));
   if (rc) return rc;
@@ -487,7 +556,7 @@ extern "C" int dv_infonce_fwd(const float* q, const float* k, const float* queue
   rc = dv_launch_status();
   if (rc) return rc;
   // dq = dlogits[:,1:] . queue^T + dlogits[:,0] * k
-  rc = launch_gemm_f32(B, D, K, dlogits + 1, K + 1, 1, queue, 1, K, dq, D, 1.f, 0, ST(stream));
+  rc = launch_gemm_f32(B, D, K, dlogits + 1, K + 1, 1, queue, 1, K, dq, D, 1.f, 0, ST(stream), workspace, workspace_bytes);
   if (rc) return rc;
   hipLaunchKernelGGL(axpy_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, ST(stream), dlogits, (int64_t)(K + 1), k, B, D, dq);
   return dv_launch_status();

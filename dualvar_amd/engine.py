@@ -25,7 +25,7 @@ from ._lib import DV_MASK_FROM_X
 from .ops import DV_ACCUM, DV_BF16, DV_BIAS, DV_F32, DV_NO_RELU_MASK, DV_RELU, DV_SIGMOID, DV_STATS, Act, cp8
 
 
-BN_REPLICAS = 8       # replicas of the BN-backward atomic accumulators (dv_bn_bwd_reduce)
+BN_REPLICAS = 1       # the BN-backward sums are reduced in block order (dv_bn_bwd_reduce's ordered form): one final copy
 
 
 def _align8(n):
@@ -909,6 +909,8 @@ class BNMember:
         self.mask_from_x = bool(relu) and residual is None
         self.sums_off = plan.reserve_zero(BN_REPLICAS * 2 * self.CP) if plan.with_grad else 0
         self.sums_len = BN_REPLICAS * 2 * self.CP
+        # per-block partial sums + ticket of the ordered backward reduce (zero once: the kernel leaves the ticket zero)
+        self.red_ws = plan.f32(int(plan.lib.dv_bn_bwd_reduce_workspace(self.M, self.C)) // 4) if plan.with_grad else None
 
 
 class BNGroupOp(Op):
@@ -966,6 +968,7 @@ class BNGroupOp(Op):
                 it.dy, it.lddy, it.dx, it.lddx = y.grad.ptr, y.grad.ld, x.grad.ptr, x.grad.ld
                 it.dres, it.lddres = (dres.ptr, dres.ld) if dres is not None else (0, 0)
                 it.sums, it.n_rep = p.zero_ptr(m.sums_off), BN_REPLICAS
+                it.red_ws = m.red_ws.data_ptr()
                 it.dgamma, it.dbeta = st.w_grad(gs), st.w_grad(bs)
                 it.inv_count, it.dparam_scale = 1.0 / (m.M * R), 1.0 / R
                 it.bwd_flags = mflag | (DV_ACCUM if (dres is not None and self.acc.get('res%d' % i)) else 0)
@@ -1058,7 +1061,8 @@ class BNGroupOp(Op):
                 if not m.reduce_fused:
                     b_red.append(Launch('bn_bwd_reduce', 'bn_bwd_reduce<%s>' % dt, lib.dv_bn_bwd_reduce,
                                         (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, m.mean.data_ptr(), m.invstd.data_ptr(),
-                                         M, Cn, mflag, sums, BN_REPLICAS), _abytes(x) * nact, 0, 'M%d C%d' % (M, Cn)))
+                                         M, Cn, mflag, sums, BN_REPLICAS, m.red_ws.data_ptr()), _abytes(x) * nact, 0,
+                                        'M%d C%d' % (M, Cn)))
                 dres = res.grad if (res is not None and res.grad is not None) else None
                 bflags = mflag | (DV_ACCUM if (dres is not None and self.acc.get('res%d' % i)) else 0)
                 nres = 0 if dres is None else (2 if bflags & DV_ACCUM else 1)

@@ -219,6 +219,9 @@ def ntxent(rows, cols, n_local, N, row_index0, temperature):
     return _NTXentFn.apply(rows, cols, n_local, N, row_index0, 1.0 / temperature)
 
 
+_INFONCE_WS = {}
+
+
 class _InfoNCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, queue, inv_T):
@@ -233,8 +236,14 @@ class _InfoNCEFn(torch.autograd.Function):
         rank0 = torch.empty(B, dtype=torch.int32, device=dev)
         dq = torch.empty(B, D, dtype=torch.float32, device=dev)
         lib, s = _lib(), ops.stream_ptr()
+        wsb = int(lib.dv_infonce_workspace(B, D, K))
+        key = (dev, wsb)
+        ws = _INFONCE_WS.get(key)          # ordered K-split of dq: zeroed once, the kernel leaves its tickets zero
+        if ws is None and wsb:
+            ws = _INFONCE_WS[key] = torch.zeros(wsb // 4, dtype=torch.float32, device=dev)
         _chk(lib.dv_infonce_fwd(q.data_ptr(), k.data_ptr(), queue.data_ptr(), B, D, K, inv_T, logits.data_ptr(),
-                                loss_rows.data_ptr(), rank0.data_ptr(), dlog.data_ptr(), dq.data_ptr(), s), 'dv_infonce_fwd')
+                                loss_rows.data_ptr(), rank0.data_ptr(), dlog.data_ptr(), dq.data_ptr(),
+                                ws.data_ptr() if ws is not None else 0, wsb, s), 'dv_infonce_fwd')
         loss = torch.empty((), dtype=torch.float32, device=dev)
         _chk(lib.dv_mean_f32(loss_rows.data_ptr(), B, loss.data_ptr(), s), 'mean')
         ctx.save_for_backward(dq)
@@ -387,9 +396,10 @@ class _BN1dTrainFn(torch.autograd.Function):
         g = _f32c(dy)
         gs, bs = st.slot(bn.weight), st.slot(bn.bias)
         sums = torch.zeros(2 * Fd, dtype=torch.float32, device=x.device)
+        ws = torch.zeros(int(lib.dv_bn_bwd_reduce_workspace(n, Fd)) // 4, dtype=torch.float32, device=x.device)
         no_mask = 32                                                     # DV_NO_RELU_MASK
         _chk(lib.dv_bn_bwd_reduce(DV_F32, g.data_ptr(), Fd, y.data_ptr(), Fd, x.data_ptr(), Fd, mean.data_ptr(), invstd.data_ptr(),
-                                  n, Fd, no_mask, sums.data_ptr(), 1, s), 'bn1d bwd reduce')
+                                  n, Fd, no_mask, sums.data_ptr(), 1, ws.data_ptr(), s), 'bn1d bwd reduce')
         dx = torch.empty_like(x)
         _chk(lib.dv_bn_bwd_apply(DV_F32, g.data_ptr(), Fd, y.data_ptr(), Fd, x.data_ptr(), Fd, mean.data_ptr(), invstd.data_ptr(),
                                  st.w_master(gs), sums.data_ptr(), 1, 1.0 / n, 1.0, st.w_grad(gs), st.w_grad(bs), dx.data_ptr(), Fd,

@@ -296,6 +296,7 @@ typedef struct dv_bn_item {
   int32_t fwd_flags, bwd_flags, n_rep;
   float eps, momentum, inv_count, dparam_scale;
   int32_t blk_stats, blk_apply, blk_red, blk_bapply;
+  float* red_ws;   /* ordered backward reduce: dv_bn_bwd_reduce_workspace(M, C) bytes (see dv_bn_bwd_reduce), or NULL */
 } dv_bn_item;
 int dv_bn_stats_multi(const dv_bn_item* items, int32_t n, int32_t finalize, int32_t total_blocks, void* stream);
 /* dv_bn_finalize for every member of the group in one launch (multi-rank step, after the all-gather): item i's rows of the
@@ -307,10 +308,16 @@ int dv_bn_bwd_reduce_multi(int32_t dtype, const dv_bn_item* items, int32_t n, in
 int dv_bn_bwd_apply_multi(int32_t dtype, const dv_bn_item* items, int32_t n, int32_t total_blocks, int32_t max_c,
                           void* stream);
 int dv_bn_bwd_blocks(int64_t M, int32_t C);
+/* sums[2][CP] = (sum g, sum g*xhat).  ORDERED form (ws != NULL): every block stores its partial sums to ws, the block that
+ * arrives last adds them in block order and WRITES sums[0 .. 2*CP) -- no float atomics, the result does not depend on the
+ * order blocks finish in; n_rep is ignored and dv_bn_bwd_apply takes n_rep = 1.  ws: dv_bn_bwd_reduce_workspace(M, C) bytes
+ * ([blocks][2][CP] partials, one row per group of 32 blocks, ticket words), ZERO before the first use (the kernel leaves the
+ * tickets zero).
+ * Atomic form (ws == NULL): sums[n_rep][2][CP] pre-zeroed by the caller, accumulated with float atomics over n_rep replicas. */
+int64_t dv_bn_bwd_reduce_workspace(int64_t M, int32_t C);
 int dv_bn_bwd_reduce(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                      int32_t ldx, const float* mean, const float* invstd, int64_t M, int32_t C,
-                     int32_t flags, float* sums /*[n_rep][2][CP], pre-zeroed, accumulated atomically*/, int32_t n_rep,
-                     void* stream);
+                     int32_t flags, float* sums, int32_t n_rep, float* ws, void* stream);
 int dv_bn_bwd_apply(int32_t dtype, const void* dy, int32_t lddy, const void* y, int32_t ldy, const void* x,
                     int32_t ldx, const float* mean, const float* invstd, const float* gamma,
                     const float* sums /*[n_rep][2][CP], global (all-reduced) sums*/, int32_t n_rep, float inv_count,
@@ -404,9 +411,13 @@ int dv_relu_bwd_f32(const float* dy, const float* y, int64_t n, float* dx, void*
 int dv_ntxent_fwd(const float* rows, const float* cols, int32_t R, int32_t n_local, int32_t N, int32_t D,
                   int32_t row_index0, float inv_T, float* logits, float* loss_rows, int32_t* rank0,
                   float* dsim, void* stream);
+/* workspace (optional): dv_infonce_workspace(B, D, K) bytes, ZERO before the first use (the kernel leaves its ticket words
+ * zero).  With it the K-split dq = dlogits . queue^T sums its slices in slice order (the last workgroup of a tile adds the
+ * partial tiles): no float atomics, run-to-run identical bits.  NULL: fp32 atomics. */
+int64_t dv_infonce_workspace(int32_t B, int32_t D, int32_t K);
 int dv_infonce_fwd(const float* q, const float* k, const float* queue, int32_t B, int32_t D, int32_t K,
                    float inv_T, float* logits, float* loss_rows, int32_t* rank0, float* dlogits /*[B][1+K]*/,
-                   float* dq, void* stream);
+                   float* dq, float* workspace, int64_t workspace_bytes, void* stream);
 /* NN-retrieval score (classifier.py:964-981, torch.topk over the test x train similarity): rank[r] = number of train
  * samples scoring strictly above test row r's best same-label train sample (n_train if the label is absent); the k-NN
  * accuracy of the reference is mean(rank < k), for every k from one pass */

@@ -653,3 +653,45 @@ def test_fused_bn_reduce_plan_gives_the_same_gradients(gpu, monkeypatch, net, dt
     tol = (2e-4 if dtype == 'fp32' else 3e-2) * float(a.abs().max())
     print(net, dtype, 'fused convs', fused[1], 'max grad diff', err, 'of', float(a.abs().max()))
     assert err <= tol, (err, tol)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# run-to-run reproducibility: no float atomics left on the training path (weight gradients: row-split slabs; BatchNorm
+# backward sums and MoCo's K-split dq: per-block partials folded in block order by the last block; gating / pooling
+# reductions: one owner per output)
+@pytest.mark.parametrize('kind,net,dtype', [('simclr_naked', 's3dg', 'fp32'), ('simclr_naked', 's3dg', 'bf16'),
+                                            ('simclr_timeseriesv4', 'r21d', 'fp32'), ('moco_naked', 's3dg', 'fp32'),
+                                            ('simclr_naked', 'r50', 'bf16')])
+def test_training_steps_are_bitwise_reproducible(gpu, kind, net, dtype):
+    from dualvar_amd import model as M
+    from dualvar_amd.optim import SGD
+    nv = 3 if 'timeseries' in kind else 2
+    block = torch.randn(8, nv, 3, 8, 112, 112, generator=torch.Generator().manual_seed(11)).to(gpu)
+
+    def run():
+        torch.manual_seed(0)
+        np.random.seed(0)
+        if kind == 'simclr_naked':
+            m = M.SimCLR_Naked(net, 128, 0.07, False)
+        elif kind == 'moco_naked':
+            m = M.MoCo_Naked(net, 128, 4096, 0.999, 0.07, False)
+        else:
+            m = M.SimCLR_TimeSeriesV4(net, 128, 0.07, False, True, 2, 64, 0.07, 0.07, 'clip-sr-tc')
+        m.set_compute_dtype(dtype).train().to(gpu)
+        opt = SGD([p for p in m.parameters() if p.requires_grad], lr=0.01, momentum=0.9, weight_decay=1e-4, stores=m.stores())
+        losses = []
+        for _ in range(2):
+            ret = m(block)
+            loss = sum(v for k, v in ret.items() if 'loss' in k)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        st = m.stores()
+        return (torch.stack(losses), torch.cat([s.grad.detach().flatten() for s in st]).clone(),
+                torch.cat([s.master.detach().flatten() for s in st]).clone())
+    a, b = run(), run()
+    assert bool(torch.isfinite(a[0]).all())
+    for name, x, y in zip(('losses', 'gradients', 'parameters'), a, b):
+        same = torch.equal(x, y)
+        assert same, (name, float((x.float() - y.float()).abs().max()), int((x != y).sum()), x.numel())

@@ -493,7 +493,16 @@ def test_batchnorm_fwd_bwd(gpu, dtype, C_, residual, relu):
     dya = ops.act_from_ncdhw(gy.to(gpu), dtype)
     flags = 0 if relu else ops.DV_NO_RELU_MASK
     sums = torch.zeros(4, 2, CP, device=gpu)          # 4 replicas of the atomic accumulators
-    ops.call('dv_bn_bwd_reduce', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, M, C_, flags, sums, 4)
+    ops.call('dv_bn_bwd_reduce', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, M, C_, flags, sums, 4, None)
+    # ordered form: per-block partials + ticket, summed in block order by the last block -- the same sums, twice the same bits
+    from dualvar_amd import _lib as L_
+    wsn = int(L_.load().dv_bn_bwd_reduce_workspace(M, C_)) // 4
+    ws = torch.zeros(wsn, device=gpu)
+    so = [torch.full((2, CP), 7.0, device=gpu) for _ in range(2)]
+    for t in so:
+        ops.call('dv_bn_bwd_reduce', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, M, C_, flags, t, 1, ws)
+    assert torch.equal(so[0], so[1]) and float(ws[-8:].abs().max()) == 0.0
+    close(so[0][:, :C_], sums.sum(0)[:, :C_], DV_F32, 'ordered bn bwd sums', factor=20)
     dg, db = torch.zeros(C_, device=gpu), torch.zeros(C_, device=gpu)
     dxa = ops.new_act(N, T, H, W, C_, dtype, gpu)
     dra = ops.new_act(N, T, H, W, C_, dtype, gpu) if residual else None
@@ -551,7 +560,7 @@ def test_batchnorm_relu_maxpool_fused(gpu, dtype, k, s, p, shape):
     dya = ops.new_act(N, T, H, W, C_, dtype, gpu)
     ops.call('dv_maxpool3d_bwd', d, gp, idx, dya, 0)
     sums = torch.zeros(4, 2, CP, device=gpu)
-    ops.call('dv_bn_bwd_reduce', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, M, C_, 0, sums, 4)
+    ops.call('dv_bn_bwd_reduce', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, M, C_, 0, sums, 4, None)
     dg, db = torch.zeros(C_, device=gpu), torch.zeros(C_, device=gpu)
     dxa = ops.new_act(N, T, H, W, C_, dtype, gpu)
     ops.call('dv_bn_bwd_apply', dtype, dya, dya.ld, ya, ya.ld, xa, xa.ld, mean, invstd, gam, sums, 4, 1.0 / M, 1.0, dg, db,
@@ -833,7 +842,18 @@ def test_infonce_against_oracle(gpu, B, K):
     loss.backward()
     logits, dl = torch.empty(B, K + 1, device=gpu), torch.empty(B, K + 1, device=gpu)
     lrows, rk, dq = torch.empty(B, device=gpu), torch.empty(B, dtype=torch.int32, device=gpu), torch.empty(B, D, device=gpu)
-    ops.call('dv_infonce_fwd', qf.detach().to(gpu), kf.to(gpu), queue.to(gpu), B, D, K, 1 / 0.07, logits, lrows, rk, dl, dq)
+    ops.call('dv_infonce_fwd', qf.detach().to(gpu), kf.to(gpu), queue.to(gpu), B, D, K, 1 / 0.07, logits, lrows, rk, dl, dq, None, 0)
+    # with the workspace the K-split of dq is ordered (partial tiles + tickets): same value, identical bits run to run
+    from dualvar_amd import _lib as L_
+    wsb = int(L_.load().dv_infonce_workspace(B, D, K))
+    assert (wsb > 0) == (K >= 4096)
+    if wsb:
+        ws = torch.zeros(wsb // 4, device=gpu)
+        dqo = [torch.full((B, D), 3.0, device=gpu) for _ in range(2)]
+        for t in dqo:
+            ops.call('dv_infonce_fwd', qf.detach().to(gpu), kf.to(gpu), queue.to(gpu), B, D, K, 1 / 0.07, logits, lrows, rk, dl, t, ws, wsb)
+        assert torch.equal(dqo[0], dqo[1])
+        close(dqo[0], qf.grad, DV_F32, 'infonce dq (ordered split-K)', factor=20)
     close(logits, lr, DV_F32, 'infonce logits', factor=5)
     close(lrows.mean(), loss, DV_F32, 'infonce loss', factor=5)
     close(dq, qf.grad, DV_F32, 'infonce dq', factor=20)

@@ -109,7 +109,7 @@ def test_batchnorm_statistics_and_backward_orthogonality_at_full_size(gpu):
     dy.buf.copy_(torch.randn(dy.buf.shape, generator=g).to(torch.bfloat16))
     CP = ops.cp8(C_)
     sums = torch.zeros(8, 2, CP, device=gpu)
-    ops.call('dv_bn_bwd_reduce', DV_BF16, dy, dy.ld, y, y.ld, x, x.ld, mean, invstd, M, C_, DV_NO_RELU_MASK, sums, 8)
+    ops.call('dv_bn_bwd_reduce', DV_BF16, dy, dy.ld, y, y.ld, x, x.ld, mean, invstd, M, C_, DV_NO_RELU_MASK, sums, 8, None)
     dx = x.like()
     dgam, dbet = torch.zeros(C_, device=gpu), torch.zeros(C_, device=gpu)
     ops.call('dv_bn_bwd_apply', DV_BF16, dy, dy.ld, y, y.ld, x, x.ld, mean, invstd, gamma, sums, 8, 1.0 / M, 1.0, dgam, dbet,
