@@ -63,7 +63,7 @@ def _worker(rank, world, port, kind, q):
         if True:
             # the same step with the all-reduce issued bucket by bucket from INSIDE the backward pass (GradSync.attach) --
             # for the dual-head objective from inside the LAST of its two encoder backward passes: the synchronised
-            # gradient must not change (beyond the summation order of the BatchNorm-backward atomics)
+            # gradient must not change (beyond the regrouping of the BatchNorm-backward sums)
             for side in (False, True):
                 m.store.zero_grad()
                 sync2 = GradSync(bucket_mb=1, side_stream=side)
@@ -438,13 +438,14 @@ def test_rccl_single_rank_rehearsal(gpu, kind, transport, net):
         return max(float(np.abs(pa[k] - pb[k]).max() / (np.abs(pb[k]).max() + 1e-12)) for k in pb)
 
     want, ref = plain(0)
-    # How far do two runs of the PLAIN path lie apart -- run to run (the BatchNorm-backward / gating reductions still use float
-    # atomics; the weight gradients no longer do), and under a rounding-sized (1e-7) perturbation of the input?  The rehearsal
-    # takes other kernels through the statistics (reduce -> gather -> finalize instead of one launch), i.e. other roundings:
-    # it cannot agree with the plain path better than the plain path agrees with itself.
+    # Two runs of the PLAIN path are bit-identical (no float atomics on the training path).  How far do they move under a
+    # rounding-sized (1e-7) perturbation of the input?  The rehearsal takes other kernels through the statistics (reduce ->
+    # gather -> finalize instead of one launch), i.e. other roundings: it cannot agree with the plain path better than the
+    # plain path agrees with its own nudged self.
     _, again = plain(0)
     _, nudged = plain(1e-7)
     s_rr, s_in = spread(again, ref), spread(nudged, ref)
+    assert s_rr == 0.0, s_rr
     print('RCCL single-rank rehearsal losses', losses, 'plain', want, '| plain-vs-plain spread: run-to-run %.2e, 1e-7 input nudge %.2e' % (s_rr, s_in))
     assert abs(losses[0] - want[0]) < 1e-5 * abs(want[0])
     assert abs(losses[1] - want[1]) < max(2e-3, 20 * max(s_rr, s_in)) * abs(want[1])     # after one SGD step
