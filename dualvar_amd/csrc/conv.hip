@@ -34,6 +34,43 @@ struct ConvGeom {
   FastDiv dW, dH, dT;    // fast division by rW, rH, rT
 };
 
+// Row ORDER of a launch whose window has taps along t (on): rows are enumerated
+//   for clip n: for 32-pixel chunk c of the (h, w) plane: for t: rows (n, t, c*32 .. c*32+31)
+// instead of the tensor's [n][t][h][w] order, so the rows a tap reads at t-1 / t+1 are rows the neighbouring steps of the
+// weight-gradient kernel read at their own t: L2 hits.  In tensor order they are a whole plane (784 .. 3 136 rows)
+// away and every tap fetched its own copy of the activation: PMC 2.2x the algorithmic bytes on the 3x1x1 / 7x1x1 weight
+// gradients (1.0 - 1.25x with this order, and 3 - 9 % faster).  A sum over rows: any fixed bijection of [0, M) will do.
+// (The same order for the tiles of the forward / data-gradient GEMMs was measured 2 - 6 % SLOWER: not used there.)
+struct RowPerm {
+  int on, pT, pS, nfull, full_span;
+  FastDiv fB, f32T, fwt;
+};
+static RowPerm make_row_perm(bool on, int T, int S) {
+  RowPerm p;
+  p.on = on ? 1 : 0; p.pT = T; p.pS = S; p.nfull = S / 32; p.full_span = p.nfull * 32 * T;
+  p.fB = make_fastdiv((uint32_t)(T * S)); p.f32T = make_fastdiv((uint32_t)(32 * T));
+  p.fwt = make_fastdiv((uint32_t)(S % 32 ? S % 32 : 1));
+  return p;
+}
+__device__ __forceinline__ uint32_t perm_row(const RowPerm& a, uint32_t q) {
+  uint32_t n, p, t, pix;
+  fd_divmod(q, a.fB, n, p);
+  if (p < (uint32_t)a.full_span) {
+    uint32_t c, w;
+    fd_divmod(p, a.f32T, c, w);
+    t = w >> 5; pix = c * 32 + (w & 31);
+  } else {
+    uint32_t r;
+    fd_divmod(p - (uint32_t)a.full_span, a.fwt, t, r);
+    pix = (uint32_t)a.nfull * 32 + r;
+  }
+  return (n * (uint32_t)a.pT + t) * (uint32_t)a.pS + pix;
+}
+static bool row_perm_enabled() {
+  static const bool off = getenv("DUALVAR_NO_ROW_PERM") && atoi(getenv("DUALVAR_NO_ROW_PERM")) != 0;
+  return !off;
+}
+
 struct ConvArgs {
   const void* src;       // gathered tensor (x for fwd, dy for dgrad)
   const void* w;         // [N rows][Ktot] K-contiguous, pitch ldw
@@ -865,6 +902,7 @@ struct WgradArgs {
   int nti, ntj;
   int rows_per_split;
   ConvGeom g;
+  RowPerm perm;           // row order of the DMA kernel (see RowPerm)
 };
 
 // one 32x32 accumulator block -> slab / dW.  Per register a half wave stores 32 consecutive floats (128 B).
@@ -1121,7 +1159,7 @@ __device__ __forceinline__ bf16x8 wg_frag(const unsigned char* tile, int col0, i
 // workgroups per CU the LDS footprint admits (<= 3), and the waves per SIMD that makes (the register allocator is
 // asked to make room for them)
 constexpr int wgrad_wgs_per_cu(int es, int bi, int bj, int nw, int ns) {
-  const int lds = ns * 32 * (bi + bj) * es + 16 * nw * 64;
+  const int lds = ns * 32 * (bi + bj) * es + 24 * nw * 64;
   const int by_lds = 163840 / lds, by_waves = 32 / nw;
   const int k = by_lds < by_waves ? by_lds : by_waves;
   return k >= 3 ? 3 : (k >= 2 ? 2 : 1);
@@ -1153,6 +1191,7 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
 
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * BUFB];
   __shared__ uint2 rowtab[2][RT];
+  __shared__ unsigned rowdy[2][RT];                  // byte offset of the row in dY (kOOB beyond the slice)
 
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1200,10 +1239,13 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
 
   // decode RT rows of round `rnd` (one per thread) into rowtab[rnd & 1]
   auto decode = [&](int rnd) {
-    const int m = m_begin + rnd * RT + tid;
+    const int q = m_begin + rnd * RT + tid;          // position in the row sequence
     uint2 e = make_uint2(0u, 0u);
-    if (m < m_end) {
-      const RowPos r = decode_row<MODE_FWD>((uint32_t)m, a.M, g);
+    unsigned dyo = kOOB;
+    if (q < m_end) {
+      const uint32_t m = a.perm.on ? perm_row(a.perm, (uint32_t)q) : (uint32_t)q;
+      dyo = m * ldyb;
+      const RowPos r = decode_row<MODE_FWD>(m, a.M, g);
       auto range = [](int x0, int k, int lim) -> unsigned {      // bits d in [0,k) with 0 <= x0 + d < lim
         const int lo = max(0, -x0), hi = min(k, lim - x0);
         return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
@@ -1213,15 +1255,18 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
       e.y = (bt && bh && bw) ? (bt | (bh << 8) | (bw << 16)) : 0u;
     }
     rowtab[rnd & 1][tid] = e;
+    rowdy[rnd & 1][tid] = dyo;
   };
 
   auto issue = [&](int s, int buf) {
-    const int mb = m_begin + s * ROWS;
+    const unsigned* dtab = rowdy[(s / SPR) & 1] + (s % SPR) * ROWS;
+    unsigned dyo[NPW];
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) dyo[u] = dtab[prow[u]];
 #pragma unroll
     for (int u = 0; u < NPW; ++u) {
       if (PPC % NW != 0 && wave + NW * u >= PPC) break;           // (wave-uniform)
-      const int m = mb + prow[u];
-      const unsigned off = (m < m_end && pcolb[u] != kOOB) ? (unsigned)m * ldyb + pcolb[u] : kOOB;
+      const unsigned off = (dyo[u] != kOOB && pcolb[u] != kOOB) ? dyo[u] + pcolb[u] : kOOB;
       dma_load16(dy_rsrc, smem_base + buf * BUFB + (wave + NW * u) * 1024, off);
     }
     const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(rowtab[(s / SPR) & 1] + (s % SPR) * ROWS);
@@ -1901,6 +1946,7 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
   a.ldx = d->ldx; a.ldy = d->ldy; a.ldw = a.g.Ktot;
   a.nti = p.nti; a.ntj = p.ntj;
   a.rows_per_split = p.rows_per_split;
+  a.perm = make_row_perm(row_perm_enabled() && d->kt > 1 && d->To > 1, d->To, d->Ho * d->Wo);
   const int grid = p.nti * p.ntj * p.splits;
   const bool narrow = p.BI == 64;
   hipStream_t s = (hipStream_t)stream;
