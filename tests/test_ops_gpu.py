@@ -1068,3 +1068,42 @@ def test_pointwise_conv_fp8_fwd_dgrad(gpu, case):
     ddacc.ldy = dy8.stride(0)
     ops.conv_dgrad_fp8(ddacc, dy8, wd8, sdy, swd, dxa)
     assert float((dxa.buf[:, :Cin].float() - 2 * ref).abs().max() / ref.abs().max()) < 1.5e-2
+
+
+@pytest.mark.parametrize('dtype', [DV_F32, DV_BF16])
+@pytest.mark.parametrize('k,s,p', [((3, 3, 3), (1, 1, 1), (1, 1, 1)), ((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1))])
+def test_maxpool_on_channel_slices(gpu, dtype, k, s, p):
+    """input, output and both gradients as channel slices of wider buffers (pitch > C, offset > 0) -- the concat-by-slice
+    layout of the Inception blocks -- through the staged (3x3x3 / 1), quad (3x3 / 2) and gather kernels: the neighbours of
+    the slices stay untouched"""
+    N, C_, T, H, W = 2, 40, 4, 13, 14
+    x = F.relu(q(rnd(N, C_, T, H, W, seed=91), dtype))
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool3d(xr, k, s, p)
+    gy = q(rnd(*yr.shape, seed=92), dtype)
+    yr.backward(gy)
+    To, Ho, Wo = yr.shape[2:]
+    wide_x = ops.new_act(N, T, H, W, C_ + 32, dtype, gpu)
+    wide_x.buf.fill_(5.0)
+    xs = wide_x.slice(16, C_)
+    xs_src = ops.act_from_ncdhw(x.to(gpu), dtype)
+    wide_x.buf[:, 16:16 + xs_src.buf.shape[1]] = xs_src.buf
+    # (the descriptor carries ONE pitch per side: dx has x's pitch, dy has y's)
+    wide_y, wide_dy = (ops.new_act(N, To, Ho, Wo, C_ + 24, dtype, gpu) for _ in range(2))
+    wide_dx = ops.new_act(N, T, H, W, C_ + 32, dtype, gpu)
+    for wbuf in (wide_y, wide_dx):
+        wbuf.buf.fill_(7.0)
+    ys, dys, dxs = wide_y.slice(8, C_), wide_dy.slice(8, C_), wide_dx.slice(16, C_)
+    g_src = ops.act_from_ncdhw(gy.to(gpu), dtype)
+    wide_dy.buf.fill_(3.0)
+    wide_dy.buf[:, 8:8 + g_src.buf.shape[1]] = g_src.buf
+    idx = torch.zeros(ys.rows, ops.cp8(C_), dtype=torch.uint8, device=gpu)
+    d = ops.pool_desc(dtype, xs, ys, k, s, p)
+    ops.call('dv_maxpool3d_fwd', d, xs, ys, idx)
+    got = wide_y.buf[:, 8:8 + C_].float().view(N, To, Ho, Wo, C_).permute(0, 4, 1, 2, 3)
+    assert torch.equal(got.cpu(), yr.detach())
+    assert float((wide_y.buf[:, :8].float() - 7).abs().max()) == 0 and float((wide_y.buf[:, 8 + ops.cp8(C_):].float() - 7).abs().max()) == 0
+    ops.call('dv_maxpool3d_bwd', d, dys, idx, dxs, 0)
+    gotx = wide_dx.buf[:, 16:16 + C_].float().view(N, T, H, W, C_).permute(0, 4, 1, 2, 3)
+    close(gotx, q(xr.grad, dtype), dtype, 'pool bwd on slices')
+    assert float((wide_dx.buf[:, :16].float() - 7).abs().max()) == 0 and float((wide_dx.buf[:, 16 + ops.cp8(C_):].float() - 7).abs().max()) == 0
