@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--dtype', default='fp32')
     ap.add_argument('--net', default='s3dg')
+    ap.add_argument('--loop', type=int, default=0, help='just run this many steps (for rocprofv3 --kernel-trace + tools/timeline_gaps.py)')
     args = ap.parse_args()
     from dualvar_amd import model as M
     from dualvar_amd.optim import SGD
@@ -35,6 +36,11 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    if args.loop:
+        for _ in range(args.loop):
+            step()
+        torch.cuda.synchronize()
+        return
     with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA],
                                 with_stack=True) as prof:
         step()
