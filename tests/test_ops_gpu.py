@@ -1107,3 +1107,16 @@ def test_maxpool_on_channel_slices(gpu, dtype, k, s, p):
     gotx = wide_dx.buf[:, 16:16 + C_].float().view(N, T, H, W, C_).permute(0, 4, 1, 2, 3)
     close(gotx, q(xr.grad, dtype), dtype, 'pool bwd on slices')
     assert float((wide_dx.buf[:, :16].float() - 7).abs().max()) == 0 and float((wide_dx.buf[:, 16 + ops.cp8(C_):].float() - 7).abs().max()) == 0
+
+
+def test_random_shapes_conv_and_pool(gpu):
+    """tools/fuzz_ops.py with a fixed seed: 60 random (shape, window, stride, dtype) cases through conv fwd / dgrad / wgrad and
+    max-pool fwd / bwd against PyTorch on the CPU -- odd channel counts, planes that are not a multiple of the 32-pixel chunk
+    of the weight gradient's t-inner row order, ragged pool tiles"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_ops.py'), '--n', '60', '--seed', '7'], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and 'ok: 60 random cases' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
