@@ -91,6 +91,28 @@ def main():
             tag = ('pool bwd', 'f32' if dt == L.DV_F32 else 'bf16')
             worst[tag] = max(worst.get(tag, 0.0), e)
             assert e <= TOL[dt], ('pool bwd', e, (N, C_, T, H, W), k, s, p)
+    # ---- per-sample reductions (self-gating mean / backward reduce): channel-chunked grids on the long-S levels
+    for it in range(max(4, args.n // 6)):
+        dt = rng.choice([L.DV_F32, L.DV_BF16])
+        N, S, C_ = rng.randint(1, 140), rng.choice([9, 49, 130, 196, 784, 1000]), rng.choice([8, 40, 132, 256, 520])
+        x = q(torch.randn(N * S, C_, generator=g), dt)
+        dy = q(torch.randn(N * S, C_, generator=g), dt)
+        gate = torch.rand(N, C_, generator=g)
+        xa = ops.new_act(N, 1, 1, S, C_, dt, dev)
+        xa.buf[:, :C_] = x.to(dev).to(ops.TORCH_DTYPE[dt])
+        dya = ops.new_act(N, 1, 1, S, C_, dt, dev)
+        dya.buf[:, :C_] = dy.to(dev).to(ops.TORCH_DTYPE[dt])
+        mean = torch.full((N, C_), 9.0, device=dev)
+        ops.call('dv_spatial_mean', dt, xa, xa.ld, N, S, C_, mean)
+        e = rel(mean, x.view(N, S, C_).double().mean(1).float())
+        worst[('spatial mean', 'f32' if dt == L.DV_F32 else 'bf16')] = max(worst.get(('spatial mean', 'f32' if dt == L.DV_F32 else 'bf16'), 0.0), e)
+        assert e <= 2e-5, ('spatial_mean', e, N, S, C_)
+        dpre = torch.full((N, C_), 9.0, device=dev)
+        ops.call('dv_gate_bwd_reduce', dt, dya, dya.ld, xa, xa.ld, gate.to(dev), N, S, C_, dpre, 0)
+        want = ((dy.double() * x.double()).view(N, S, C_).sum(1) * (gate * (1 - gate)).double()).float()
+        e = rel(dpre, want)
+        worst[('gate reduce', 'f32' if dt == L.DV_F32 else 'bf16')] = max(worst.get(('gate reduce', 'f32' if dt == L.DV_F32 else 'bf16'), 0.0), e)
+        assert e <= 5e-5, ('gate_bwd_reduce', e, N, S, C_)
     for k_, v in sorted(worst.items()):
         print('%-12s %-5s worst rel err %.2e' % (k_[0], k_[1], v))
     print('ok: %d random cases' % args.n)
