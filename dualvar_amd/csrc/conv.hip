@@ -291,6 +291,42 @@ __device__ __forceinline__ Split3 split3(const float (&v)[8]) {
   }
   return s;
 }
+// The weight-gradient kernels' split (they are bound by the vector-instruction count of exactly this function):
+// hi = bf16(x), rounded to nearest (one v_cvt_pk_bf16_f32 per pair); r1 = x - hi is exact, has <= 16 significant bits and a
+// sign that does not follow x's; mid = the TOP 16 BITS of r1 (truncated: the bf16 is the upper half of the fp32 word, so the
+// pair is one v_perm_b32 and widening it back is one v_and per value); lo = r1 - mid has <= 8 significant bits and is exact
+// in bf16 (again the upper half).  Per pair of values: 1 conversion, 2 widenings, 2 v_and, 2 packed subtractions, 2 v_perm =
+// 36 vector instructions per 8 values; rounding mid and lo as well takes 42, and these kernels are bound by that count
+// (weight gradients -6.6 %, step -1.1 %).  The forward / data-gradient kernels keep the fully rounded split3 above: they are
+// MFMA bound, and with the truncated mid the loss after two SGD steps moved from 1.1e-3 to 1.6e-3 of the reference's on the
+// R(2+1)D fixture (a weight gradient enters the next step scaled by the learning rate; an activation enters it directly).  Truncating hi too would cost the same 36 but biases every dropped partial product
+// (mid*lo, lo*mid, lo*lo) towards the sign of x*y: in the long, cancelling sums of a weight gradient that bias showed as
+// 1e-1 relative differences between a batch and its two halves (1e-3 .. 1e-2 with the rounded hi).
+__device__ __forceinline__ Split3 split3w(const float (&v)[8]) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
+  u32x4v H, Mi, Lo;
+  const u32x2 mask = {0xffff0000u, 0xffff0000u};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const f32x2 x = {v[2 * p], v[2 * p + 1]};
+    const bf16x2 hb = __builtin_convertvector(x, bf16x2);              // one v_cvt_pk_bf16_f32
+    const unsigned hw = __builtin_bit_cast(unsigned, hb);
+    const u32x2 hwide = {hw << 16, hw & 0xffff0000u};
+    const f32x2 r1 = x - __builtin_bit_cast(f32x2, hwide);
+    const u32x2 rb = __builtin_bit_cast(u32x2, r1);
+    const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, rb & mask);
+    const u32x2 qb = __builtin_bit_cast(u32x2, r2);
+    H[p] = hw;
+    Mi[p] = __builtin_amdgcn_perm(rb.y, rb.x, 0x07060302u);
+    Lo[p] = __builtin_amdgcn_perm(qb.y, qb.x, 0x07060302u);
+  }
+  Split3 s;
+  s.hi = __builtin_bit_cast(bf16x8, H); s.mid = __builtin_bit_cast(bf16x8, Mi); s.lo = __builtin_bit_cast(bf16x8, Lo);
+  return s;
+}
 __device__ __forceinline__ void mma_split3(const Split3& a, const Split3& b, f32x16& acc) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
@@ -1329,28 +1365,47 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
     } else if constexpr (SPLIT) {
       // f32 tiles, products on the bf16 matrix cores (split3 above): the K index of this GEMM is the ROW, so a lane's
       // fragment is 8 rows of one column (conflict-free dword reads, immediate offsets)
+      // Software pipeline inside the step: the fragments of K half 1 are split while the MFMAs of K half 0 run.  In program order
+      // a wave would split everything (vector ALU only), then multiply (matrix pipe only); sched_group_barrier makes the
+      // scheduler emit one MFMA, then its share of the split instructions, so both pipes work at once.
+      auto frag_a = [&](int ks, int i, float (&v)[8]) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        Split3 af[TI], bf[TJ];
+        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(tp + (ks * 16 + 8 * h + e) * RBP + (wi0 + i * 32 + l31) * 4);
+      };
+      auto frag_b = [&](int ks, int j, float (&v)[8]) {
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-          float v[8];
+        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(tq + (ks * 16 + 8 * h + e) * RBQ + (wj0 + j * 32 + l31) * 4);
+      };
+      Split3 a0[TI], b0[TJ], a1[TI], b1[TJ];
+      float ra[TI][8], rb[TJ][8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(tp + (ks * 16 + 8 * h + e) * RBP + (wi0 + i * 32 + l31) * 4);
-          af[i] = split3(v);
+      for (int i = 0; i < TI; ++i) { float v[8]; frag_a(0, i, v); a0[i] = split3w(v); }
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) { float v[8]; frag_b(0, j, v); b0[j] = split3w(v); }
+#pragma unroll
+      for (int i = 0; i < TI; ++i) frag_a(1, i, ra[i]);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) frag_b(1, j, rb[j]);
+#pragma unroll
+      for (int i = 0; i < TI; ++i) a1[i] = split3w(ra[i]);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) b1[j] = split3w(rb[j]);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) mma_split3(a0[i], b0[j], acc[i][j]);
+      {
+        constexpr int NM = TI * TJ * 6, VPM = (44 * (TI + TJ) + NM - 1) / NM;
+#pragma unroll
+        for (int qq = 0; qq < NM; ++qq) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x2, VPM, 0);
         }
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(tq + (ks * 16 + 8 * h + e) * RBQ + (wj0 + j * 32 + l31) * 4);
-          bf[j] = split3(v);
-        }
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) mma_split3(af[i], bf[j], acc[i][j]);
       }
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) mma_split3(a1[i], b1[j], acc[i][j]);
     } else {
 #pragma unroll 4
       for (int ks = 0; ks < ROWS / 2; ++ks) {
