@@ -1204,10 +1204,16 @@ constexpr int wgrad_waves_per_simd(int es, int bi, int bj, int nw, int ns) {
   return (wgrad_wgs_per_cu(es, bi, bj, nw, ns) * nw + 3) / 4;
 }
 
-template <typename T, int BI, int BJ, int WVI, int WVJ, int NS, bool SPLIT = false>
+// SHARE (fp32 split mode, 1 x 4 waves): the dY fragments of a step -- which every one of the four waves needs -- are split
+// ONCE per workgroup (one fragment per thread, the bf16 triples written to LDS in fragment order, a barrier, operands
+// fetched as ds_read_b128); each wave splits only its own 32 columns of x.  Three fragments per wave and step instead of the
+// six of the 2 x 2 layout (where the two waves of a row / column each split the fragments they share): the kernel is bound
+// by the count of exactly those vector instructions.  12 KB of LDS more: still two workgroups per CU.
+template <typename T, int BI, int BJ, int WVI, int WVJ, int NS, bool SPLIT = false, bool SHARE = false>
 __global__ __launch_bounds__(WVI * WVJ * 64)
 __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI * WVJ, NS)))) void conv_wgrad_dma_kernel(WgradDmaArgs aa) {
   static_assert(!SPLIT || sizeof(T) == 4, "the bf16 split is the fp32 mode's product");
+  static_assert(!SHARE || SPLIT, "the shared split belongs to the fp32 split mode");
   const WgradArgs& a = aa.w;
   constexpr int ES = (int)sizeof(T);
   constexpr int EPV = 16 / ES;                       // elements per 16-byte DMA slot
@@ -1228,6 +1234,10 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * BUFB];
   __shared__ uint2 rowtab[2][RT];
   __shared__ unsigned rowdy[2][RT];                  // byte offset of the row in dY (kOOB beyond the slice)
+  // SHARE: [k half * 2 + h][hi | mid | lo][column] bf16x8 fragments of the current step's dY tile
+  constexpr int NFRAG = SHARE ? BI * 4 : 1;
+  __shared__ uint4 planes[NFRAG * 3];
+  static_assert(!SHARE || (NFRAG == NT && WVI == 1), "one dY fragment per thread, every wave spans all of BI");
 
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1361,6 +1371,50 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
         for (int i = 0; i < TI; ++i)
 #pragma unroll
           for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    } else if constexpr (SHARE) {
+      // split phase: thread -> dY fragment (kh = k half * 2 + h = its wave, column = its lane): conflict-free dword reads of 8
+      // rows of a column, 16-byte writes of the three planes
+      {
+        const int kh = wave, col = lane;
+        const unsigned char* src = tp + ((kh >> 1) * 16 + 8 * (kh & 1)) * RBP + col * 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(src + e * RBP);
+        const Split3 s3 = split3w(v);
+        uint4* dst = planes + kh * 3 * BI + col;
+        dst[0] = __builtin_bit_cast(uint4, s3.hi);
+        dst[BI] = __builtin_bit_cast(uint4, s3.mid);
+        dst[2 * BI] = __builtin_bit_cast(uint4, s3.lo);
+      }
+      // this wave's own x fragments (both K halves) are split while the other waves finish their dY fragment (splitting K half 1
+      // under the MFMAs of K half 0 instead was measured equal)
+      Split3 bfr[2][TJ];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(tq + (ks * 16 + 8 * h + e) * RBQ + (wj0 + j * 32 + l31) * 4);
+          bfr[ks][j] = split3w(v);
+        }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        Split3 af[TI];
+        const int kh = ks * 2 + h;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const uint4* pa = planes + kh * 3 * BI + wi0 + i * 32 + l31;
+          af[i].hi = __builtin_bit_cast(bf16x8, pa[0]);
+          af[i].mid = __builtin_bit_cast(bf16x8, pa[BI]);
+          af[i].lo = __builtin_bit_cast(bf16x8, pa[2 * BI]);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) mma_split3(af[i], bfr[ks][j], acc[i][j]);
       }
     } else if constexpr (SPLIT) {
       // f32 tiles, products on the bf16 matrix cores (split3 above): the K index of this GEMM is the ROW, so a lane's
@@ -2025,8 +2079,13 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
         if (p.cfg == 1) WGD(float, 64, 128, 2, 2, 2);
         else WGD(float, 128, 128, 2, 2, 2);
       } else {
-        if (p.cfg == 1) WGD(float, 64, 128, 2, 2, 2, true);
-        else WGD(float, 128, 128, 2, 2, 2, true);
+        static const int share = env_int("DUALVAR_WGRAD_SHARE", 1);
+        if (share && p.cfg == 1) {
+          WGD(float, 64, 128, 1, 4, 2, true, true);
+        } else {
+          if (p.cfg == 1) WGD(float, 64, 128, 2, 2, 2, true);
+          else WGD(float, 128, 128, 2, 2, 2, true);
+        }
       }
     }
 #undef WGD
