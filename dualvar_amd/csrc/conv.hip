@@ -362,7 +362,7 @@ __device__ __forceinline__ float act_apply(float v, int flags) {
 // K loop is issue bound and resident waves are what hides it): 6 for the 128x64 / 64x128 bf16 tiles (<= 80 VGPRs instead
 // of 84-88), 3 for 128x128 (<= 168 instead of 172), no request otherwise.
 constexpr int conv_waves_per_simd(int es, int gvb, int bm, int bn) {
-  return (es != 2 || gvb != 16) ? 1 : (bm * bn == 128 * 64) ? 6 : (bm == 128 && bn == 128) ? 3 : 1;
+  return (es == 4 && gvb == 16 && bm == 256) ? 3 : (es != 2 || gvb != 16) ? 1 : (bm * bn == 128 * 64) ? 6 : (bm == 128 && bn == 128) ? 3 : 1;
 }
 
 // WF (fp32 split mode): the weights arrive PRE-SPLIT in fragment order (dv_pack_w3: [K tile][k half h][row][hi|mid|lo][8]
