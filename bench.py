@@ -2,6 +2,7 @@
 """bench.py -- clips/sec of the DualVar pretrain step (S3D-G 8x112x112 SimCLR) on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...          (no launcher: starts the N ranks itself, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -60,6 +61,12 @@ def parse():
     ap.add_argument('--dump-launches', default='', help='write a per-launch timing table (calibration step) to this file')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--launch-check', action='store_true',
+                    help='only exercise the N-rank launch / rendezvous / watchdog plumbing (no GPU work): every rank joins the process '
+                         'group, one all-reduce, rank 0 prints {"launch_check": true, "n_gpus": N}')
+    ap.add_argument('--hang-check', type=float, default=0.0,
+                    help='with --launch-check: rank 1 never joins the all-reduce, and the watchdog deadline is this many seconds '
+                         '(tests the deadline path)')
     return ap.parse_args()
 
 
@@ -167,10 +174,87 @@ def cpu_baseline(args, V):
                       f'best of {args.cpu_steps} full train steps after 1 warm-up, torch {torch.__version__} CPU, {ncpu} threads'}
 
 
+class Watchdog:
+    """Deadline per phase for the N > 1 flow: a collective that never completes (a rank that died, a communicator that cannot
+    form) would otherwise end as a run killed at its time limit with nothing printed.  A daemon thread checks the deadline of
+    the current phase; when it passes, it says which phase is stuck and ends the process with a non-zero code (os._exit: the
+    main thread is inside a blocking call and cannot be unwound; never a re-exec)."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.name, self.deadline = rank, 'start', None
+        self._lock = threading.Lock()
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def phase(self, name, seconds):
+        with self._lock:
+            self.name, self.deadline = name, (time.monotonic() + seconds if seconds else None)
+
+    def _run(self):
+        while True:
+            time.sleep(1.0)
+            with self._lock:
+                late = self.deadline is not None and time.monotonic() > self.deadline
+                name = self.name
+            if late:
+                print(f'[bench] WATCHDOG: rank {self.rank} stuck in phase "{name}" past its deadline -- giving up', file=sys.stderr, flush=True)
+                os._exit(3)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run as a CHILD process,
+    before this process has touched the GPU) and relay rank 0's JSON line.  The reference launches its 8 workers the same way
+    (paper_scripts/*/pretrain/*.sh:8-19 -> torch.distributed.launch, pretrain.py:205-220)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('[bench] --gpus %d without WORLD_SIZE: launching %s' % (args.gpus, ' '.join(cmd[1:8])), file=sys.stderr, flush=True)
+    limit = float(os.environ.get('DUALVAR_BENCH_TIMEOUT', 1500))
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=limit)
+    except subprocess.TimeoutExpired as e:
+        sys.stdout.write((e.stdout or b'').decode(errors='replace'))
+        print(f'[bench] the {args.gpus}-rank job did not finish within {limit:.0f} s', file=sys.stderr, flush=True)
+        sys.exit(4)
+    for line in r.stdout.decode(errors='replace').splitlines():      # the JSON line to stdout, library chatter to stderr
+        print(line, file=sys.stdout if line.startswith('{') else sys.stderr, flush=True)
+    sys.exit(r.returncode)
+
+
+WD = None
+
+
 def setup_dist(args):
+    global WD
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    # DUALVAR_FORCE_EXCHANGE rehearses the N > 1 code path with ONE rank: there --gpus stays 1
+    if world != args.gpus:
+        raise SystemExit(f'[bench] --gpus {args.gpus} but WORLD_SIZE is {world}: launch with '
+                         f'`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` '
+                         f'(or plain `python bench.py --gpus {args.gpus}`, which starts the ranks itself)')
+    WD = Watchdog(rank)
+    if args.launch_check:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        WD.phase('init_process_group(gloo)', 120)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        WD.phase('launch-check all-reduce', args.hang_check or 120)
+        t = torch.ones(1)
+        if args.hang_check and rank == 1:
+            time.sleep(args.hang_check + 30)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({'launch_check': True, 'n_gpus': world, 'sum': float(t)}), flush=True)
+        WD.phase('teardown', 60)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0)
     # DUALVAR_FORCE_EXCHANGE=1: rehearse the multi-GPU step (every RCCL collective issued) with one rank on a 1-GPU box
     distributed = world > 1 or os.environ.get('DUALVAR_FORCE_EXCHANGE') == '1'
     if os.environ.get('DUALVAR_BENCH_BACKEND'):      # rehearsal of the N > 1 flow on a 1-GPU box: ranks share the device (gloo)
@@ -181,6 +265,7 @@ def setup_dist(args):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         backend = os.environ.get('DUALVAR_BENCH_BACKEND', 'nccl')
+        WD.phase('init_process_group(%s)' % backend, 300)
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
@@ -194,6 +279,8 @@ def run_leg(args, dtype, rank, world, distributed, dev):
     from dualvar_amd.optim import SGD
     from dualvar_amd.parallel import GradSync
     import dualvar_amd.engine as _eng
+    wd_on = world > 1                 # deadlines only where a peer can keep us waiting
+    WD.phase(f'{dtype}: build model + first steps (RCCL communicators form here)', 600 if wd_on else 0)
     torch.manual_seed(0)
     np.random.seed(1234 + rank)
     model = build_model(args, distributed)
@@ -221,6 +308,7 @@ def run_leg(args, dtype, rank, world, distributed, dev):
     # calibration step: time every launch once to find the kernel with the largest share
     # (single stream for this one step, so that every kernel's time is its own: in the timed region the weight
     # gradients run on a side stream, concurrently with the main chain -- engine.Plan.run_backward)
+    WD.phase(f'{dtype}: calibration step', 300 if wd_on else 0)
     side_default = _eng.WGRAD_SIDE_STREAM
     _eng.WGRAD_SIDE_STREAM = False
     cal = KernelTimer()
@@ -242,6 +330,7 @@ def run_leg(args, dtype, rank, world, distributed, dev):
     for p in all_plans(model):
         p.timer = probe
 
+    WD.phase(f'{dtype}: timed region ({args.steps} steps)', (300 + 5 * args.steps) if wd_on else 0)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -258,6 +347,7 @@ def run_leg(args, dtype, rank, world, distributed, dev):
         dt = float(t)
     for p in all_plans(model):
         p.timer = None
+    WD.phase(f'{dtype}: report', 120 if wd_on else 0)
 
     print(f'[bench] {dtype}: timed region: {args.steps} steps in {dt:.3f} s', file=sys.stderr, flush=True)
     clips = world * B * V * args.steps
@@ -314,6 +404,8 @@ def run_leg(args, dtype, rank, world, distributed, dev):
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)             # never returns; nothing in this process has touched the GPU yet
     rank, world, distributed, dev = setup_dist(args)
     V = 2 if args.model.endswith('naked') else 3
     B = args.batch
@@ -358,6 +450,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args, V)
         print(json.dumps(out))
     if distributed:
+        WD.phase('teardown', 120 if world > 1 else 0)
         dist.barrier()
         torch.cuda.synchronize()
         from dualvar_amd import rccl

@@ -9,6 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdualvar_hip.so')
 
+ABI_VERSION = 2              # == DV_ABI_VERSION of include/dualvar_hip.h (tests/test_abi_and_host.py compares the two)
 DV_F32, DV_BF16 = 0, 1
 DV_BIAS, DV_RELU, DV_SIGMOID, DV_ACCUM, DV_STATS, DV_NO_RELU_MASK, DV_MASK_FROM_X = 1, 2, 4, 8, 16, 32, 64
 DV_W3 = 128                  # conv fwd / dgrad in DV_F32: weights pre-split in fragment order (dv_pack_w3)
@@ -164,8 +165,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the ABI and this table disagree
         fn.argtypes = argtypes
         fn.restype = C.c_int64 if name in RETURNS_INT64 else C.c_int
-    if lib.dv_abi_version() != 1:
-        raise DualVarHipError('libdualvar_hip.so ABI version mismatch')
+    got = lib.dv_abi_version()
+    if got != ABI_VERSION:
+        raise DualVarHipError(f'libdualvar_hip.so reports ABI version {got}, this binding was written against {ABI_VERSION}: '
+                              'rebuild with `python -m dualvar_amd.build --force`')
     _lib = lib
     return lib
 

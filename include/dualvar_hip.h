@@ -32,7 +32,11 @@
 extern "C" {
 #endif
 
-#define DV_ABI_VERSION 1
+/* Bumped on every incompatible change of a signature or struct below; dv_abi_version() returns the value the library was
+   built with and a consumer must refuse a library whose value differs from the header it was compiled against.
+   2: dv_conv3d_wgrad (workspace, workspace_bytes), dv_bn_bwd_reduce (ws), dv_infonce_fwd (workspace, bytes),
+      dv_augment_ingest (blur, blur_scratch) gained arguments; dv_bn_item grew by red_ws (round 2 of this build). */
+#define DV_ABI_VERSION 2
 
 enum { DV_F32 = 0, DV_BF16 = 1 };
 

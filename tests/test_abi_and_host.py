@@ -33,7 +33,9 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f'{name} missing from the ctypes table'
         assert len(_lib.SIGNATURES[name]) == len(args), (name, len(_lib.SIGNATURES[name]), args)
     assert set(_lib.SIGNATURES) == set(decl)
-    assert lib.dv_abi_version() == 1
+    hdr = open(os.path.join(ROOT, 'include', 'dualvar_hip.h')).read()
+    declared = int(re.search(r'#define\s+DV_ABI_VERSION\s+(\d+)', hdr).group(1))
+    assert lib.dv_abi_version() == declared == _lib.ABI_VERSION >= 2
 
 
 def test_argument_validation_without_gpu():
@@ -254,3 +256,37 @@ def test_backward_list_reorder_hides_syncbn_exchange_behind_weight_gradients():
     # single-GPU lists (no exchange steps) are untouched
     plain = [L_(n, t) for n, t in names if not n.startswith('syncbn')]
     assert [x.tag for x in overlap_bn_exchange(plain)] == [x.tag for x in plain]
+
+
+def _run_bench(argv, env_extra=None, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          env=env, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher on the command line must start two ranks itself (the reference's scripts launch
+    their 8 workers the same way, pretrain.py:205-220) and print n_gpus == 2 -- not silently time one rank.  --launch-check keeps
+    it to the launch / rendezvous / report plumbing so that it runs on a CPU-only host; the full 2-rank bench runs in
+    tests/test_distributed_gpu.py."""
+    import json
+    r = _run_bench(['--gpus', '2', '--launch-check'])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout.decode()
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['sum'] == 2.0
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = _run_bench(['--gpus', '2', '--launch-check'], {'WORLD_SIZE': '1', 'RANK': '0'})
+    assert r.returncode != 0 and b'WORLD_SIZE is 1' in r.stderr
+
+
+def test_bench_watchdog_names_the_stuck_phase():
+    """a collective one rank never joins ends as a named phase and a non-zero exit code within the deadline, not as a silent hang"""
+    r = _run_bench(['--gpus', '2', '--launch-check', '--hang-check', '3'], timeout=200)
+    assert r.returncode != 0
+    assert b'WATCHDOG' in r.stderr and b'launch-check all-reduce' in r.stderr
+    assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')]
