@@ -141,11 +141,24 @@ def test_two_ranks_equal_one_process(gpu, kind):
             # after GradSync every rank holds the same averaged gradient = single-process gradient / world
             assert torch.allclose(res[0][2][k], res[1][2][k])
             assert torch.allclose(res[0][2][k], gsum / 2, rtol=1e-5, atol=1e-8)
-        print('sum-over-ranks param grad vs single process: worst rel err', worst, worst_key)
-        # the per-rank problems are half as tall, so they run with different tile shapes (= summation orders) than the
-        # single-process run; at B=4 the BatchNorm backward amplifies that to ~1e-3..1e-2 in individual tensors
-        # (identical tile shapes gave 6.5e-6).  The exact identities are the two asserts inside the loop.
-        assert worst < 3e-2
+        # The per-rank problems are half as tall, so they run with different tile shapes (= summation orders, and in fp32 mode
+        # other groupings of the six partial products) than the single-process run: the two gradients cannot agree better than
+        # the single-process gradient agrees with itself under a rounding-sized change.  Measure that: the same single-process
+        # backward with the input nudged by 1e-7 (relative, per element) -- at B = 4 the BatchNorm backward of the random-init R3D
+        # amplifies it to 1e-4 .. 1e-2 in individual tensors -- and bound the identity by k = 10 times it.
+        # Recorded on MI355X (gpurun r3, same seed): see the printed line; DUALVAR_F32_EXACT=1 (exact-f32 MFMA, no operand
+        # split) gives the same order of magnitude, i.e. the band is the conditioning of the net, not the split.
+        block = P.procedural_clips(B, V, T, H, H)
+        noise = torch.from_numpy(np.random.RandomState(99).standard_normal(block.numel())).float().reshape(block.shape)
+        np.random.seed(1234)
+        _, grads_n = _run(m, (block * (1 + 1e-7 * noise)).to(gpu))
+        spread = max(float((grads_n[k] - g1).abs().max() / (g1.abs().max() + 1e-12)) for k, g1 in grads1.items())
+        np.random.seed(1234)
+        _, grads_r = _run(m, block.to(gpu))
+        assert all(torch.equal(grads_r[k], grads1[k]) for k in grads1), 'the single-process backward must be bit-reproducible'
+        print('sum-over-ranks param grad vs single process: worst rel err %.3e (%s); single-process spread under a 1e-7 input nudge '
+              '%.3e; F32_EXACT=%s' % (worst, worst_key, spread, os.environ.get('DUALVAR_F32_EXACT', '0')))
+        assert worst < max(1e-4, 10 * spread), (worst, spread)
 
 
 # ---------------------------------------------------------------------------------------------------------------

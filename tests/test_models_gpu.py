@@ -1,6 +1,8 @@
 """End-to-end GPU parity of the HIP engine against the golden fixtures (reference outputs) and the oracle.
 
-fp32 mode (exact-fp32 MFMA) is the parity proof.  Base tolerances: pooled features 3e-4 relative, step-0 logits
+fp32 mode is the parity proof: fp32 storage, statistics and accumulation; products on the bf16 matrix cores through the exact
+3-way bf16 split of every fp32 operand (six partial products, error at fp32 rounding level; DUALVAR_F32_EXACT=1 selects the
+exact-f32 MFMA kernels for A/B runs -- same pass / fail, same error magnitudes).  Base tolerances: pooled features 3e-4 relative, step-0 logits
 2e-3 absolute (scale 1/T = 14.3), step-0 loss 1e-3 (the north-star bound), gradient |g| checksums 2e-2, parameters
 after the SGD steps 5e-3.  Randomly initialised BatchNorm nets amplify rounding-sized perturbations exponentially
 with depth (S3D-G: the reference's own fp32 output differs from its fp64 output by 1.6e-4, and after ONE SGD step
@@ -150,7 +152,15 @@ def test_train_steps_fp32_against_reference_fixture(gpu, kind, net, B, steps):
                 assert nsamp >= 12 and worst < 1.0, (nsamp, worst, wkey)
         opt.step()
         lsens = max([float(g[k]) for k in g.files if k.startswith('sens/last/out/') and 'logits' in k] + [0.0]) if it > 0 else 0.0
-        assert abs(float(loss) - float(g[f'loss_step{it}'])) < max(1e-3, 5 * float(g[f'sens/loss_step{it}']), 0.1 * lsens)
+        bound = max(1e-3, 5 * float(g[f'sens/loss_step{it}']), 0.1 * lsens)
+        if bound > 1e-2:
+            # NOT a parity statement: at the paper's lr = 0.003 the randomly initialised S3D-G leaves its basin in one step and
+            # the REFERENCE's own post-step logits move by O(1) under a 1e-6 input nudge (sens/last/out/*), so this bound is
+            # ~0.3 on a loss of ~2.  It only catches a diverged step.  S3D-G's backward + optimizer are pinned by
+            # test_s3dg_well_conditioned_steps_fp32 (wc/* fixtures, lr 3e-7, bound <= max(1e-3, 5 sens)) and by the
+            # element-wise gradient samples above.
+            report.append((f'step{it}', 'loss bound %.2g is a divergence check only (ill-conditioned fixture)' % bound))
+        assert abs(float(loss) - float(g[f'loss_step{it}'])) < bound
     pc = param_checksum(m, P)
     worst = max(abs(v[0] - g[f'param/{k}'][0]) / max(5e-3 * abs(g[f'param/{k}'][0]) + 1e-9, (10 if steps <= 2 else 25) * float(g[f'sens/param/{k}']))
                 for k, v in pc.items() if f'param/{k}' in g.files)
@@ -625,12 +635,37 @@ def test_r50_fp8_pointwise_mode(gpu):
     assert abs(losses['fp8pw'][0] - losses['bf16'][0]) < 0.15 and abs(losses['fp8pw'][1] - losses['bf16'][1]) < 0.3
 
 
+def test_r50_fp8_pointwise_mode_at_32x224(gpu):
+    """fp8pw on ITS OWN config (BASELINE configs[4]: 32 x 224 x 224 clips; 16x the rows of the 8 x 112 x 112 test, other tile
+    choices: 128-row tiles on every pointwise GEMM), B = 1, against the reference's pooled features of tests/golden/shapes.npz
+    (`r50_224/*`).  Same TOLERANCE STATEMENT as test_r50_fp8_pointwise_mode: within 2x of what e4m3 quantisation of the
+    pointwise operands does to the oracle, plus the bf16-storage bound (8e-2)."""
+    from dualvar_amd.backbone import select_backbone
+    P = _P()
+    g = gold('shapes')
+    x = P.procedural_clips(1, 1, T=32, H=224, W=224)[:, 0]
+    emu, n_fp8 = _fp8_emulated_oracle(P, x)
+    e_emu = rel_err(emu.mean(dim=(2, 3, 4)).numpy(), g['r50_224/pooled'])
+    m, _ = select_backbone('r50')
+    P.procedural_init(m)
+    m.set_compute_dtype('fp8pw').train().to(gpu)
+    with torch.no_grad():
+        fmap = m(x.to(gpu))
+    assert tuple(fmap.shape) == tuple(g['r50_224/shape'])
+    kn = [l.kname for pl in m._plans.values() for p_ in pl for l in p_.f_list]
+    assert sum('conv_gemm<fp8,FWD' in k for k in kn) == n_fp8 == 23
+    e = rel_err(fmap.mean(dim=(2, 3, 4)).cpu().numpy(), g['r50_224/pooled'])
+    print(f'r50 fp8pw 32x224x224: pooled rel err {e:.2e}; oracle with e4m3 pointwise operands {e_emu:.2e}')
+    assert e < 2 * e_emu + 8e-2
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # optional plan: BatchNorm-backward reduce inside the consuming conv's data gradient (engine.FUSE_BN_REDUCE)
 @pytest.mark.parametrize('net,dtype', [('r3d', 'fp32'), ('r21d', 'fp32'), ('s3dg', 'bf16')])
 def test_fused_bn_reduce_plan_gives_the_same_gradients(gpu, monkeypatch, net, dtype):
     """DUALVAR_FUSE_BN_REDUCE=1 moves the reduce of every conv -> BatchNorm -> conv chain with a single reader into
-    dv_conv3d_dgrad_bn.  Same step, same gradients up to the order of the fp32 sums (both forms end in float atomics)."""
+    dv_conv3d_dgrad_bn.  Same step, same gradients up to the order of the fp32 sums (the standalone reduce folds its per-block rows in
+    block order; the fused form adds one value per column and tile with an atomic into a few replicas)."""
     from dualvar_amd import engine, model as M
     block = torch.randn(4, 2, 3, 8, 64, 64, generator=torch.Generator().manual_seed(3)).to(gpu)
     grads, fused = [], []

@@ -1120,3 +1120,85 @@ def test_random_shapes_conv_and_pool(gpu):
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_ops.py'), '--n', '60', '--seed', '7'], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and 'ok: 60 random cases' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+BIG_M_CASES = [
+    # name, N, Cin, T, H, W, Cout, k, s, p   -- >= 200 704 output rows behind a 64-column tile (dgrad: input rows behind Cin = 64)
+    ('sp3_200k', 8, 64, 8, 56, 56, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('tm7_s2_200k', 16, 64, 8, 56, 56, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0)),
+]
+
+
+@pytest.mark.parametrize('case', BIG_M_CASES, ids=[c[0] for c in BIG_M_CASES])
+def test_fp32_conv_at_headline_tile_sizes_against_cpu_conv3d(gpu, case):
+    """The fp32 instantiations only big layers reach, against an oracle: M >= 200 k rows x 64 channels selects
+    conv_gemm<f32,FWD,256,64> / <f32,DGRAD,256,64> (pick_tile: >= 512 tiles of 256 rows) and a weight gradient of ~100 row
+    splits in the t-inner row order (7x1x1) -- at the 8..12-clip sizes of the other tests these layers run 64- / 128-row tiles
+    and a handful of splits.  Oracle: torch.nn.functional.conv3d on the CPU in float64 (the op the reference's nn.Conv3d is,
+    backbone/s3dg.py:39-42); the CPU fp32 result measures what fp32 arithmetic itself costs, the kernels must stay within 4x that."""
+    from dualvar_amd._lib import DV_W3
+    import ctypes as C
+    from dualvar_amd import _lib as L
+    name, N, Cin, T, H, W, Cout, k, s, p = case
+    x = rnd(N, Cin, T, H, W, seed=1).relu_()
+    w = rnd(Cout, Cin, *k, seed=2, scale=(Cin * k[0] * k[1] * k[2]) ** -0.5)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, s, p)
+    gy = rnd(*yr.shape, seed=3)
+    yr.backward(gy.double())
+    x32, w32 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y32 = F.conv3d(x32, w32, None, s, p)
+    y32.backward(gy)
+
+    def rel(a, ref):
+        return float((a.double().cpu() - ref).abs().max() / ref.abs().max())
+    cpu = {'fwd': rel(y32.detach(), yr.detach()), 'dgrad': rel(x32.grad, xr.grad), 'wgrad': rel(w32.grad, wr.grad)}
+
+    xa = ops.act_from_ncdhw(x.to(gpu), DV_F32)
+    To, Ho, Wo = yr.shape[2:]
+    ya = ops.new_act(N, To, Ho, Wo, Cout, DV_F32, gpu, zero=True)
+    d = ops.conv_desc(DV_F32, xa, ya, k, s, p, flags=ops.DV_STATS | DV_W3)
+    rows_, cols_ = C.c_int32(), C.c_int32()
+    lib = L.load()
+    for dg in (0, 1):
+        assert lib.dv_conv3d_tile_shape(C.byref(d), dg, C.byref(rows_), C.byref(cols_)) == 0
+        if not (dg and max(s) > 1):       # (a strided data gradient runs one launch per parity class on fewer rows each)
+            assert (rows_.value, cols_.value) == (256, 64), (name, dg, rows_.value, cols_.value)
+    wp = ops.pack_weight(w.to(gpu), ops.cp8(Cin))
+    tiles = ops.stat_tiles(d)
+    stats = torch.zeros(2, Cout, tiles, device=gpu)
+    ops.conv_fwd(d, xa, ops.pack_w3(wp.view(Cout, -1)), None, ya, stats)
+    got = {'fwd': rel(ops.act_to_ncdhw(ya), yr.detach())}
+    # fused BatchNorm partials of the 256-row tiles == statistics of the float64 output
+    M = N * To * Ho * Wo
+    local = torch.zeros(2 * Cout + 1, device=gpu)
+    ops.call('dv_bn_reduce_stats', stats, tiles, ops.tile_rows(d), Cout, M, Cout, local)
+    mean_ref, var_ref = yr.detach().mean(dim=(0, 2, 3, 4)), yr.detach().var(dim=(0, 2, 3, 4), unbiased=False)
+    assert float(((local[:Cout].cpu().double() / M) - mean_ref).abs().max()) <= 2e-6 * float(var_ref.sqrt().max())
+    assert torch.allclose(local[Cout:2 * Cout].cpu().double() / M, var_ref, rtol=5e-6)
+
+    dya = ops.act_from_ncdhw(gy.to(gpu), DV_F32)
+    d2 = ops.conv_desc(DV_F32, xa, dya, k, s, p)
+    r_, c_, sp_ = C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.dv_conv3d_wgrad_tile(C.byref(d2), C.byref(r_), C.byref(c_), C.byref(sp_)) == 0
+    assert sp_.value >= 64, (name, sp_.value)
+    dw = torch.zeros_like(wp)
+    ops.conv_wgrad(d2, xa, dya, dw)
+    dw2 = torch.zeros_like(wp)
+    ops.conv_wgrad(d2, xa, dya, dw2)
+    assert torch.equal(dw, dw2)
+    got['wgrad'] = rel(ops.unpack_weight(dw, w.shape), wr.grad)
+
+    taps = k[0] * k[1] * k[2]
+    wd = torch.zeros(Cin, taps, ops.cp8(Cout), device=gpu)
+    wd[:, :, :Cout] = w.to(gpu).reshape(Cout, Cin, taps).permute(1, 2, 0)
+    dxa = ops.new_act(N, T, H, W, Cin, DV_F32, gpu, zero=True)
+    if max(s) == 1:
+        ops.conv_dgrad(ops.conv_desc(DV_F32, xa, dya, k, s, p, flags=DV_W3), dya, ops.pack_w3(wd.view(Cin, -1)), dxa)
+    else:
+        ops.conv_dgrad(d2, dya, wd, dxa)
+    got['dgrad'] = rel(ops.act_to_ncdhw(dxa), xr.grad)
+    print(name, 'relative-to-max error vs float64:', {k_: ('%.2e (cpu fp32 %.2e)' % (got[k_], cpu[k_])) for k_ in got},
+          'wgrad splits', sp_.value)
+    for k_ in got:
+        assert got[k_] <= max(4 * cpu[k_], 2e-6), (name, k_, got[k_], cpu[k_])

@@ -1,5 +1,5 @@
-"""Size-independent properties at the BASELINE sizes (128 clips of 8x112x112 per GPU, bf16) -- where the CPU oracle would
-take minutes per layer, the kernels are checked through identities that hold at any size:
+"""Size-independent properties at the BASELINE sizes (128 clips of 8x112x112 per GPU; fp32 -- the headline arithmetic -- and
+bf16) -- where the CPU oracle would take minutes per layer, the kernels are checked through identities that hold at any size:
 
   * conv: <conv(x, w), dy> == <x, dgrad(dy, w)> == <w, wgrad(x, dy)>  (fwd / dgrad / wgrad are mutual adjoints) on the
     largest S3D-G layers, and exact homogeneity conv(x, 2w) == 2 conv(x, w) (a power-of-two scale is exact in bf16);
@@ -15,7 +15,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from dualvar_amd import ops  # noqa: E402
-from dualvar_amd.ops import DV_BF16  # noqa: E402
+from dualvar_amd.ops import DV_BF16, DV_F32  # noqa: E402
+
+DTYPES = [pytest.param(DV_F32, id='fp32'), pytest.param(DV_BF16, id='bf16')]
 
 N_CLIPS = 128
 
@@ -41,23 +43,38 @@ def _dot(a, b):
     return float((a.double() * b.double()).sum())
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('layer', BIG_LAYERS, ids=[c[0] for c in BIG_LAYERS])
-def test_conv_adjoint_identities_at_full_size(gpu, layer):
+def test_conv_adjoint_identities_at_full_size(gpu, layer, dtype):
+    """fp32: the instantiations only the headline-size step reaches -- conv_gemm<f32,*,256,64> (>= 131 k rows behind a 64-column
+    tile), weight gradients with >= 100 row splits, the t-inner row order -- run here with the engine's pre-split weights
+    (DV_W3) where the engine uses them (forward; stride-1 data gradient)."""
+    from dualvar_amd._lib import DV_W3
     name, N_CLIPS, T, H, W, Ci, Co, k, s, p = layer
+    tdt = ops.TORCH_DTYPE[dtype]
+    f32 = dtype == DV_F32
     g = torch.Generator(device='cpu').manual_seed(7)
-    x = ops.new_act(N_CLIPS, T, H, W, Ci, DV_BF16, gpu)
-    x.buf.copy_(torch.randn(x.buf.shape, generator=g).relu_().to(torch.bfloat16))
+    x = ops.new_act(N_CLIPS, T, H, W, Ci, dtype, gpu)
+    x.buf.copy_(torch.randn(x.buf.shape, generator=g).relu_().to(tdt))
     To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
-    y, dy = ops.new_act(N_CLIPS, To, Ho, Wo, Co, DV_BF16, gpu), ops.new_act(N_CLIPS, To, Ho, Wo, Co, DV_BF16, gpu)
-    dy.buf.copy_(torch.randn(dy.buf.shape, generator=g).to(torch.bfloat16))
+    y, dy = ops.new_act(N_CLIPS, To, Ho, Wo, Co, dtype, gpu), ops.new_act(N_CLIPS, To, Ho, Wo, Co, dtype, gpu)
+    dy.buf.copy_(torch.randn(dy.buf.shape, generator=g).to(tdt))
     taps = k[0] * k[1] * k[2]
     wf = (torch.randn(Co, taps, Ci, generator=g) * (taps * Ci) ** -0.5).to(gpu)            # master layout [Co][tap][Ci]
-    w16 = wf.to(torch.bfloat16)
-    wd = w16.float().permute(2, 1, 0).contiguous().to(torch.bfloat16)                      # dgrad layout [Ci][tap][Co]
-    d = ops.conv_desc(DV_BF16, x, y, k, s, p)
-    ops.conv_fwd(d, x, w16, None, y, None)
+    w16 = wf.to(tdt)
+    wd = w16.float().permute(2, 1, 0).contiguous().to(tdt)                                 # dgrad layout [Ci][tap][Co]
+    d = ops.conv_desc(dtype, x, y, k, s, p)
     dx = x.like()
-    ops.conv_dgrad(d, dy, wd, dx)
+    if f32:
+        d3 = ops.conv_desc(dtype, x, y, k, s, p, flags=DV_W3)
+        ops.conv_fwd(d3, x, ops.pack_w3(w16.view(Co, -1)), None, y, None)
+        if max(s) == 1:
+            ops.conv_dgrad(d3, dy, ops.pack_w3(wd.view(Ci, -1)), dx)
+        else:
+            ops.conv_dgrad(d, dy, wd, dx)
+    else:
+        ops.conv_fwd(d, x, w16, None, y, None)
+        ops.conv_dgrad(d, dy, wd, dx)
     dw = torch.zeros(Co, taps * Ci, device=gpu)
     ops.conv_wgrad(d, x, dy, dw)
     torch.cuda.synchronize()
@@ -68,73 +85,88 @@ def test_conv_adjoint_identities_at_full_size(gpu, layer):
     assert torch.equal(dw, dw2), 'the weight gradient must be reproducible bit for bit'
     c = _dot(w16.float().reshape(Co, -1), dw)  # <w, wgrad(x,dy)>  (fp32 accumulation, exact up to summation order)
     scale = float(y.buf.double().norm() * dy.buf.double().norm())
-    print(f'{name}: <y,dy>={a:.6e} <x,dx>={b:.6e} <w,dw>={c:.6e} (|y||dy|={scale:.3e})')
-    # rounding of y / dx to bf16 is unbiased: the inner products agree to ~2^-9 / sqrt(#elements) of |y||dy|
-    assert abs(a - c) <= 2e-4 * scale and abs(b - c) <= 2e-4 * scale
-    # homogeneity: doubling the weights doubles every output bit for bit
+    print(f'{name}: <y,dy>={a:.6e} <x,dx>={b:.6e} <w,dw>={c:.6e} (|y||dy|={scale:.3e}) '
+          f'|a-c|/scale={abs(a - c) / scale:.2e} |b-c|/scale={abs(b - c) / scale:.2e}')
+    # bf16: rounding of y / dx to bf16 is unbiased: the inner products agree to ~2^-9 / sqrt(#elements) of |y||dy|
+    # fp32: every element of y / dx / dw carries a relative error of a few 2^-24; the three inner products agree to 1e-6 of |y||dy|
+    tol = 1e-6 if f32 else 2e-4
+    assert abs(a - c) <= tol * scale and abs(b - c) <= tol * scale
+    # homogeneity: doubling the weights doubles every output bit for bit (a power of two scales the bf16 triple of an fp32 weight
+    # exactly as well)
     y2 = y.like()
-    ops.conv_fwd(d, x, (w16.float() * 2).to(torch.bfloat16), None, y2, None)
+    if f32:
+        ops.conv_fwd(d3, x, ops.pack_w3((w16 * 2).view(Co, -1)), None, y2, None)
+    else:
+        ops.conv_fwd(d, x, (w16.float() * 2).to(torch.bfloat16), None, y2, None)
     assert torch.equal(y2.buf.float(), y.buf.float() * 2)
 
 
-def test_batchnorm_statistics_and_backward_orthogonality_at_full_size(gpu):
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_batchnorm_statistics_and_backward_orthogonality_at_full_size(gpu, dtype):
     """the stem's BatchNorm (M = 128*8*56*56 = 3.2 M rows, C = 64): conv epilogue partials -> statistics -> apply ->
-    backward reduce / apply"""
-    from dualvar_amd._lib import DV_NO_RELU_MASK
+    backward reduce / apply; fp32 = the headline step's arithmetic (256 x 64 forward tiles, two-pass M2 partials)"""
+    from dualvar_amd._lib import DV_NO_RELU_MASK, DV_W3
+    f32 = dtype == DV_F32
+    tdt = ops.TORCH_DTYPE[dtype]
     T, H, W, C_ = 8, 56, 56, 64
     g = torch.Generator().manual_seed(11)
-    xin = ops.new_act(N_CLIPS, T, H, W, 64, DV_BF16, gpu)
-    xin.buf.copy_(torch.randn(xin.buf.shape, generator=g).to(torch.bfloat16))
-    x = ops.new_act(N_CLIPS, T, H, W, C_, DV_BF16, gpu)
-    d = ops.conv_desc(DV_BF16, xin, x, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=ops.DV_STATS)
-    w16 = (torch.randn(C_, 64, generator=g) / 8).to(gpu).to(torch.bfloat16)
+    xin = ops.new_act(N_CLIPS, T, H, W, 64, dtype, gpu)
+    xin.buf.copy_(torch.randn(xin.buf.shape, generator=g).to(tdt))
+    x = ops.new_act(N_CLIPS, T, H, W, C_, dtype, gpu)
+    d = ops.conv_desc(dtype, xin, x, (1, 1, 1), (1, 1, 1), (0, 0, 0), flags=ops.DV_STATS | (DV_W3 if f32 else 0))
+    w16 = (torch.randn(C_, 64, generator=g) / 8).to(gpu).to(tdt)
     tiles = ops.stat_tiles(d)
     part = torch.zeros(2, C_, tiles, device=gpu)
-    ops.conv_fwd(d, xin, w16, None, x, part)
+    ops.conv_fwd(d, xin, ops.pack_w3(w16) if f32 else w16, None, x, part)
     M = x.rows
     gamma, beta = (1 + 0.2 * torch.randn(C_, generator=g)).to(gpu), (0.1 * torch.randn(C_, generator=g)).to(gpu)
     local = torch.zeros(2 * C_ + 1, device=gpu)
     mean, invstd, scale, shift = (torch.zeros(C_, device=gpu) for _ in range(4))
     ops.call('dv_bn_stats_finalize', part, tiles, ops.tile_rows(d), C_, M, C_, local, gamma, beta, 1e-5, 0.1, None, None,
              mean, invstd, scale, shift)
-    xs = x.buf.float()
-    assert torch.allclose(mean, xs.mean(0), atol=2e-5, rtol=1e-4)                       # fused partials == direct statistics
-    assert torch.allclose(invstd, (xs.var(0, unbiased=False) + 1e-5).rsqrt(), rtol=2e-4)
+    xs = x.buf.double()
+    mean_ref, var_ref = xs.mean(0), xs.var(0, unbiased=False)
+    # fused partials == direct statistics of the stored tensor (float64 reference)
+    assert float((mean.double() - mean_ref).abs().max()) <= (2e-6 if f32 else 2e-5) * float(var_ref.sqrt().max())
+    assert torch.allclose(invstd.double(), (var_ref + 1e-5).rsqrt(), rtol=2e-6 if f32 else 2e-4)
     y = x.like()
-    ops.call('dv_bn_apply', DV_BF16, x, x.ld, scale, shift, None, 0, y, y.ld, M, C_, 0)
-    ys = y.buf.float()
-    assert float((ys.mean(0) - beta).abs().max()) < 2e-3                                 # bf16 storage of y
-    assert float((ys.var(0, unbiased=False).sqrt() - gamma.abs()).abs().max()) < 5e-3
+    ops.call('dv_bn_apply', dtype, x, x.ld, scale, shift, None, 0, y, y.ld, M, C_, 0)
+    ys = y.buf.double()
+    assert float((ys.mean(0) - beta.double()).abs().max()) < (2e-6 if f32 else 2e-3)          # (bf16: storage of y)
+    assert float((ys.var(0, unbiased=False).sqrt() - gamma.abs().double()).abs().max()) < (1e-5 if f32 else 5e-3)
     dy = x.like()
-    dy.buf.copy_(torch.randn(dy.buf.shape, generator=g).to(torch.bfloat16))
+    dy.buf.copy_(torch.randn(dy.buf.shape, generator=g).to(tdt))
     CP = ops.cp8(C_)
     sums = torch.zeros(8, 2, CP, device=gpu)
-    ops.call('dv_bn_bwd_reduce', DV_BF16, dy, dy.ld, y, y.ld, x, x.ld, mean, invstd, M, C_, DV_NO_RELU_MASK, sums, 8, None)
+    ops.call('dv_bn_bwd_reduce', dtype, dy, dy.ld, y, y.ld, x, x.ld, mean, invstd, M, C_, DV_NO_RELU_MASK, sums, 8, None)
     dx = x.like()
     dgam, dbet = torch.zeros(C_, device=gpu), torch.zeros(C_, device=gpu)
-    ops.call('dv_bn_bwd_apply', DV_BF16, dy, dy.ld, y, y.ld, x, x.ld, mean, invstd, gamma, sums, 8, 1.0 / M, 1.0, dgam, dbet,
+    ops.call('dv_bn_bwd_apply', dtype, dy, dy.ld, y, y.ld, x, x.ld, mean, invstd, gamma, sums, 8, 1.0 / M, 1.0, dgam, dbet,
              dx, dx.ld, None, 0, M, C_, DV_NO_RELU_MASK)
     torch.cuda.synchronize()
-    gs = dy.buf.float()
-    assert torch.allclose(dbet, gs.sum(0), rtol=1e-3, atol=1e-1)
-    xhat = (xs - mean) * invstd
-    assert torch.allclose(dgam, (gs * xhat).sum(0), rtol=2e-3, atol=1.0)
+    gs = dy.buf.double()
+    assert torch.allclose(dbet.double(), gs.sum(0), rtol=1e-3, atol=1e-1)
+    xhat = (xs - mean.double()) * invstd.double()
+    assert torch.allclose(dgam.double(), (gs * xhat).sum(0), rtol=2e-3, atol=1.0)
     # the BatchNorm backward projects out the constant and the xhat direction of every channel
-    dxs = dx.buf.float()
+    dxs = dx.buf.double()
     tot = dxs.abs().sum(0)
-    assert float((dxs.sum(0).abs() / tot).max()) < 2e-3 and float(((dxs * xhat).sum(0).abs() / tot).max()) < 2e-3
+    lim = 2e-6 if f32 else 2e-3
+    assert float((dxs.sum(0).abs() / tot).max()) < lim and float(((dxs * xhat).sum(0).abs() / tot).max()) < lim
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('k,s,p,T,H,W,C_', [((3, 3, 3), (1, 1, 1), (1, 1, 1), 4, 14, 14, 256),
                                             ((1, 3, 3), (1, 2, 2), (0, 1, 1), 4, 56, 56, 64)])
-def test_maxpool_bounds_and_gradient_mass_at_full_size(gpu, k, s, p, T, H, W, C_):
+def test_maxpool_bounds_and_gradient_mass_at_full_size(gpu, k, s, p, T, H, W, C_, dtype):
+    tdt = ops.TORCH_DTYPE[dtype]
     g = torch.Generator().manual_seed(13)
-    x = ops.new_act(N_CLIPS, T, H, W, C_, DV_BF16, gpu)
-    x.buf.copy_(torch.randn(x.buf.shape, generator=g).relu_().to(torch.bfloat16))
+    x = ops.new_act(N_CLIPS, T, H, W, C_, dtype, gpu)
+    x.buf.copy_(torch.randn(x.buf.shape, generator=g).relu_().to(tdt))
     To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
-    y = ops.new_act(N_CLIPS, To, Ho, Wo, C_, DV_BF16, gpu)
+    y = ops.new_act(N_CLIPS, To, Ho, Wo, C_, dtype, gpu)
     idx = torch.zeros(y.rows, ops.cp8(C_), dtype=torch.uint8, device=gpu)
-    d = ops.pool_desc(DV_BF16, x, y, k, s, p)
+    d = ops.pool_desc(dtype, x, y, k, s, p)
     ops.call('dv_maxpool3d_fwd', d, x, y, idx)
     xs, ys = x.buf.view(N_CLIPS, T, H, W, C_), y.buf.view(N_CLIPS, To, Ho, Wo, C_)
     # the centre tap of every window is inside it: y >= x at the window centres; and y never exceeds the global maximum
@@ -142,20 +174,22 @@ def test_maxpool_bounds_and_gradient_mass_at_full_size(gpu, k, s, p, T, H, W, C_
     assert bool((ys >= ctr).all()) and float(ys.float().max()) == float(xs.float().max())
     assert int(idx.max()) < k[0] * k[1] * k[2]
     dy = y.like()
-    dy.buf.copy_(torch.randn(dy.buf.shape, generator=g).to(torch.bfloat16))
+    dy.buf.copy_(torch.randn(dy.buf.shape, generator=g).to(tdt))
     dx = x.like()
     ops.call('dv_maxpool3d_bwd', d, dy, idx, dx, 0)
     torch.cuda.synchronize()
     sy, sx = dy.buf.double().sum(0), dx.buf.double().sum(0)               # per channel: every dy lands on exactly one input
-    assert float((sy - sx).abs().max()) <= 2e-3 * float(dy.buf.double().abs().sum(0).max())
+    # (an input that wins several windows holds the fp32 / bf16 SUM of their gradients: one rounding per such element)
+    assert float((sy - sx).abs().max()) <= (2e-7 if dtype == DV_F32 else 2e-3) * float(dy.buf.double().abs().sum(0).max())
 
 
-def test_full_size_step_is_batch_symmetric_and_loss_matches_its_logits(gpu):
-    """S3D-G SimCLR_Naked, 64 samples x 2 views of 8x112x112, bf16 (the bench workload)"""
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_full_size_step_is_batch_symmetric_and_loss_matches_its_logits(gpu, mode):
+    """S3D-G SimCLR_Naked, 64 samples x 2 views of 8x112x112 (the bench workload), in fp32 (the headline arithmetic) and bf16"""
     from dualvar_amd import model as M
     torch.manual_seed(0)
     m = M.SimCLR_Naked('s3dg', 128, 0.07, False)
-    m.set_compute_dtype('bf16').train().to(gpu)
+    m.set_compute_dtype(mode).train().to(gpu)
     g = torch.Generator().manual_seed(5)
     block = torch.randn(64, 2, 3, 8, 112, 112, generator=g).to(gpu)
     perm = torch.randperm(64, generator=g).to(gpu)
@@ -168,9 +202,51 @@ def test_full_size_step_is_batch_symmetric_and_loss_matches_its_logits(gpu):
     ce = float(torch.nn.functional.cross_entropy(lg, torch.zeros(128, dtype=torch.long)))
     assert abs(ce - float(r1['clip_contrast_loss'])) < 1e-4
     # batch statistics do not depend on the order of the samples: same loss, and row i's positive logit moves with it
-    assert abs(float(r1['clip_contrast_loss']) - float(r2['clip_contrast_loss'])) < 5e-2
+    # (a permutation regroups the partial sums of the statistics; the random-init S3D-G amplifies that rounding-sized change --
+    # DESIGN section 2 -- which bf16 storage of every activation then multiplies)
+    dl = abs(float(r1['clip_contrast_loss']) - float(r2['clip_contrast_loss']))
     pos1, pos2 = lg[:64, 0], r2['clip_logits'].float().cpu()[:64, 0]
-    assert float((pos1[perm.cpu()] - pos2).abs().max()) < 0.15 * float(pos1.abs().max())
+    dp = float((pos1[perm.cpu()] - pos2).abs().max()) / float(pos1.abs().max())
+    print(f'{mode}: |dloss| under a batch permutation {dl:.3e}, positive logits {dp:.3e} (relative)')
+    assert dl < (2e-3 if mode == 'fp32' else 5e-2) and dp < (2e-2 if mode == 'fp32' else 0.15)
+
+
+def test_full_size_fp32_training_step(gpu):
+    """The headline bench step itself (S3D-G SimCLR_Naked fp32, 64 x 2 clips of 8x112x112): forward, backward, SGD.  Finite
+    gradients everywhere, the step is reproducible bit for bit from the same state, and the loss goes down along the gradient for a
+    small enough step (a wrong tile or a wrong split in any big-M weight gradient breaks the last two)."""
+    from dualvar_amd import model as M
+    from dualvar_amd.optim import SGD
+
+    def run(lr, steps):
+        torch.manual_seed(0)
+        m = M.SimCLR_Naked('s3dg', 128, 0.07, False)
+        m.set_compute_dtype('fp32').train().to(gpu)
+        block = torch.randn(64, 2, 3, 8, 112, 112, generator=torch.Generator().manual_seed(5)).to(gpu)
+        opt = SGD([p for p in m.parameters() if p.requires_grad], lr=lr, momentum=0.0, weight_decay=0.0, stores=m.stores())
+        losses, grads = [], None
+        for _ in range(steps):
+            ret = m(block)
+            opt.zero_grad()
+            ret['clip_contrast_loss'].backward()
+            if grads is None:
+                grads = [st.grad.detach().clone() for st in m.stores()]
+            opt.step()
+            losses.append(float(ret['clip_contrast_loss']))
+        return losses, grads
+
+    _, g0 = run(0.0, 1)
+    assert all(bool(torch.isfinite(g).all()) for g in g0)
+    gn2 = float(sum(float(g.double().pow(2).sum()) for g in g0))
+    assert gn2 > 0
+    # first-order decrease: L(w - lr g) - L(w) = -lr |g|^2 (1 + O(lr)); lr chosen for a predicted decrease of 0.02 on a loss of ~4.8
+    lr = 0.02 / gn2
+    l1, g1 = run(lr, 2)
+    l2, g2 = run(lr, 2)
+    assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(g1, g2)), 'the fp32 step must be bit-reproducible'
+    assert all(torch.equal(a, b) for a, b in zip(g0, g1))
+    print(f'|g|^2 {gn2:.4e}, lr {lr:.3e}: loss {l1[0]:.6f} -> {l1[1]:.6f}; predicted decrease 0.02, observed {l1[0] - l1[1]:.4e}')
+    assert 0.01 < l1[0] - l1[1] < 0.03
 
 
 def test_full_size_16_frame_step_bf16(gpu):
