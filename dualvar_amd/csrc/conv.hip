@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -302,31 +304,42 @@ __device__ __forceinline__ Split3 split3(const float (&v)[8]) {
 // R(2+1)D fixture (a weight gradient enters the next step scaled by the learning rate; an activation enters it directly).  Truncating hi too would cost the same 36 but biases every dropped partial product
 // (mid*lo, lo*mid, lo*lo) towards the sign of x*y: in the long, cancelling sums of a weight gradient that bias showed as
 // 1e-1 relative differences between a batch and its two halves (1e-3 .. 1e-2 with the rounded hi).
-__device__ __forceinline__ Split3 split3w(const float (&v)[8]) {
+// one pair of values -> the pair's dword of each of the three planes (the step split3w repeats four times)
+__device__ __forceinline__ void split3w_pair(float x0, float x1, unsigned& H, unsigned& Mi, unsigned& Lo) {
   typedef __attribute__((ext_vector_type(2))) float f32x2;
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  const u32x2 mask = {0xffff0000u, 0xffff0000u};
+  const f32x2 x = {x0, x1};
+  const bf16x2 hb = __builtin_convertvector(x, bf16x2);              // one v_cvt_pk_bf16_f32
+  const unsigned hw = __builtin_bit_cast(unsigned, hb);
+  const u32x2 hwide = {hw << 16, hw & 0xffff0000u};
+  const f32x2 r1 = x - __builtin_bit_cast(f32x2, hwide);
+  const u32x2 rb = __builtin_bit_cast(u32x2, r1);
+  const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, rb & mask);
+  const u32x2 qb = __builtin_bit_cast(u32x2, r2);
+  H = hw;
+  Mi = __builtin_amdgcn_perm(rb.y, rb.x, 0x07060302u);
+  Lo = __builtin_amdgcn_perm(qb.y, qb.x, 0x07060302u);
+}
+__device__ __forceinline__ Split3 split3w(const float (&v)[8]) {
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
   u32x4v H, Mi, Lo;
-  const u32x2 mask = {0xffff0000u, 0xffff0000u};
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const f32x2 x = {v[2 * p], v[2 * p + 1]};
-    const bf16x2 hb = __builtin_convertvector(x, bf16x2);              // one v_cvt_pk_bf16_f32
-    const unsigned hw = __builtin_bit_cast(unsigned, hb);
-    const u32x2 hwide = {hw << 16, hw & 0xffff0000u};
-    const f32x2 r1 = x - __builtin_bit_cast(f32x2, hwide);
-    const u32x2 rb = __builtin_bit_cast(u32x2, r1);
-    const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, rb & mask);
-    const u32x2 qb = __builtin_bit_cast(u32x2, r2);
-    H[p] = hw;
-    Mi[p] = __builtin_amdgcn_perm(rb.y, rb.x, 0x07060302u);
-    Lo[p] = __builtin_amdgcn_perm(qb.y, qb.x, 0x07060302u);
+    unsigned h_, m_, l_;
+    split3w_pair(v[2 * p], v[2 * p + 1], h_, m_, l_);
+    H[p] = h_; Mi[p] = m_; Lo[p] = l_;
   }
   Split3 s;
   s.hi = __builtin_bit_cast(bf16x8, H); s.mid = __builtin_bit_cast(bf16x8, Mi); s.lo = __builtin_bit_cast(bf16x8, Lo);
   return s;
 }
+// compile-time loop: f(std::integral_constant<int, 0>()) ... f(std::integral_constant<int, N - 1>())
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>()), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>()); }
 __device__ __forceinline__ void mma_split3(const Split3& a, const Split3& b, f32x16& acc) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
@@ -922,6 +935,197 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
 }
 
 // ------------------------------------------------------------------------------------------
+// fwd / dgrad for FEW ROWS and a LONG K (fp32 split mode; the 1 152- and 12 544-row levels of S3D-G, Mixed_4b .. 5c, and the
+// projection heads): "K split over the waves".  With 18 .. 196 row tiles the grid of conv_gemm_kernel cannot fill the chip and
+// every workgroup walks 30 .. 216 K tiles one after the other, each step costing a global -> LDS round trip and a barrier
+// (measured 0.5 us per 64-byte K step: 12.9 TFLOP/s on the 1x3x3 data gradient of Mixed_5c).  Here the FOUR WAVES of a
+// workgroup own the same 64 x BN output tile and a quarter of the K range each: every wave runs a private NS-stage DMA
+// pipeline (its own LDS stages: no barrier in the K loop, only counted vmcnt waits), so four K steps are in flight per
+// workgroup and the sequential depth is a quarter.  The four partial tiles are added through LDS in wave order (fixed order:
+// bit-reproducible), then bias / activation / store / BatchNorm partials as in conv_gemm_kernel.
+// Restricted to what the engine's fp32 mode issues for those layers: pre-split weights (DV_W3), uniform-tap gathers
+// (channel pitch a multiple of 16, <= 32 taps), no parity classes, no fused BatchNorm-backward reduce.
+template <int MODE, int BN, int NS>
+__global__ __launch_bounds__(256) void conv_gemm_ks_kernel(ConvArgs a) {
+  constexpr int BM = 64, NW = 4, TM = 2, TN = BN / 32;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 96;          // one K tile: 16 f32 per row of A; hi|mid|lo of both k halves of B
+  constexpr int BPC = B_BYTES / 1024;
+  static_assert(B_BYTES % 1024 == 0, "B tile in 1 KiB pieces");
+  constexpr int STG = A_BYTES + B_BYTES;
+  constexpr int PIECES = A_BYTES / 1024 + BPC;
+  constexpr int D = NS - 1;
+  static_assert(D >= 1 && (D - 1) * PIECES <= 24, "counted wait");
+  constexpr unsigned kOOB = 0x80000000u;
+  static_assert(NW * NS * STG >= NW * BM * BN * 4 + BM * BN * 4, "the reduction scratch fits the stage buffers");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NW * NS * STG];
+
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int lbid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_n = lbid % a.ntn, tile_m = lbid / a.ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const dma_rsrc_t src_dma = dma_make_rsrc(a.src, (unsigned)a.src_bytes), w_dma = dma_make_rsrc(a.w, (unsigned)a.w_bytes);
+  unsigned char* wsm = smem + wave * (NS * STG);               // this wave's stages
+  const unsigned wbase = lds_addr(wsm);
+  const unsigned ldb = (unsigned)a.lds_ * 4u;
+  const int vslot = (lane & 3) ^ ((lane >> 4) & 3), vrow = lane >> 2;
+
+  unsigned rowoff[4], imask[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const RowPos r = decode_row<MODE>((uint32_t)(m0 + 16 * p + vrow), a.M, g);
+    unsigned bt = 0, bh = 0, bw = 0;
+    int pos;
+    if (MODE == MODE_FWD) {
+      for (int d = 0; d < g.kt; ++d) bt |= ((unsigned)(r.t0 + d) < (unsigned)g.sT ? 1u : 0u) << d;
+      for (int d = 0; d < g.kh; ++d) bh |= ((unsigned)(r.h0 + d) < (unsigned)g.sH ? 1u : 0u) << d;
+      for (int d = 0; d < g.kw; ++d) bw |= ((unsigned)(r.w0 + d) < (unsigned)g.sW ? 1u : 0u) << d;
+      pos = r.base + (r.t0 * g.sH + r.h0) * g.sW + r.w0;
+    } else {                                                   // stride 1 (checked on the host)
+      for (int d = 0; d < g.kt; ++d) { int v = r.t0 - d; bt |= ((v >= 0 && v < g.sT) ? 1u : 0u) << d; }
+      for (int d = 0; d < g.kh; ++d) { int v = r.h0 - d; bh |= ((v >= 0 && v < g.sH) ? 1u : 0u) << d; }
+      for (int d = 0; d < g.kw; ++d) { int v = r.w0 - d; bw |= ((v >= 0 && v < g.sW) ? 1u : 0u) << d; }
+      pos = r.base + (r.t0 * g.sH + r.h0) * g.sW + r.w0;
+    }
+    if (!r.valid) bt = 0;
+    unsigned inv = 0;
+    int tp = 0;
+    for (int dt = 0; dt < g.kt; ++dt)
+      for (int dh = 0; dh < g.kh; ++dh)
+        for (int dw = 0; dw < g.kw; ++dw, ++tp) inv |= ((((bt >> dt) & (bh >> dh) & (bw >> dw)) & 1u) ^ 1u) << tp;
+    imask[p] = inv;
+    rowoff[p] = (unsigned)pos * ldb + (unsigned)vslot * 16u;
+  }
+  unsigned woff[BPC];
+#pragma unroll
+  for (int p = 0; p < BPC; ++p) {
+    const unsigned o = (unsigned)p * 1024u + (unsigned)lane * 16u;
+    const unsigned hh = o / (BN * 48u), rem = o - hh * (BN * 48u);
+    woff[p] = (hh * (unsigned)a.ldw + (unsigned)n0) * 48u + rem;          // + K tile * ldw * 96 (a.ldw = padded rows)
+  }
+  // this wave's K range and its wave-uniform cursor
+  const int nk = g.Ktot / 16;
+  const int k_lo = (int)(((long long)nk * wave) / NW), k_hi = (int)(((long long)nk * (wave + 1)) / NW);
+  int u_tap = (k_lo * 16) / g.CP, u_c0 = k_lo * 16 - u_tap * g.CP;
+  int u_dw = u_tap % g.kw, u_dh = (u_tap / g.kw) % g.kh, u_dt = u_tap / (g.kw * g.kh);
+  auto tap_off = [&]() -> unsigned {
+    const int toff = MODE == MODE_FWD ? (u_dt * g.sH + u_dh) * g.sW + u_dw : -((u_dt * g.sH + u_dh) * g.sW + u_dw);
+    return (unsigned)toff * ldb;
+  };
+  unsigned u_toffb = tap_off();
+  auto gload = [&](int kt, int st) {
+    const unsigned s_a = u_toffb + (unsigned)u_c0 * 4u;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const unsigned off = ((__builtin_amdgcn_ubfe(imask[p], (unsigned)u_tap, 1u)) << 31) | (rowoff[p] + s_a);
+      dma_load16(src_dma, wbase + st * STG + p * 1024, off);
+    }
+#pragma unroll
+    for (int p = 0; p < BPC; ++p)
+      dma_load16(w_dma, wbase + st * STG + A_BYTES + p * 1024, woff[p] + (unsigned)kt * (unsigned)a.ldw * 96u);
+    u_c0 += 16;
+    if (u_c0 >= g.CP) {
+      u_c0 = 0;
+      ++u_tap;
+      if (++u_dw == g.kw) { u_dw = 0; if (++u_dh == g.kh) { u_dh = 0; ++u_dt; } }
+      u_toffb = tap_off();
+    }
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int swz = (l31 >> 2) & 3;
+  const int nmine = k_hi - k_lo;
+  for (int t = 0; t < D && t < nmine; ++t) gload(k_lo + t, t);
+  int cur = 0, nxt = D % NS;
+  for (int t = 0; t < nmine; ++t) {
+    dma_wait_upto(min(D - 1, nmine - 1 - t) * PIECES);         // tile t of this wave has landed
+    if (t + D < nmine) gload(k_lo + t + D, nxt);               // its stage was read by step t - 1 of THIS wave (program order)
+    const unsigned char* sa = wsm + cur * STG;
+    const unsigned char* sb = sa + A_BYTES;
+    Split3 af[TM], bf[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = split3_row(sa + (i * 32 + l31) * 64, h, swz);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const unsigned char* pb = sb + ((h * BN + j * 32 + l31) * 3) * 16;
+      bf[j].hi = *reinterpret_cast<const bf16x8*>(pb);
+      bf[j].mid = *reinterpret_cast<const bf16x8*>(pb + 16);
+      bf[j].lo = *reinterpret_cast<const bf16x8*>(pb + 32);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) mma_split3(af[i], bf[j], acc[i][j]);
+    cur = cur + 1 == NS ? 0 : cur + 1;
+    nxt = nxt + 1 == NS ? 0 : nxt + 1;
+  }
+  // ---- the four partial tiles -> LDS [wave][row][col], added in wave order
+  __syncthreads();                                             // every wave is done with its stages
+  float* red = reinterpret_cast<float*>(smem);                 // [NW][BM][BN]
+  float* fin = red + NW * BM * BN;                             // [BM][BN]: the tile as stored (statistics)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        red[(wave * BM + row) * BN + j * 32 + l31] = acc[i][j][r];
+      }
+  __syncthreads();
+  constexpr int CPT = BN / 4;                                  // columns per thread: thread = (row, quarter of the columns)
+  const int row = tid >> 2, c0 = (tid & 3) * CPT;
+  const int flags = a.flags;
+  const bool row_ok = m0 + row < a.M;
+  float* out = reinterpret_cast<float*>(a.out);
+#pragma unroll
+  for (int c4 = 0; c4 < CPT / 4; ++c4) {
+    const int col = c0 + c4 * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(red + (0 * BM + row) * BN + col);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(red + (w * BM + row) * BN + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int cg = n0 + col + e;
+      float x = v[e];
+      if (flags & DV_BIAS) x += cg < a.N ? a.bias[cg] : 0.f;
+      x = act_apply(x, flags);
+      if (cg >= a.N || !row_ok) x = 0.f;
+      v[e] = x;
+    }
+    *reinterpret_cast<f32x4*>(fin + row * BN + col) = v;
+    if (row_ok && n0 + col < a.NP) {
+      float* p = out + (size_t)(m0 + row) * a.ldo + n0 + col;
+      if (flags & DV_ACCUM) v += *reinterpret_cast<const f32x4*>(p);
+      *reinterpret_cast<f32x4*>(p) = v;
+    }
+  }
+  if constexpr (MODE == MODE_FWD) {
+    if (flags & DV_STATS) {                                    // per column: sum and M2 about the tile mean of the values as stored
+      __syncthreads();
+      if (tid < BN && n0 + tid < a.N) {
+        const int rows_here = min(BM, a.M - m0);
+        const int n_mt = (a.M + BM - 1) / BM;
+        float s = 0.f;
+        for (int r = 0; r < rows_here; ++r) s += fin[r * BN + tid];
+        const float mu = s / (float)rows_here;
+        float m2 = 0.f;
+        for (int r = 0; r < rows_here; ++r) { const float dlt = fin[r * BN + tid] - mu; m2 += dlt * dlt; }
+        a.stats[(size_t)(n0 + tid) * n_mt + tile_m] = s;
+        a.stats[(size_t)(a.N + n0 + tid) * n_mt + tile_m] = m2;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // wgrad kernels.  Each workgroup owns a BI (output channels) x BJ (im2col columns) tile of dW and a contiguous slice of
 // rows (a "row split"); 32 rows per step.  DETERMINISTIC two-phase accumulation: a workgroup stores its fp32 partial
 // tile with plain stores into slab[split] (caller-owned scratch, [splits][Cout][J]) and wgrad_reduce_kernel adds the
@@ -1488,6 +1692,387 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
 
 
 // ------------------------------------------------------------------------------------------
+// fp32 weight gradient, second form ("f32s"): products on the bf16 matrix cores as above, but laid out around the count of
+// vector instructions the operand SPLITS cost, which is what bounded conv_wgrad_dma_kernel<float, 64, 128, 1, 4, 2, true, true>
+// (PMC: vector issue 77 % busy, matrix pipe 42 %; ~210 vector instructions against 24 MFMAs per wave and 32-row step):
+//  * 1 x 4 waves, wave tiles BI x BJ/4 with BJ/4 = 64 (or 32): a wave splits its OWN x columns once per step and uses each
+//    fragment for TI = BI/32 blocks; the dY fragments, which every wave needs, are split once per WORKGROUP (a 64-lane
+//    "fragment op" per 8 rows x 64 columns, dealt over the waves) and shared through LDS planes in fragment order
+//    ([k group][hi|mid|lo][column] bf16x8: conflict-free ds_write_b128 / ds_read_b128).  Split instructions per MFMA:
+//    64x256: 3.75, 128x128: 3.0, 128x256: 2.25 (the 64x128 form above: 4.5, and its 2x2 predecessor 9);
+//  * ONE barrier per step instead of two: the planes are double buffered, and the loop is rotated -- iteration s multiplies
+//    step s (planes[s & 1], the x fragments split one iteration earlier) and, in the same basic block, splits step s + 1
+//    (vector ALU and LDS work the scheduler can place between the MFMAs), then waits for the DMA of step s + 2 and meets the
+//    barrier.  Three LDS stages of fp32 tiles (prefetch distance 2): a tile has a whole iteration to land;
+//  * ROWS = 16 rows per step keep a workgroup at <= 80 KB of LDS, i.e. two workgroups per CU whose phases interleave.
+// Everything else (row table, tap masks, t-inner row order, slab epilogue) is the DMA kernel's.
+constexpr int wgrad_f32s_lds(int bi, int bj, int rows, int ns) {
+  return ns * rows * (bi + bj) * 4 + 2 * (rows / 8) * 3 * bi * 16 + 2 * 256 * 12;
+}
+constexpr int wgrad_f32s_waves_per_simd(int bi, int bj, int rows, int ns) {
+  return 163840 / wgrad_f32s_lds(bi, bj, rows, ns) >= 2 ? 2 : 1;
+}
+
+template <int BI, int BJ, int ROWS, int NS, int SGB_VALU = 0, int SGB_DSR = 1>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(wgrad_f32s_waves_per_simd(BI, BJ, ROWS, NS)))) void conv_wgrad_f32s_kernel(WgradDmaArgs aa) {
+  const WgradArgs& a = aa.w;
+  constexpr int NW = 4, NT = 256;
+  constexpr int RBP = BI * 4, RBQ = BJ * 4;          // row bytes of the dY (P) and im2col (Q) tiles
+  constexpr int DP = RBP / 16, DQ = RBQ / 16;        // 16-byte slots per row
+  constexpr int QOFF = ROWS * RBP, BUFB = ROWS * (RBP + RBQ);
+  static_assert(QOFF % 1024 == 0 && BUFB % 1024 == 0, "1 KiB DMA pieces");
+  constexpr int PPC = QOFF / 1024, QPC = (BUFB - QOFF) / 1024;
+  constexpr int NPW = (PPC + NW - 1) / NW, NQW = (QPC + NW - 1) / NW;
+  constexpr int RT = NT, SPR = RT / ROWS;
+  constexpr int WJ = BJ / NW, TI = BI / 32, TJ = WJ / 32;
+  constexpr int NKS = ROWS / 16, NKH = ROWS / 8;     // MFMA k steps / 8-row k groups per step
+  constexpr int NPF = NKH * (BI / 64);               // dY fragment ops (8 rows x 64 columns) per step
+  constexpr int PLN = NKH * 3 * BI;                  // uint4 entries of one planes buffer
+  constexpr int D = NS - 1;
+  static_assert(TI >= 1 && TJ >= 1 && BI % 64 == 0 && ROWS % 16 == 0, "tile");
+  static_assert(D >= 2 && D < SPR, "the rotated loop needs a prefetch distance of two steps");
+  constexpr unsigned kOOB = 0x80000000u;
+
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * BUFB];
+  __shared__ uint2 rowtab[2][RT];
+  __shared__ unsigned rowdy[2][RT];
+  __shared__ uint4 planes[2 * PLN];
+
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_j = bid % a.ntj; bid /= a.ntj;
+  const int tile_i = bid % a.nti;
+  const int split = bid / a.nti;
+  const int i0 = tile_i * BI, j0 = tile_j * BJ;
+  const int wj0 = wave * WJ;
+  const int m_begin = split * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+
+  const dma_rsrc_t x_rsrc = dma_make_rsrc(a.x, (unsigned)aa.x_bytes), dy_rsrc = dma_make_rsrc(a.dy, (unsigned)aa.dy_bytes);
+  const unsigned smem_base = lds_addr(smem);
+  const unsigned ldxb = (unsigned)a.ldx * 4u, ldyb = (unsigned)a.ldy * 4u;
+
+  int prow[NPW]; unsigned pcolb[NPW];
+#pragma unroll
+  for (int u = 0; u < NPW; ++u) {
+    const int sl = (wave + NW * u) * 64 + lane;
+    prow[u] = sl / DP;
+    const int n = i0 + (sl % DP) * 4;
+    pcolb[u] = n < a.CoutP ? (unsigned)n * 4u : kOOB;
+  }
+  int qrow[NQW]; unsigned qtb[NQW], qbit[NQW];
+#pragma unroll
+  for (int u = 0; u < NQW; ++u) {
+    const int sl = (wave + NW * u) * 64 + lane;
+    qrow[u] = sl / DQ;
+    const int col = j0 + (sl % DQ) * 4;
+    if (col < a.J) {
+      const int tap = col / g.CP, c = col - tap * g.CP;
+      const int dw = tap % g.kw, t2 = tap / g.kw, dh = t2 % g.kh, dt = t2 / g.kh;
+      qbit[u] = (1u << dt) | (1u << (8 + dh)) | (1u << (16 + dw));
+      qtb[u] = (unsigned)((dt * g.sH + dh) * g.sW + dw) * ldxb + (unsigned)c * 4u;
+    } else {
+      qbit[u] = 0xffffffffu;
+      qtb[u] = 0;
+    }
+  }
+
+  auto decode = [&](int rnd) {
+    const int q = m_begin + rnd * RT + tid;
+    uint2 e = make_uint2(0u, 0u);
+    unsigned dyo = kOOB;
+    if (q < m_end) {
+      const uint32_t m = a.perm.on ? perm_row(a.perm, (uint32_t)q) : (uint32_t)q;
+      dyo = m * ldyb;
+      const RowPos r = decode_row<MODE_FWD>(m, a.M, g);
+      auto range = [](int x0, int k, int lim) -> unsigned {
+        const int lo = max(0, -x0), hi = min(k, lim - x0);
+        return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+      };
+      const unsigned bt = range(r.t0, g.kt, g.sT), bh = range(r.h0, g.kh, g.sH), bw = range(r.w0, g.kw, g.sW);
+      e.x = (unsigned)(r.base + (r.t0 * g.sH + r.h0) * g.sW + r.w0) * ldxb;
+      e.y = (bt && bh && bw) ? (bt | (bh << 8) | (bw << 16)) : 0u;
+    }
+    rowtab[rnd & 1][tid] = e;
+    rowdy[rnd & 1][tid] = dyo;
+  };
+  auto issue = [&](int s, int buf) {
+    const unsigned* dtab = rowdy[(s / SPR) & 1] + (s % SPR) * ROWS;
+    unsigned dyo[NPW];
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) dyo[u] = dtab[prow[u]];
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) {
+      if (PPC % NW != 0 && wave + NW * u >= PPC) break;
+      const unsigned off = (dyo[u] != kOOB && pcolb[u] != kOOB) ? dyo[u] + pcolb[u] : kOOB;
+      dma_load16(dy_rsrc, smem_base + buf * BUFB + (wave + NW * u) * 1024, off);
+    }
+    const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(rowtab[(s / SPR) & 1] + (s % SPR) * ROWS);
+    unsigned long long e[NQW];
+#pragma unroll
+    for (int u = 0; u < NQW; ++u) e[u] = tab[qrow[u] & (ROWS - 1)];
+#pragma unroll
+    for (int u = 0; u < NQW; ++u) {
+      if (QPC % NW != 0 && wave + NW * u >= QPC) break;
+      const unsigned ex = (unsigned)e[u], ey = (unsigned)(e[u] >> 32);
+      const unsigned off = ((ey & qbit[u]) == qbit[u]) ? ex + qtb[u] : kOOB;
+      dma_load16(x_rsrc, smem_base + buf * BUFB + QOFF + (wave + NW * u) * 1024, off);
+    }
+  };
+  int my_pieces = 0;
+#pragma unroll
+  for (int u = 0; u < NPW; ++u) my_pieces += (wave + NW * u < PPC) ? 1 : 0;
+#pragma unroll
+  for (int u = 0; u < NQW; ++u) my_pieces += (wave + NW * u < QPC) ? 1 : 0;
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int h = lane >> 5, l31 = lane & 31;
+  const int nsteps = (m_end - m_begin + ROWS - 1) / ROWS;
+
+  // split step s: this wave's share of the dY fragment ops -> planes[s & 1]; its own x fragments -> bq
+  auto split_step = [&](int s, Split3 (&bq)[NKS][TJ]) {
+    const unsigned char* tp = smem + (s % NS) * BUFB;
+    const unsigned char* tq = tp + QOFF;
+    uint4* pl = planes + (s & 1) * PLN;
+    static_assert(NPF % NW == 0 || NW % NPF == 0, "fragment ops deal evenly over the waves");
+#pragma unroll
+    for (int f0 = 0; f0 < NPF; f0 += NW) {
+      // fewer ops than waves: the spare waves repeat one (same values to the same place) rather than branch around it --
+      // the step takes as long as its slowest wave either way, and a branch would cut the block the scheduler interleaves
+      const int f = NPF % NW == 0 ? f0 + wave : (f0 + wave) % NPF;
+      {
+        const int kh = f % NKH, col = (f / NKH) * 64 + lane;
+        const unsigned char* src = tp + (kh * 8) * RBP + col * 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(src + e * RBP);
+        const Split3 s3 = split3w(v);
+        uint4* dst = pl + kh * 3 * BI + col;
+        dst[0] = __builtin_bit_cast(uint4, s3.hi);
+        dst[BI] = __builtin_bit_cast(uint4, s3.mid);
+        dst[2 * BI] = __builtin_bit_cast(uint4, s3.lo);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(tq + (ks * 16 + 8 * h + e) * RBQ + (wj0 + j * 32 + l31) * 4);
+        bq[ks][j] = split3w(v);
+      }
+  };
+  auto mma_step = [&](int s, const Split3 (&bq)[NKS][TJ]) {
+    const uint4* pl = planes + (s & 1) * PLN;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int kh = ks * 2 + h;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const uint4* pa = pl + kh * 3 * BI + i * 32 + l31;
+        Split3 af;
+        af.hi = __builtin_bit_cast(bf16x8, pa[0]);
+        af.mid = __builtin_bit_cast(bf16x8, pa[BI]);
+        af.lo = __builtin_bit_cast(bf16x8, pa[2 * BI]);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) mma_split3(af, bq[ks][j], acc[i][j]);
+      }
+    }
+  };
+  // iteration s (-1 <= s < nsteps): multiply step s, split step s + 1, prefetch step s + 1 + D, make step s + 2 visible.
+  // STEADY: every part exists (0 <= s, s + 1 + D < nsteps) -- no conditions, so that the multiply and the split are ONE basic
+  // block the scheduler can interleave; the first and the last D + 1 iterations take the conditional form.
+  static_assert(PPC % NW == 0 && QPC % NW == 0, "every wave issues the same pieces per step (compile-time wait counts)");
+  constexpr int PIECES = PPC / NW + QPC / NW;
+  static_assert((D - 1) * PIECES <= 24, "counted wait");
+  auto wait_tail = [&](int tiles) { dma_wait_upto(tiles * PIECES); };
+  // The steady iteration in HAND-PLACED order (HAND): an in-order wave only fills the 24 idle issue cycles behind an MFMA
+  // with what follows it in ITS OWN instruction stream, and the compiler's scheduler clusters the MFMAs of a block (24 back to
+  // back, then the ~190 vector instructions of the split: matrix pipe and vector ALU take turns, PMC: matrix pipe 52 % busy
+  // with two waves per SIMD).  Here every MFMA is followed by one UNIT of the next step's work -- a pair of values split
+  // (9 vector instructions), the three plane stores of a dY fragment, or one DMA piece's address and issue -- and a
+  // sched_barrier(0) pins that order.  All LDS reads of the iteration are issued up front.
+  constexpr int NPFW = NPF >= NW ? NPF / NW : 1;                   // dY fragment ops per wave and step
+  constexpr int NM = NKS * TI * TJ * 6;                            // MFMAs per wave and step
+  constexpr int U_P = NPFW * 5, U_Q = NKS * TJ * 4, U_ALL = U_P + U_Q + PIECES;
+  auto steady_hand = [&](int s, int st_next, int st_issue, const Split3 (&bcur)[NKS][TJ], Split3 (&bnext)[NKS][TJ]) {
+    const int sn = s + 1;
+    if ((sn % SPR) == 0 && (sn + SPR) < nsteps) decode(sn / SPR + 1);
+    const uint4* pl = planes + (s & 1) * PLN;
+    uint4* pln = planes + (sn & 1) * PLN;
+    const unsigned char* tp = smem + st_next * BUFB;
+    const unsigned char* tq = tp + QOFF;
+    Split3 af[NKS][TI];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const uint4* pa = pl + (ks * 2 + h) * 3 * BI + i * 32 + l31;
+        af[ks][i].hi = __builtin_bit_cast(bf16x8, pa[0]);
+        af[ks][i].mid = __builtin_bit_cast(bf16x8, pa[BI]);
+        af[ks][i].lo = __builtin_bit_cast(bf16x8, pa[2 * BI]);
+      }
+    float pv[NPFW][8], qv[NKS][TJ][8];
+    int pdst[NPFW];
+#pragma unroll
+    for (int f0 = 0; f0 < NPFW; ++f0) {
+      const int f = NPF % NW == 0 ? f0 * NW + wave : wave % NPF;
+      const int kh = f % NKH, col = (f / NKH) * 64 + lane;
+      pdst[f0] = kh * 3 * BI + col;
+      const unsigned char* src = tp + (kh * 8) * RBP + col * 4;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pv[f0][e] = *reinterpret_cast<const float*>(src + e * RBP);
+    }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          qv[ks][j][e] = *reinterpret_cast<const float*>(tq + (ks * 16 + 8 * h + e) * RBQ + (wj0 + j * 32 + l31) * 4);
+    const int si = sn + D;
+    const unsigned* dtab = rowdy[(si / SPR) & 1] + (si % SPR) * ROWS;
+    const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(rowtab[(si / SPR) & 1] + (si % SPR) * ROWS);
+    unsigned dyo[NPW];
+    unsigned long long te[NQW];
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) dyo[u] = dtab[prow[u]];
+#pragma unroll
+    for (int u = 0; u < NQW; ++u) te[u] = tab[qrow[u] & (ROWS - 1)];
+    const unsigned stage_base = smem_base + st_issue * BUFB;
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned PH[NPFW][4], PM[NPFW][4], PL[NPFW][4], QH[NKS][TJ][4], QM[NKS][TJ][4], QL[NKS][TJ][4];
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
+    auto unit = [&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (k < U_P) {
+        constexpr int f = k / 5, q = k % 5;
+        if constexpr (q < 4) {
+          split3w_pair(pv[f][2 * q], pv[f][2 * q + 1], PH[f][q], PM[f][q], PL[f][q]);
+        } else {
+          uint4* dst = pln + pdst[f];
+          dst[0] = make_uint4(PH[f][0], PH[f][1], PH[f][2], PH[f][3]);
+          dst[BI] = make_uint4(PM[f][0], PM[f][1], PM[f][2], PM[f][3]);
+          dst[2 * BI] = make_uint4(PL[f][0], PL[f][1], PL[f][2], PL[f][3]);
+        }
+      } else if constexpr (k < U_P + U_Q) {
+        constexpr int idx = k - U_P, fr = idx / 4, q = idx % 4, ks = fr / TJ, j = fr % TJ;
+        split3w_pair(qv[ks][j][2 * q], qv[ks][j][2 * q + 1], QH[ks][j][q], QM[ks][j][q], QL[ks][j][q]);
+        // (pin the results HERE: their only reader is the next iteration, and the machine-sink pass otherwise moves the whole split
+        // behind the barrier into the successor block -- correct, but it is this placement between the MFMAs that is wanted)
+        asm volatile("" : "+v"(QH[ks][j][q]), "+v"(QM[ks][j][q]), "+v"(QL[ks][j][q]));
+        if constexpr (q == 3) {
+          const u32x4v vh = {QH[ks][j][0], QH[ks][j][1], QH[ks][j][2], QH[ks][j][3]};
+          const u32x4v vm = {QM[ks][j][0], QM[ks][j][1], QM[ks][j][2], QM[ks][j][3]};
+          const u32x4v vl = {QL[ks][j][0], QL[ks][j][1], QL[ks][j][2], QL[ks][j][3]};
+          bnext[ks][j].hi = __builtin_bit_cast(bf16x8, vh);
+          bnext[ks][j].mid = __builtin_bit_cast(bf16x8, vm);
+          bnext[ks][j].lo = __builtin_bit_cast(bf16x8, vl);
+        }
+      } else {
+        constexpr int u = k - U_P - U_Q;
+        if constexpr (u < NPW) {
+          const unsigned off = (dyo[u] != kOOB && pcolb[u] != kOOB) ? dyo[u] + pcolb[u] : kOOB;
+          dma_load16(dy_rsrc, stage_base + (wave + NW * u) * 1024, off);
+        } else {
+          constexpr int v = u - NPW;
+          const unsigned ex = (unsigned)te[v], ey = (unsigned)(te[v] >> 32);
+          const unsigned off = ((ey & qbit[v]) == qbit[v]) ? ex + qtb[v] : kOOB;
+          dma_load16(x_rsrc, stage_base + QOFF + (wave + NW * v) * 1024, off);
+        }
+      }
+    };
+    static_for<NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int blk = m / 6, prod = m % 6, j = blk % TJ, i = (blk / TJ) % TI, ks = blk / (TJ * TI);
+      const Split3& A = af[ks][i];
+      const Split3& B = bcur[ks][j];
+      if constexpr (prod == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.mid, B.mid, acc[i][j], 0, 0, 0);
+      if constexpr (prod == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.lo, acc[i][j], 0, 0, 0);
+      if constexpr (prod == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.lo, B.hi, acc[i][j], 0, 0, 0);
+      if constexpr (prod == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.mid, acc[i][j], 0, 0, 0);
+      if constexpr (prod == 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.mid, B.hi, acc[i][j], 0, 0, 0);
+      if constexpr (prod == 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.hi, acc[i][j], 0, 0, 0);
+      constexpr int k0 = (m * U_ALL + NM - 1) / NM, k1 = ((m + 1) * U_ALL + NM - 1) / NM;     // units of this slot
+      static_for<(k1 - k0)>([&](auto dc) { unit(std::integral_constant<int, k0 + decltype(dc)::value>()); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (D == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else wait_tail(D - 1);
+    __syncthreads();
+  };
+  auto iteration = [&](int s, const Split3 (&bcur)[NKS][TJ], Split3 (&bnext)[NKS][TJ], auto steady) {
+    constexpr bool STEADY = decltype(steady)::value;
+    const int sn = s + 1;
+    if ((STEADY || sn < nsteps) && (sn % SPR) == 0 && (sn + SPR) < nsteps) decode(sn / SPR + 1);
+    if (STEADY || sn + D < nsteps) issue(sn + D, (sn + D) % NS);  // its stage was last read by split_step(s), one barrier ago
+    if (STEADY || s >= 0) mma_step(s, bcur);
+    if (STEADY || sn < nsteps) split_step(sn, bnext);
+    if constexpr (STEADY) {
+      if constexpr (D == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+      else wait_tail(D - 1);
+    } else if (sn + 1 < nsteps) {
+      wait_tail(min(D - 1, nsteps - 2 - sn));                     // step s + 2 has landed (this wave's pieces)
+    }
+    __syncthreads();
+  };
+  typedef std::integral_constant<bool, true> steady_t;
+  typedef std::integral_constant<bool, false> edge_t;
+
+  decode(0);
+  if (SPR < nsteps) decode(1);                       // (the loop decodes round r + 1 at the first step of round r, r >= 1)
+  __syncthreads();
+  for (int t = 0; t < D && t < nsteps; ++t) issue(t, t);
+  wait_tail(min(D - 1, nsteps - 1));                 // step 0 has landed
+  __syncthreads();
+  Split3 b0[NKS][TJ], b1[NKS][TJ];
+  {
+    // iteration -1 without its decode (round 1 is decoded above)
+    if (D < nsteps) issue(D, D % NS);
+    split_step(0, b0);
+    if (1 < nsteps) wait_tail(min(D - 1, nsteps - 2));
+    __syncthreads();
+  }
+  // steady iterations: s + 1 + D < nsteps, in pairs (the x fragments alternate between two register sets)
+  const int n_steady = max(0, nsteps - 1 - D) & ~1;
+  int s = 0;
+  if constexpr (SGB_VALU > 0) {
+    int st_next = 1 % NS, st_issue = (1 + D) % NS;               // stages of steps s + 1 and s + 1 + D at s = 0
+    auto adv = [&] { st_next = st_next + 1 == NS ? 0 : st_next + 1; st_issue = st_issue + 1 == NS ? 0 : st_issue + 1; };
+    for (; s < n_steady; s += 2) {
+      steady_hand(s, st_next, st_issue, b0, b1); adv();
+      steady_hand(s + 1, st_next, st_issue, b1, b0); adv();
+    }
+  } else {
+    for (; s < n_steady; s += 2) {
+      iteration(s, b0, b1, steady_t());
+      iteration(s + 1, b1, b0, steady_t());
+    }
+  }
+  for (; s < nsteps; s += 2) {
+    iteration(s, b0, b1, edge_t());
+    if (s + 1 < nsteps) iteration(s + 1, b1, b0, edge_t());
+  }
+
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+      wgrad_store_block(a, split, i0 + i * 32, j0 + wj0 + j * 32 + l31, h, acc[i][j]);
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 static bool fill_geom(const dv_conv_desc* d, int mode, ConvGeom& g) {
   g.kt = d->kt; g.kh = d->kh; g.kw = d->kw;
@@ -1569,6 +2154,11 @@ extern "C" int dv_pack_w3(const float* base, void* out_base, const dv_w3_desc* d
   hipLaunchKernelGGL(pack_w3_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, base, (unsigned char*)out_base, descs,
                      reinterpret_cast<const int2*>(block_map));
   return dv_launch_status();
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
 }
 
 static bool f32_exact() {
@@ -1694,6 +2284,30 @@ static void launch_gemm(int bm, int bn, const ConvArgs& a, int grid, hipStream_t
 
 }  // namespace
 
+// conv_gemm_ks_kernel (K split over the waves) takes a fwd / dgrad launch when the ordinary tiling leaves a small grid with a
+// long K loop.  Returns the column tile (32 / 64) or 0.  DUALVAR_CONV_KS=0 switches it off (A/B runs).
+static int ks_tile(int dtype, const ConvArgs& a, int bm) {
+  static const int on = env_int("DUALVAR_CONV_KS", 1), max_grid = env_int("DUALVAR_CONV_KS_MAXGRID", 400),
+                   min_nk = env_int("DUALVAR_CONV_KS_MINK", 16);
+  if (!on || dtype != DV_F32 || !(a.flags & DV_W3) || f32_exact() || a.cls_on || a.bn_x != nullptr || bm != 64) return 0;
+  if (a.g.CP % 16 != 0 || a.g.kt * a.g.kh * a.g.kw > 32 || a.g.Ktot / 16 < min_nk) return 0;
+  if (a.g.st > 1 || a.g.sh > 1 || a.g.sw > 1) return 0;       // (few-row layers are stride 1; keeps one gather form)
+  const int64_t mt = (a.M + 63) / 64;
+  const int64_t g32 = mt * ((a.NP + 31) / 32), g64 = mt * ((a.NP + 63) / 64);
+  // one workgroup per CU (its four private pipelines fill the LDS): a grid of at most one round, and as many workgroups as that
+  // allows; 64-column tiles when 32-column ones would need a second round
+  if (g32 <= 256) return 32;
+  if (g64 <= max_grid) return g64 <= 256 || g32 > max_grid ? 64 : 32;
+  return 0;
+}
+template <int MODE>
+static void launch_ks(int bn, ConvArgs& a, hipStream_t s) {
+  a.ntn = (a.NP + bn - 1) / bn;
+  const int grid = a.ntn * ((a.M + 63) / 64);
+  if (bn == 32) hipLaunchKernelGGL((conv_gemm_ks_kernel<MODE, 32, 4>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_gemm_ks_kernel<MODE, 64, 3>), dim3(grid), dim3(256), 0, s, a);
+}
+
 extern "C" int dv_conv3d_tile_rows(const dv_conv_desc* d) {
   if (!d) return DV_EINVAL;
   const int64_t m = (int64_t)d->N * d->To * d->Ho * d->Wo;
@@ -1760,6 +2374,10 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   a.ntn = (a.NP + bn - 1) / bn;
   const int grid = a.ntn * ((a.M + bm - 1) / bm);
   hipStream_t s = (hipStream_t)stream;
+  if (const int kbn = ks_tile(d->dtype, a, bm)) {
+    launch_ks<MODE_FWD>(kbn, a, s);
+    return dv_launch_status();
+  }
   if (d->dtype == DV_F32) launch_gemm<float, MODE_FWD, 16>(bm, bn, a, grid, s);
   else if (gvb == 16) launch_gemm<bf16_t, MODE_FWD, 16>(bm, bn, a, grid, s);
   else launch_gemm<bf16_t, MODE_FWD, 8>(bm, bn, a, grid, s);
@@ -1910,6 +2528,10 @@ static int dgrad_impl(const dv_conv_desc* d, const void* dy, const void* wd, voi
   pick_tile(d->dtype, a.M, a.NP, bm, bn);
   a.ntn = (a.NP + bn - 1) / bn;
   const int grid = a.ntn * ((a.M + bm - 1) / bm);
+  if (const int kbn = ks_tile(d->dtype, a, bm)) {
+    launch_ks<MODE_DGRAD>(kbn, a, s);
+    return dv_launch_status();
+  }
   if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, a, grid, s);
   else launch_gemm<bf16_t, MODE_DGRAD, 16>(bm, bn, a, grid, s);
   return dv_launch_status();
@@ -1933,17 +2555,22 @@ static const WgradCfg kWgBf16[] = {{128, 128, 2, 2, 3}, {64, 256, 1, 4, 3}, {128
 // (f32 split mode: a two-wave 64 x 128 workgroup with 64 x 64 wave tiles -- one fragment split per 32x32 block instead of
 // 1.5 -- was measured slower than the four-wave one with 32 x 64 wave tiles: 950 vs 827 us on the 7x1x1 stem layer)
 static const WgradCfg kWgF32[] = {{128, 128, 2, 2, 2}, {64, 128, 2, 2, 2}};
+// conv_wgrad_f32s_kernel<BI, BJ, ROWS, NS> instantiations (the fp32 split mode's second weight-gradient form)
+struct WgradF32sCfg { int BI, BJ, ROWS, NS; };
+static const WgradF32sCfg kWgF32s[] = {{64, 256, 16, 3}, {64, 256, 32, 3}, {128, 128, 16, 3}, {128, 128, 32, 3}, {128, 256, 16, 3},
+                                       {64, 128, 16, 3},
+                                       // 6..: the same tiles with the split interleaved between the MFMAs (sched_group_barrier)
+                                       {64, 256, 16, 3}, {64, 256, 32, 3}, {128, 128, 16, 3}, {128, 128, 32, 3}, {128, 256, 16, 3},
+                                       {64, 128, 16, 3}};
+static const int kNWgF32s = 12;
 
 struct WgradPlan {
   int BI, BJ, nti, ntj, splits, rows_per_split, gvb, cfg;
+  int f32s;                   // >= 0: conv_wgrad_f32s_kernel configuration kWgF32s[f32s]
   bool dma;
   long long slab_stride;      // elements
 };
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
 
 static WgradPlan plan_wgrad(const dv_conv_desc* d) {
   WgradPlan p;
@@ -1959,7 +2586,14 @@ static WgradPlan plan_wgrad(const dv_conv_desc* d) {
   }
   int per_cu = 3;
   p.cfg = -1;
-  if (p.dma) {
+  p.f32s = -1;
+  static const int f32s_force = env_int("DUALVAR_WGRAD_F32S", -1);
+  if (p.dma && d->dtype == DV_F32 && !f32_exact() && f32s_force >= 0 && f32s_force < kNWgF32s) {
+    const WgradF32sCfg& k = kWgF32s[f32s_force];
+    p.f32s = f32s_force;
+    p.BI = k.BI; p.BJ = k.BJ;
+    per_cu = std::max(1, std::min(2, 163840 / wgrad_f32s_lds(k.BI, k.BJ, k.ROWS, k.NS)));
+  } else if (p.dma) {
     // candidate with the least estimated time: LDS-fill bytes at ~18 TB/s chip-wide against padded MFMA work at ~2/3 of
     // peak; a configuration whose tiles cannot even fill the chip once (few rows) pays for the idle CUs
     const WgradCfg* tab = d->dtype == DV_F32 ? kWgF32 : kWgBf16;
@@ -2065,9 +2699,31 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
     aa.w = a;
     aa.x_bytes = (int)(((int64_t)d->N * d->Ti * d->Hi * d->Wi - 1) * d->ldx * es + (int64_t)d->cin_pitch * es);
     aa.dy_bytes = (int)(((int64_t)a.M - 1) * d->ldy * es + (int64_t)d->cout_pitch * es);
+    {   // diagnosis only (wrong results): every gather out of range -> zero fill without touching memory
+      static const int oob = env_int("DUALVAR_WGRAD_DIAG_OOB", 0);
+      if (oob & 1) aa.x_bytes = 16;
+      if (oob & 2) aa.dy_bytes = 16;
+    }
 #define WGD(T_, BI_, BJ_, WI_, WJ_, NS_, ...) \
   hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, BI_, BJ_, WI_, WJ_, NS_, ##__VA_ARGS__>), dim3(grid), dim3(WI_ * WJ_ * 64), 0, s, aa)
-    if (d->dtype == DV_BF16) {
+#define WGS(BI_, BJ_, R_, NS_, ...) \
+  hipLaunchKernelGGL((conv_wgrad_f32s_kernel<BI_, BJ_, R_, NS_, ##__VA_ARGS__>), dim3(grid), dim3(256), 0, s, aa)
+    if (p.f32s >= 0) {
+      switch (p.f32s) {
+        case 0: WGS(64, 256, 16, 3); break;
+        case 1: WGS(64, 256, 32, 3); break;
+        case 2: WGS(128, 128, 16, 3); break;
+        case 3: WGS(128, 128, 32, 3); break;
+        case 4: WGS(128, 256, 16, 3); break;
+        case 5: WGS(64, 128, 16, 3); break;
+        case 6: WGS(64, 256, 16, 3, 7); break;
+        case 7: WGS(64, 256, 32, 3, 7); break;
+        case 8: WGS(128, 128, 16, 3, 4); break;
+        case 9: WGS(128, 128, 32, 3, 4); break;
+        case 10: WGS(128, 256, 16, 3, 4); break;
+        default: WGS(64, 128, 16, 3, 9); break;
+      }
+    } else if (d->dtype == DV_BF16) {
       switch (p.cfg) {
         case 0: WGD(bf16_t, 128, 128, 2, 2, 3); break;
         case 1: WGD(bf16_t, 64, 256, 1, 4, 3); break;
@@ -2089,6 +2745,7 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
       }
     }
 #undef WGD
+#undef WGS
   } else {
 #define WG_LAUNCH(T_, G_)                                                                                   \
   do {                                                                                                      \

@@ -141,13 +141,13 @@ def test_two_ranks_equal_one_process(gpu, kind):
             # after GradSync every rank holds the same averaged gradient = single-process gradient / world
             assert torch.allclose(res[0][2][k], res[1][2][k])
             assert torch.allclose(res[0][2][k], gsum / 2, rtol=1e-5, atol=1e-8)
-        # The per-rank problems are half as tall, so they run with different tile shapes (= summation orders, and in fp32 mode
-        # other groupings of the six partial products) than the single-process run: the two gradients cannot agree better than
-        # the single-process gradient agrees with itself under a rounding-sized change.  Measure that: the same single-process
-        # backward with the input nudged by 1e-7 (relative, per element) -- at B = 4 the BatchNorm backward of the random-init R3D
-        # amplifies it to 1e-4 .. 1e-2 in individual tensors -- and bound the identity by k = 10 times it.
-        # Recorded on MI355X (gpurun r3, same seed): see the printed line; DUALVAR_F32_EXACT=1 (exact-f32 MFMA, no operand
-        # split) gives the same order of magnitude, i.e. the band is the conditioning of the net, not the split.
+        # The per-rank problems are half as tall, so they may run with other tile shapes (= summation orders, and in fp32 mode
+        # other groupings of the six partial products) than the single-process run.  Two measurements bound the identity
+        # (MI355X, round 3, this seed): the identity itself holds to 4.7e-6 (worst tensor: bn1.weight) with the bf16-split
+        # products and to the same order under DUALVAR_F32_EXACT=1 (exact-f32 MFMA) -- so what is left is summation order, not
+        # the split -- while the single-process gradient moves by 2.5e-2 under a 1e-7 relative nudge of the input (the
+        # conditioning of the random-init R3D at B = 4, printed below for the record).  Bound: 20x the measured identity error;
+        # the round-2 band of 3e-2 was three orders of magnitude wider than what the kernels deliver.
         block = P.procedural_clips(B, V, T, H, H)
         noise = torch.from_numpy(np.random.RandomState(99).standard_normal(block.numel())).float().reshape(block.shape)
         np.random.seed(1234)
@@ -158,7 +158,7 @@ def test_two_ranks_equal_one_process(gpu, kind):
         assert all(torch.equal(grads_r[k], grads1[k]) for k in grads1), 'the single-process backward must be bit-reproducible'
         print('sum-over-ranks param grad vs single process: worst rel err %.3e (%s); single-process spread under a 1e-7 input nudge '
               '%.3e; F32_EXACT=%s' % (worst, worst_key, spread, os.environ.get('DUALVAR_F32_EXACT', '0')))
-        assert worst < max(1e-4, 10 * spread), (worst, spread)
+        assert worst < 1e-4, (worst, worst_key, spread)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -465,3 +465,24 @@ def test_rccl_single_rank_rehearsal(gpu, kind, transport, net):
     worst = spread(params, ref)
     print('parameters after 2 steps: worst rel diff', worst)
     assert worst < max(2e-3, 20 * max(s_rr, s_in)), (worst, s_rr, s_in)
+
+
+def test_bench_gpus_2_launches_itself_and_reports_two_ranks(gpu):
+    """`python bench.py --gpus 2` with NO launcher on the command line (gloo rehearsal: both ranks share the one test GPU):
+    the script starts its two ranks itself, every rank runs the data-parallel step, rank 0 prints ONE JSON line with
+    n_gpus == 2 and the clips of both ranks in `value`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['DUALVAR_BENCH_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2', '--batch', '4',
+                        '--net', 'r3d', '--size', '64', '--secondary', 'none', '--no-cpu-baseline'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['clips_per_step'] == 2 * 4 * 2 and out['config']['parallelism'] == 'dp2'
+    assert abs(out['value'] - out['config']['clips_per_step'] / (out['ms_per_step'] * 1e-3)) < 0.02 * out['value']

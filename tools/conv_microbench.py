@@ -31,6 +31,9 @@ LAYERS = {
     'm4f_3x1x1':      (128, 2, 7, 7, 320, 320, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
     'm5c_1x3x3':      (128, 1, 3, 3, 192, 384, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     'm5c_3x1x1':      (128, 1, 3, 3, 384, 384, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    # synthetic shapes for tile experiments (no padding waste with 128 / 256-wide tiles)
+    'x256_3x1x1':     (128, 4, 14, 14, 256, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    'x128_1x3x3_28':  (128, 4, 28, 28, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
 }
 BIG = ['stem2_7x1x1', 'c2b_1x1x1', 'c2c_1x3x3', 'c2c_3x1x1', 'm3c_entry', 'm3c_1x3x3', 'm3c_3x1x1']
 
