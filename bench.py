@@ -29,6 +29,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from dualvar_amd import _lib as _dv_lib  # noqa: E402   (pure Python at import: no GPU call)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # dense MFMA peaks per dtype (MI355X_MICROARCH.md).  fp32 is priced against the guide's fp32 matrix peak, 157.3 TFLOP/s.  The
@@ -376,7 +377,7 @@ def run_leg(args, dtype, rank, world, distributed, dev):
     roof['isolated'] = {'avg_launch_us': round(cms / cn * 1e3, 2), 'GB/s': round(iso_bw, 1), 'TFLOP/s': round(iso_tf, 2),
                         'frac_hbm': round(iso_bw / HBM_PEAK_GBS, 4), 'frac_mfma': round(iso_tf / MFMA_PEAK_TF[dtype], 4)}
     roof['concurrent'] = bool(side_default and dominant.startswith('conv_wgrad'))
-    if dtype == 'fp32' and os.environ.get('DUALVAR_F32_EXACT') != '1':
+    if dtype == 'fp32' and not _dv_lib.f32_exact():
         roof['split_peak'] = round(F32_SPLIT_PEAK_TF, 1)
         roof['frac_of_split_peak'] = round(tf / F32_SPLIT_PEAK_TF, 4)
         roof['note'] = ('fp32 products = 6 bf16 MFMAs per 32x32x16 block (exact 3-way bf16 split of both operands): `peak` is the '

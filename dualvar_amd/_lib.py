@@ -192,6 +192,40 @@ def require_device():
     _device_ok = True
 
 
+def f32_exact():
+    """DUALVAR_F32_EXACT as the LIBRARY reads it (csrc/conv.hip f32_exact(): atoi(value) != 0), so that the host's choice of
+    pre-split weights and the kernels' choice of MFMA never disagree ('2', '01', ' 1' all mean on; 'yes' means off)."""
+    import re
+    m = re.match(r'\s*([+-]?\d+)', os.environ.get('DUALVAR_F32_EXACT', ''))
+    return bool(m) and int(m.group(1)) != 0
+
+
+# Workspaces of the ordered (ticketed) reductions -- dv_bn_bwd_reduce*, dv_infonce_fwd: their ticket words are "zero on entry,
+# zero again on exit".  A launch that FAILS may leave tickets behind and would corrupt every later sum silently, so every such
+# workspace registers here and check() re-zeroes them all after a failed launch.
+import weakref as _weakref
+_ticket_ws = []
+
+
+def register_ticket_workspace(t):
+    _ticket_ws.append(_weakref.ref(t))
+    return t
+
+
+def _rezero_ticket_workspaces():
+    for r in list(_ticket_ws):
+        t = r()
+        if t is None:
+            _ticket_ws.remove(r)
+            continue
+        try:
+            t.zero_()
+        except Exception:       # the device itself may be in an error state: nothing more to do here
+            pass
+
+
 def check(rc, name):
     if rc != 0:
+        if rc > 0:              # a launch failed (hipError_t): ticket state unknown
+            _rezero_ticket_workspaces()
         raise DualVarHipError(f'{name} failed: {_ERR.get(rc, "hipError_t %d" % rc)}')

@@ -112,6 +112,12 @@ class _BackboneFn(torch.autograd.Function):
     def backward(ctx, g):
         plan = ctx.plan
         backbone_store = plan.store
+        if getattr(backbone_store, '_sync_started', False):
+            # the bucket-wise all-reduce of this arena (GradSync.attach) is already in flight: a further backward pass would add
+            # local gradients to buckets that hold cross-rank sums, and the ranks would diverge silently.  The reference's loop
+            # runs ONE loss.backward() per optimizer step (pretrain.py:447-451).
+            raise RuntimeError('a backward pass wrote the gradient arena after its overlapped all-reduce had started; gradient '
+                               'accumulation over several loss.backward() calls needs GradSync without attach()')
         backbone_store.attach_grads()
         # Bucket-wise gradient all-reduce from inside the backward list (parallel.GradSync.attach) only on the LAST encoder
         # backward of the step: the dual-head objectives run the encoder two or three times per step (simclr.py:354,385;

@@ -68,10 +68,6 @@ __device__ __forceinline__ uint32_t perm_row(const RowPerm& a, uint32_t q) {
   }
   return (n * (uint32_t)a.pT + t) * (uint32_t)a.pS + pix;
 }
-static bool row_perm_enabled() {
-  static const bool off = getenv("DUALVAR_NO_ROW_PERM") && atoi(getenv("DUALVAR_NO_ROW_PERM")) != 0;
-  return !off;
-}
 
 struct ConvArgs {
   const void* src;       // gathered tensor (x for fwd, dy for dgrad)
@@ -93,6 +89,9 @@ struct ConvArgs {
   // it (row space = the class's sub-lattice, kernel = its taps, padding (cot + pt - crt) / cst) -- instead of gathering
   // all taps and multiplying zeros for the (st*sh*sw - 1)/(st*sh*sw) that miss.  The weights are not repacked: a class tap
   // reads the ORIGINAL tap ((crt+cst*jt)*oKH + crh+csh*jh)*oKW + crw+csw*jw; output rows map back to the full input.
+  // cls_on == 2: only the TAPS are remapped (cst = csh = csw = 1, crt / crh / crw = first live tap): a window whose outer taps
+  // fall into the padding for EVERY row (3x1x1 with padding 1 on a one-frame map: two of three taps) runs as the smaller
+  // window of its live taps -- trim_dead_taps() on the host.
   int cls_on, cst, csh, csw, cot, coh, cow, crt, crh, crw, oKH, oKW, oT, oH, oW;
   // dgrad whose output is dL/dy of y = relu(x_bn * scale + shift), the BatchNorm in front of this conv, and is that
   // gradient's only contribution (dv_conv3d_dgrad_bn): the epilogue also accumulates the BatchNorm backward's
@@ -537,7 +536,8 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
       for (int p = 0; p < B_G; ++p)
         if (uwave + p * NW < BPC)
           dma_load16(w_dma, smem_base + buf * BUFB + BM * PITCH + (uwave + p * NW) * 1024,
-                     WF ? (woff[p] == kOOB ? kOOB : woff[p] + (unsigned)kt_idx * (unsigned)a.ldw * 96u) : woff[p] + s_b);
+                     WF ? (woff[p] == kOOB ? kOOB : woff[p] + ((unsigned)(u_otap * g.CP + u_c0) / (unsigned)BKE) * (unsigned)a.ldw * 96u)
+                        : woff[p] + s_b);                       // (WF: the K tile of the weights' own tap; == kt_idx unless taps are remapped)
       u_c0 += BKE;
       if (u_c0 >= g.CP) {
         u_c0 = 0;
@@ -688,7 +688,7 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
   }
   // row of the output tensor for row `m` of this launch (identity, or class sub-lattice -> full input: see ConvArgs)
   auto out_row = [&](int m) -> size_t {
-    if (!a.cls_on) return (size_t)m;
+    if (a.cls_on != 1) return (size_t)m;           // (2: taps remapped only -- trimmed window, rows are the tensor's)
     uint32_t q_, w_, h_, t_, n_;
     fd_divmod((uint32_t)m, g.dW, q_, w_);
     fd_divmod(q_, g.dH, q_, h_);
@@ -1015,7 +1015,10 @@ __global__ __launch_bounds__(256) void conv_gemm_ks_kernel(ConvArgs a) {
     return (unsigned)toff * ldb;
   };
   unsigned u_toffb = tap_off();
-  auto gload = [&](int kt, int st) {
+  auto w_tap = [&]() -> int { return a.cls_on ? ((a.crt + u_dt) * a.oKH + a.crh + u_dh) * a.oKW + a.crw + u_dw : u_tap; };
+  int u_otap = w_tap();
+  auto gload = [&](int, int st) {
+    const unsigned kt = (unsigned)(u_otap * g.CP + u_c0) >> 4;   // K tile of the weights (their own tap when the window is trimmed)
     const unsigned s_a = u_toffb + (unsigned)u_c0 * 4u;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -1031,6 +1034,7 @@ __global__ __launch_bounds__(256) void conv_gemm_ks_kernel(ConvArgs a) {
       ++u_tap;
       if (++u_dw == g.kw) { u_dw = 0; if (++u_dh == g.kh) { u_dh = 0; ++u_dt; } }
       u_toffb = tap_off();
+      u_otap = w_tap();
     }
   };
   f32x16 acc[TM][TN];
@@ -2191,12 +2195,11 @@ static void pick_tile(int dtype, int M, int NP, int& bm, int& bn) {
   bn = pick_bn(NP);
   const int ntn = (NP + bn - 1) / bn;
   bm = pick_bm(M, ntn);
-  static const int big = getenv("DUALVAR_F32_BM256") ? atoi(getenv("DUALVAR_F32_BM256")) : 1;
-  if (dtype == DV_F32 && !f32_exact() && big && bm == 128 && bn == 64 && (int64_t)((M + 255) / 256) * ntn >= 512) bm = 256;
+  if (dtype == DV_F32 && !f32_exact() && bm == 128 && bn == 64 && (int64_t)((M + 255) / 256) * ntn >= 512) bm = 256;
   // Few rows (the 1 152-row layers of Mixed_5b/5c: 18 row tiles): 128-column tiles leave three quarters of the CUs without a
   // workgroup while each busy CU runs one latency-bound K loop -- narrower tiles until the grid covers the chip
-  static const int fill = getenv("DUALVAR_CONV_FILL") ? atoi(getenv("DUALVAR_CONV_FILL")) : 256;
-  if (fill > 0 && bm == 64) {
+  constexpr int fill = 256;
+  if (bm == 64) {
     const int64_t mt = (M + 63) / 64;
     while (bn > 32 && mt * ((NP + bn - 1) / bn) < fill) bn >>= 1;
   }
@@ -2237,17 +2240,12 @@ static void launch_gemm_ns(int bm, int bn, const ConvArgs& a, int grid, hipStrea
 // (they cost resident workgroups, and the K loop is issue bound).  Launches of at most ~2 workgroups per CU (64-row tiles
 // of the 12 544- and 1 152-row layers) are latency bound instead -- one workgroup per CU waits out every DMA round trip --
 // and get four stages: those layers 252 -> 200 us (1 152 rows) and 581 -> 541 us (12 544 rows) per pass, step 10.53 ->
-// 10.35 ms.  Six stages on the smallest grids add nothing.  DUALVAR_CONV_NS_SMALL / _SMALL_GRID / _TINY_GRID: tuning knobs.
+// 10.35 ms.  Three stages, and six on the smallest grids, were measured equal or slower.
 template <typename T, int MODE, int GVB, int GM>
 static void launch_gemm_gm(int bm, int bn, const ConvArgs& a, int grid, hipStream_t s) {
   if constexpr (GVB == 16 && sizeof(T) == 2) {
-    static const int ns_small = getenv("DUALVAR_CONV_NS_SMALL") ? atoi(getenv("DUALVAR_CONV_NS_SMALL")) : 4;
-    static const int small_grid = getenv("DUALVAR_CONV_SMALL_GRID") ? atoi(getenv("DUALVAR_CONV_SMALL_GRID")) : 512;
-    if (bm == 64 && grid <= small_grid && ns_small != 2) {
-      static const int tiny_grid = getenv("DUALVAR_CONV_TINY_GRID") ? atoi(getenv("DUALVAR_CONV_TINY_GRID")) : 0;
-      if (grid <= tiny_grid) launch_gemm_ns<T, MODE, GVB, GM, 6>(bm, bn, a, grid, s);
-      else if (ns_small == 3) launch_gemm_ns<T, MODE, GVB, GM, 3>(bm, bn, a, grid, s);
-      else launch_gemm_ns<T, MODE, GVB, GM, 4>(bm, bn, a, grid, s);
+    if (bm == 64 && grid <= 512) {
+      launch_gemm_ns<T, MODE, GVB, GM, 4>(bm, bn, a, grid, s);
       return;
     }
   }
@@ -2284,12 +2282,49 @@ static void launch_gemm(int bm, int bn, const ConvArgs& a, int grid, hipStream_t
 
 }  // namespace
 
+// Taps that fall into the padding for EVERY row of the launch contribute nothing: run the window of the live taps instead
+// (per axis a contiguous range [lo, hi]).  Mixed_5b / 5c of S3D-G at 8-frame clips have ONE frame left: their 3x1x1 convs
+// (padding 1) keep one tap of three -- a third of the K loop.  Weights stay where they are: the kernel addresses a live tap
+// at its original index (ConvArgs::cls_on == 2).  Stride-1 data gradients and forward convs; not for the generic-gather
+// pre-split-weight path (its K tiles straddle taps).
+static void trim_dead_taps(ConvArgs& a, int mode, int dtype) {
+  ConvGeom& g = a.g;
+  if (a.cls_on || g.kt * g.kh * g.kw <= 1) return;
+  if (mode == MODE_DGRAD && (g.st > 1 || g.sh > 1 || g.sw > 1)) return;
+  if ((a.flags & DV_W3) && (g.CP % 16 != 0 || g.kt * g.kh * g.kw > 32)) return;
+  (void)dtype;
+  auto live = [&](int k, int rdim, int sdim, int stride, int pad, int& lo, int& hi) {
+    lo = k; hi = -1;
+    for (int d = 0; d < k; ++d) {
+      bool any = false;
+      for (int o = 0; o < rdim && !any; ++o) {
+        const int v = mode == MODE_FWD ? o * stride - pad + d : o + pad - d;
+        any = v >= 0 && v < sdim;
+      }
+      if (any) { lo = std::min(lo, d); hi = std::max(hi, d); }
+    }
+  };
+  int lt, ht, lh, hh, lw, hw;
+  live(g.kt, g.rT, g.sT, g.st, g.pt, lt, ht);
+  live(g.kh, g.rH, g.sH, g.sh, g.ph, lh, hh);
+  live(g.kw, g.rW, g.sW, g.sw, g.pw, lw, hw);
+  if (ht < lt || hh < lh || hw < lw) return;                   // (no live tap at all: leave it to the zero fill)
+  if (ht - lt + 1 == g.kt && hh - lh + 1 == g.kh && hw - lw + 1 == g.kw) return;
+  a.cls_on = 2;
+  a.cst = a.csh = a.csw = 1; a.cot = a.coh = a.cow = 0;
+  a.crt = lt; a.crh = lh; a.crw = lw; a.oKH = g.kh; a.oKW = g.kw; a.oT = g.rT; a.oH = g.rH; a.oW = g.rW;
+  // tap d' = d - lo: forward t = o*s - p + d = o*s - (p - lo) + d'; data gradient t = o + p - d = o + (p - lo) - d'
+  g.kt = ht - lt + 1; g.kh = hh - lh + 1; g.kw = hw - lw + 1;
+  g.pt -= lt; g.ph -= lh; g.pw -= lw;
+  g.Ktot = g.kt * g.kh * g.kw * g.CP;
+}
+
 // conv_gemm_ks_kernel (K split over the waves) takes a fwd / dgrad launch when the ordinary tiling leaves a small grid with a
 // long K loop.  Returns the column tile (32 / 64) or 0.  DUALVAR_CONV_KS=0 switches it off (A/B runs).
 static int ks_tile(int dtype, const ConvArgs& a, int bm) {
-  static const int on = env_int("DUALVAR_CONV_KS", 1), max_grid = env_int("DUALVAR_CONV_KS_MAXGRID", 400),
-                   min_nk = env_int("DUALVAR_CONV_KS_MINK", 16);
-  if (!on || dtype != DV_F32 || !(a.flags & DV_W3) || f32_exact() || a.cls_on || a.bn_x != nullptr || bm != 64) return 0;
+  static const int on = env_int("DUALVAR_CONV_KS", 1);
+  constexpr int max_grid = 400, min_nk = 16;
+  if (!on || dtype != DV_F32 || !(a.flags & DV_W3) || f32_exact() || a.cls_on == 1 || a.bn_x != nullptr || bm != 64) return 0;
   if (a.g.CP % 16 != 0 || a.g.kt * a.g.kh * a.g.kw > 32 || a.g.Ktot / 16 < min_nk) return 0;
   if (a.g.st > 1 || a.g.sh > 1 || a.g.sw > 1) return 0;       // (few-row layers are stride 1; keeps one gather form)
   const int64_t mt = (a.M + 63) / 64;
@@ -2369,6 +2404,7 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   if (gvb == 16 && !aligned16(x)) return DV_EALIGN;
   const int esz = d->dtype == DV_F32 ? 4 : 2;
   if ((d->ldx * esz) % gvb || (a.ldw * esz) % gvb) return DV_EALIGN;
+  trim_dead_taps(a, MODE_FWD, d->dtype);
   int bm, bn;
   pick_tile(d->dtype, a.M, a.NP, bm, bn);
   a.ntn = (a.NP + bn - 1) / bn;
@@ -2524,6 +2560,7 @@ static int dgrad_impl(const dv_conv_desc* d, const void* dy, const void* wd, voi
         }
     return dv_launch_status();
   }
+  trim_dead_taps(a, MODE_DGRAD, d->dtype);
   int bm, bn;
   pick_tile(d->dtype, a.M, a.NP, bm, bn);
   a.ntn = (a.NP + bn - 1) / bn;
@@ -2587,10 +2624,20 @@ static WgradPlan plan_wgrad(const dv_conv_desc* d) {
   int per_cu = 3;
   p.cfg = -1;
   p.f32s = -1;
+  // DUALVAR_WGRAD_F32S: -1 (default) = the measured rule below, -2 = never, 0 .. 11 = that configuration everywhere (sweeps).
+  // Rule (tools/wgrad_sweep.sh on MI355X, isolated launches): the hand-placed 128 x 128 tile where Cout fills 128-row tiles
+  // (Mixed_3b 1x3x3 146 -> 131 us, a 128 -> 128 3x3 at 28x28 756 -> 692 us), the hand-placed 64 x 256 tile for the 64-channel
+  // layers with a wide im2col row (the 7x1x1 stem conv 797 -> 736 us); everything else stays on the 64 x 128 form (Cout = 192:
+  // 128-row tiles would idle a third of the MFMAs, 256-column tiles pad J = 576 by a third).
   static const int f32s_force = env_int("DUALVAR_WGRAD_F32S", -1);
-  if (p.dma && d->dtype == DV_F32 && !f32_exact() && f32s_force >= 0 && f32s_force < kNWgF32s) {
-    const WgradF32sCfg& k = kWgF32s[f32s_force];
-    p.f32s = f32s_force;
+  int f32s_pick = f32s_force >= 0 && f32s_force < kNWgF32s ? f32s_force : -1;
+  if (f32s_force == -1 && p.dma && d->dtype == DV_F32 && !f32_exact() && M >= 8192) {
+    if (d->Cout % 128 == 0 && J >= 256) f32s_pick = 8;
+    else if (d->Cout == 64 && J >= 384 && (J + 255) / 256 * 256 - J <= J / 6) f32s_pick = 6;
+  }
+  if (p.dma && d->dtype == DV_F32 && !f32_exact() && f32s_pick >= 0) {
+    const WgradF32sCfg& k = kWgF32s[f32s_pick];
+    p.f32s = f32s_pick;
     p.BI = k.BI; p.BJ = k.BJ;
     per_cu = std::max(1, std::min(2, 163840 / wgrad_f32s_lds(k.BI, k.BJ, k.ROWS, k.NS)));
   } else if (p.dma) {
@@ -2598,8 +2645,7 @@ static WgradPlan plan_wgrad(const dv_conv_desc* d) {
     // peak; a configuration whose tiles cannot even fill the chip once (few rows) pays for the idle CUs
     const WgradCfg* tab = d->dtype == DV_F32 ? kWgF32 : kWgBf16;
     const int ncfg = d->dtype == DV_F32 ? 2 : 4;
-    static const int force = env_int("DUALVAR_WGRAD_CFG", -1);
-    static const int minrows_ = env_int("DUALVAR_WGRAD_MINROWS", 256);
+    constexpr int minrows_ = 256;
     double best = 0;
     for (int c = 0; c < ncfg; ++c) {
       const WgradCfg& k = tab[c];
@@ -2612,7 +2658,6 @@ static WgradPlan plan_wgrad(const dv_conv_desc* d) {
       const double t = std::max(fill, mfma) * std::max(1.0, 256.0 / wgs);
       if (p.cfg < 0 || t < best) { best = t; p.cfg = c; }
     }
-    if (force >= 0 && force < ncfg) p.cfg = force;
     const WgradCfg& k = tab[p.cfg];
     p.BI = k.BI; p.BJ = k.BJ;
     per_cu = wgrad_wgs_per_cu(es, k.BI, k.BJ, k.WVI * k.WVJ, k.NS);
@@ -2627,11 +2672,9 @@ static WgradPlan plan_wgrad(const dv_conv_desc* d) {
   const int tiles = p.nti * p.ntj;
   // Row splits: ONE round of co-resident workgroups (256 CUs x the workgroups per CU the kernel's LDS / registers admit)
   // -- a grid of 1.5 rounds leaves half the chip idle for the second one -- but at least `minrows` rows each: a split's
-  // partial tile costs as much traffic as ~128 rows of its inputs.  DUALVAR_WGRAD_WGS(_F32) / _MINROWS: tuning knobs.
-  static const int tgt_bf16 = env_int("DUALVAR_WGRAD_WGS", 0), tgt_f32 = env_int("DUALVAR_WGRAD_WGS_F32", 0);
-  static const int minrows = env_int("DUALVAR_WGRAD_MINROWS", 256);
-  int tgt = d->dtype == DV_F32 ? tgt_f32 : tgt_bf16;
-  if (tgt <= 0) tgt = 256 * per_cu;
+  // partial tile costs as much traffic as ~128 rows of its inputs.
+  constexpr int minrows = 256;
+  const int tgt = 256 * per_cu;
   int splits = tgt / tiles;                          // round down: never more workgroups than fit at once
   const int max_splits = (M + minrows - 1) / minrows;
   if (splits > max_splits) splits = max_splits;
@@ -2640,11 +2683,10 @@ static WgradPlan plan_wgrad(const dv_conv_desc* d) {
   // S = sqrt(M/32 * t_step / (8 |W| / 4e6 us)).  (Layers with few rows and a large dW -- Mixed_4/5 -- had slab traffic of
   // 3x their operands.)
   {
-    static const int no_opt = env_int("DUALVAR_WGRAD_NO_SPLIT_MODEL", 0);
     const double t_step = d->dtype == DV_F32 ? 1.5 : 0.7;                        // us per 32-row step of one workgroup
     const double slab_us = 8.0 * d->Cout * (double)J / 4e6;
     const int s_opt = (int)(std::sqrt(M / 32.0 * t_step / slab_us) + 0.5);
-    if (!no_opt && splits > s_opt) splits = s_opt;
+    if (splits > s_opt) splits = s_opt;
   }
   if (splits < 1) splits = 1;
   p.rows_per_split = ((M + splits - 1) / splits + 31) / 32 * 32;
@@ -2689,7 +2731,7 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
   a.ldx = d->ldx; a.ldy = d->ldy; a.ldw = a.g.Ktot;
   a.nti = p.nti; a.ntj = p.ntj;
   a.rows_per_split = p.rows_per_split;
-  a.perm = make_row_perm(row_perm_enabled() && d->kt > 1 && d->To > 1, d->To, d->Ho * d->Wo);
+  a.perm = make_row_perm(d->kt > 1 && d->To > 1, d->To, d->Ho * d->Wo);
   const int grid = p.nti * p.ntj * p.splits;
   const bool narrow = p.BI == 64;
   hipStream_t s = (hipStream_t)stream;
@@ -2699,11 +2741,6 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
     aa.w = a;
     aa.x_bytes = (int)(((int64_t)d->N * d->Ti * d->Hi * d->Wi - 1) * d->ldx * es + (int64_t)d->cin_pitch * es);
     aa.dy_bytes = (int)(((int64_t)a.M - 1) * d->ldy * es + (int64_t)d->cout_pitch * es);
-    {   // diagnosis only (wrong results): every gather out of range -> zero fill without touching memory
-      static const int oob = env_int("DUALVAR_WGRAD_DIAG_OOB", 0);
-      if (oob & 1) aa.x_bytes = 16;
-      if (oob & 2) aa.dy_bytes = 16;
-    }
 #define WGD(T_, BI_, BJ_, WI_, WJ_, NS_, ...) \
   hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, BI_, BJ_, WI_, WJ_, NS_, ##__VA_ARGS__>), dim3(grid), dim3(WI_ * WJ_ * 64), 0, s, aa)
 #define WGS(BI_, BJ_, R_, NS_, ...) \
@@ -2735,13 +2772,8 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
         if (p.cfg == 1) WGD(float, 64, 128, 2, 2, 2);
         else WGD(float, 128, 128, 2, 2, 2);
       } else {
-        static const int share = env_int("DUALVAR_WGRAD_SHARE", 1);
-        if (share && p.cfg == 1) {
-          WGD(float, 64, 128, 1, 4, 2, true, true);
-        } else {
-          if (p.cfg == 1) WGD(float, 64, 128, 2, 2, 2, true);
-          else WGD(float, 128, 128, 2, 2, 2, true);
-        }
+        if (p.cfg == 1) WGD(float, 64, 128, 1, 4, 2, true, true);
+        else WGD(float, 128, 128, 2, 2, 2, true);
       }
     }
 #undef WGD

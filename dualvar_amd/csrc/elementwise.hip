@@ -340,9 +340,10 @@ __device__ __forceinline__ void column_reduce(int64_t r_begin, int64_t r_end, in
 // Tail of an ordered reduction over the nblk blocks of one item, each of which has stored NO = 2*CP partial sums to
 // ws[bid][NO].  Two levels, so that no single block has to walk hundreds of partial rows: the block that takes the last
 // ticket of its group of kFoldGroup blocks adds the group's rows in block order into a group row; the block that takes the
-// last group ticket adds the group rows in group order and WRITES out[NO].  Fences at agent scope around the tickets; after
-// the acquire the rows are read with ordinary (unrolled) loads.  Layout of ws: [nblk][NO] rows, [ngrp][NO] group rows,
-// [ngrp + 1] ticket words (zero on entry, zero again on exit).
+// last group ticket adds the group rows in group order and WRITES out[NO].  The hand-off (rows -> ticket -> reader) is the
+// sc1 / s_waitcnt form described below, not agent-scope fences.  Layout of ws: [nblk][NO] rows, [ngrp][NO] group rows,
+// [ngrp + 1] ticket words (zero on entry, zero again on exit; the host re-zeroes them after a failed launch:
+// dualvar_amd/_lib.py register_ticket_workspace).
 constexpr int kFoldGroup = 32;
 static inline int64_t ordered_fold_floats(int nblk, int CP) {
   const int ngrp = (nblk + kFoldGroup - 1) / kFoldGroup;
@@ -352,6 +353,18 @@ static inline int64_t ordered_fold_floats(int nblk, int CP) {
 // ordered by a plain s_waitcnt -- NOT by agent-scope fences: a release fence is a write-back of the whole L2 (buffer_wbl2) and
 // an acquire fence an invalidate, from every one of the thousands of blocks of a launch; measured, they took the reduce
 // launches of the S3D-G step from 1.4 to 4.0 - 7.9 ms.
+// The protocol, spelled out: (1) EVERY store of a handed-off row is an sc1 (write-through, agent-coherent) store; (2) every
+// storing wave drains them with s_waitcnt vmcnt(0), then the workgroup's barrier; (3) ONE lane takes the ticket with an
+// agent-scope atomic add; (4) only the workgroup whose add returned the last ticket reads, after a barrier its ticket lane
+// joins, and EVERY load of the rows is an sc1 load to registers (never cached in the reading CU's L1).  This is the
+// "sc1 stores + drained counter + sc1 loads" hand-off measured valid on gfx950 (MI355X_MICROARCH.md, inter-workgroup
+// visibility, valid forms); it is NOT a HIP memory-model guarantee and relies on stores retiring under vmcnt on this part.
+// Hence the guard: the file refuses to build for any other target (the library's host side refuses to run elsewhere too:
+// dv_check_device).  A port would replace coherent_store / stores_done / coherent_load by plain accesses between
+// __builtin_amdgcn_fence(__ATOMIC_RELEASE / __ATOMIC_ACQUIRE, "agent").
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "ordered_fold's sc1 / s_waitcnt hand-off is validated on gfx950 only (see the comment above)"
+#endif
 __device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float coherent_load(const float* p) {
   return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -410,9 +423,9 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const T* __restrict__ dy, int
                                                    const float* __restrict__ shift = nullptr, float* __restrict__ ws = nullptr,
                                                    uint32_t nblk = 0) {
   constexpr int V = DT<T>::VEC;
-  // Ordered mode (ws != nullptr): the block stores its partial sums to ws[bid][2][CP]; the block that arrives last (ticket
-  // behind the partials, agent-scope fences) adds the partials in block order into sums_all[0] -- no float atomics, so the sums
-  // do not depend on the order blocks finish in.  Legacy mode: atomics, spread over n_rep replicas because atomics on one
+  // Ordered mode (ws != nullptr): the block stores its partial sums to ws[bid][2][CP] (sc1 stores); the block that takes the
+  // last ticket (ordered_fold: drained stores -> ticket -> sc1 loads) adds the partials in block order into sums_all[0] -- no
+  // float atomics, so the sums do not depend on the order blocks finish in.  Legacy mode: atomics, spread over n_rep replicas because atomics on one
   // address serialise at the memory side (~12 ns each).
   float* sums = ws ? ws + (size_t)bid * 2 * CP : sums_all + (size_t)(bid % n_rep) * 2 * CP;
   const int64_t r0 = (int64_t)bid * rows_per_block;
@@ -1274,22 +1287,12 @@ static bool pool_tile_args(const PoolArgs& p, int V, int TH, int TW, int CV, int
   a.accumulate = accumulate;
   return true;
 }
-static int pool_tile_cv(int dflt) {
-  static const char* e = getenv("DUALVAR_POOL_CV");
-  return e ? atoi(e) : dflt;
-}
+static int pool_tile_cv(int dflt) { return dflt; }
 // Tile width / channel vectors per workgroup.  Measured on the 14x14 and 7x7 pools of S3D-G (tools/pool_sweep.sh): the
 // backward is occupancy-bound (three-plane ring of dy + idx), so it takes the 7-wide tile and 64 bytes of dy per pixel; the
-// forward (two single-plane slots) is flat between the shapes.  DUALVAR_POOL_TW / DUALVAR_POOL_CV override (experiments).
-static int pool_tile_tw(int W, bool narrow) {
-  static const char* e = getenv("DUALVAR_POOL_TW");
-  const int forced = e ? atoi(e) : 0;
-  return (forced == 7 || forced == 14) ? forced : ((W <= 7 || narrow) ? 7 : 14);
-}
-static bool pool_tile_off() {
-  static const char* e = getenv("DUALVAR_POOL_GATHER");
-  return e && atoi(e) != 0;
-}
+// forward (two single-plane slots) is flat between the shapes.
+static int pool_tile_tw(int W, bool narrow) { return (W <= 7 || narrow) ? 7 : 14; }
+static bool pool_tile_off() { return false; }
 
 // ------------------------------------------------------------------ spatial mean / gating
 // One workgroup per (sample, slice of the S positions): with one workgroup per sample (N = 128) half the CUs had no
@@ -1826,8 +1829,7 @@ extern "C" int dv_maxpool3d_bwd(const dv_pool_desc* d, const void* dy, const uin
     POOL_BWD_TILE(14, 2); POOL_BWD_TILE(14, 4); POOL_BWD_TILE(14, 8);
 #undef POOL_BWD_TILE
   }
-  static const bool no_quad = getenv("DUALVAR_POOL_NO_QUAD") && atoi(getenv("DUALVAR_POOL_NO_QUAD")) != 0;
-  if (!no_quad && a.kh == 3 && a.kw == 3 && a.sh == 2 && a.sw == 2 && a.ph == 1 && a.pw == 1 && (reinterpret_cast<uintptr_t>(idx) & 7) == 0) {
+  if (a.kh == 3 && a.kw == 3 && a.sh == 2 && a.sw == 2 && a.ph == 1 && a.pw == 1 && (reinterpret_cast<uintptr_t>(idx) & 7) == 0) {
     const int Hq = (a.Hi + 1) / 2, Wq = (a.Wi + 1) / 2;
     DISPATCH_T(d->dtype, {
       const int64_t total = (int64_t)a.N * a.Ti * Hq * Wq * (a.CP / DT<T>::VEC);

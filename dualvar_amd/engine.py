@@ -37,14 +37,14 @@ WGRAD_SIDE_STREAM = os.environ.get('DUALVAR_WGRAD_STREAM', '1') != '0'
 # backward launches whose results only the optimizer reads: weight gradients, the gate FCs' bias gradients
 SIDE_LAUNCHES = ('conv_wgrad', 'gate_db')
 # side launches issued per main-stream event (the event marker costs the main stream a few microseconds each)
-WGRAD_BATCH = int(os.environ.get('DUALVAR_WGRAD_BATCH', '4'))
-# BatchNorm + ReLU whose only consumer is a max-pool (the stems) run fused with it; '0' keeps the separate passes
-FUSE_BN_POOL = os.environ.get('DUALVAR_FUSE_BN_POOL', '1') != '0'
+WGRAD_BATCH = 4
+# BatchNorm + ReLU whose only consumer is a max-pool (the stems) run fused with it (module switch: the tests compare both forms)
+FUSE_BN_POOL = True
 # conv -> BatchNorm -> conv with a single reader: the BatchNorm-backward reduce can run in the second conv's data-gradient
 # epilogue (dv_conv3d_dgrad_bn).  OFF by default -- measured on the S3D-G step (MI355X, fp32 / bf16): the reduce launches shrink
 # 1.36 -> 0.66 / 1.07 -> 0.55 ms per step, but the data gradients that carry them grow by 0.62 / 0.52 ms (a serial tail per
 # workgroup that re-reads its tile and the BatchNorm input), and they sit on the critical path: 20.47 -> 20.77 / 9.79 -> 9.98 ms.
-FUSE_BN_REDUCE = os.environ.get('DUALVAR_FUSE_BN_REDUCE', '0') == '1'
+FUSE_BN_REDUCE = False        # (module switch, no environment variable: tests/test_models_gpu.py monkeypatches it)
 
 
 class Slot:
@@ -293,7 +293,7 @@ class ParamStore:
         self._w3_jobs = []
         for s_ in self.slots + self.merged:
             s_.w3_off = s_.wd3_off = -1
-        if dtype != DV_F32 or os.environ.get('DUALVAR_F32_EXACT') == '1' or os.environ.get('DUALVAR_F32_W3', '1') == '0':
+        if dtype != DV_F32 or L.f32_exact():
             return
         lib = L.load()
         convs = [s_ for s_ in self.slots + self.merged if s_.kind in ('conv', 'merged')]
@@ -910,7 +910,8 @@ class BNMember:
         self.sums_off = plan.reserve_zero(BN_REPLICAS * 2 * self.CP) if plan.with_grad else 0
         self.sums_len = BN_REPLICAS * 2 * self.CP
         # per-block partial sums + ticket of the ordered backward reduce (zero once: the kernel leaves the ticket zero)
-        self.red_ws = plan.f32(int(plan.lib.dv_bn_bwd_reduce_workspace(self.M, self.C)) // 4) if plan.with_grad else None
+        self.red_ws = (L.register_ticket_workspace(plan.f32(int(plan.lib.dv_bn_bwd_reduce_workspace(self.M, self.C)) // 4))
+                       if plan.with_grad else None)
 
 
 class BNGroupOp(Op):

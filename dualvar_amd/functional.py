@@ -237,10 +237,13 @@ class _InfoNCEFn(torch.autograd.Function):
         dq = torch.empty(B, D, dtype=torch.float32, device=dev)
         lib, s = _lib(), ops.stream_ptr()
         wsb = int(lib.dv_infonce_workspace(B, D, K))
-        key = (dev, wsb)
-        ws = _INFONCE_WS.get(key)          # ordered K-split of dq: zeroed once, the kernel leaves its tickets zero
+        # ordered K-split of dq: zeroed once, the kernel leaves its tickets zero.  One workspace per STREAM: two launches that
+        # share tickets from different streams would count each other's arrivals.
+        key = (dev, wsb, s)
+        ws = _INFONCE_WS.get(key)
         if ws is None and wsb:
-            ws = _INFONCE_WS[key] = torch.zeros(wsb // 4, dtype=torch.float32, device=dev)
+            from ._lib import register_ticket_workspace
+            ws = _INFONCE_WS[key] = register_ticket_workspace(torch.zeros(wsb // 4, dtype=torch.float32, device=dev))
         _chk(lib.dv_infonce_fwd(q.data_ptr(), k.data_ptr(), queue.data_ptr(), B, D, K, inv_T, logits.data_ptr(),
                                 loss_rows.data_ptr(), rank0.data_ptr(), dlog.data_ptr(), dq.data_ptr(),
                                 ws.data_ptr() if ws is not None else 0, wsb, s), 'dv_infonce_fwd')
@@ -396,7 +399,7 @@ class _BN1dTrainFn(torch.autograd.Function):
         g = _f32c(dy)
         gs, bs = st.slot(bn.weight), st.slot(bn.bias)
         sums = torch.zeros(2 * Fd, dtype=torch.float32, device=x.device)
-        ws = torch.zeros(int(lib.dv_bn_bwd_reduce_workspace(n, Fd)) // 4, dtype=torch.float32, device=x.device)
+        ws = torch.zeros(int(lib.dv_bn_bwd_reduce_workspace(n, Fd)) // 4, dtype=torch.float32, device=x.device)   # (fresh per call)
         no_mask = 32                                                     # DV_NO_RELU_MASK
         _chk(lib.dv_bn_bwd_reduce(DV_F32, g.data_ptr(), Fd, y.data_ptr(), Fd, x.data_ptr(), Fd, mean.data_ptr(), invstd.data_ptr(),
                                   n, Fd, no_mask, sums.data_ptr(), 1, ws.data_ptr(), s), 'bn1d bwd reduce')

@@ -85,25 +85,39 @@ class SGD(torch.optim.Optimizer):
         momentum buffers restored and warns when some are missing (a silent cold restart of the momentum is a
         different training run)."""
         import warnings
-        for g, s in zip(self.param_groups, sd['param_groups']):
-            g.update({k: v for k, v in s.items() if k != 'params'})
-        restored, views = 0, self._momentum_views()
+        views = self._momentum_views()
+        live = [st for st in self.stores if st.master is not None]
+        # validate EVERYTHING first: a mismatch must leave this optimizer exactly as it was (pretrain.py logs 'optimizer state
+        # not restored' and trains on -- with a half-restored momentum that would be a different, silent run)
+        if len(sd['param_groups']) != len(self.param_groups):
+            raise ValueError('optimizer state has %d param_groups, this optimizer %d' % (len(sd['param_groups']), len(self.param_groups)))
         if 'momentum_arenas' in sd:                         # round-1 format: one flat arena per store
-            for st, b in zip([s for s in self.stores if s.master is not None], sd['momentum_arenas']):
-                self._momentum_buf(st).copy_(b)
-            return len(views)
-        state = sd.get('state', {})
-        with torch.no_grad():
+            if len(sd['momentum_arenas']) != len(live) or any(b.numel() != st.total for st, b in zip(live, sd['momentum_arenas'])):
+                raise ValueError('momentum arenas do not match the parameter stores')
+        else:
+            state = sd.get('state', {})
+            staged = []
             for i, v in views:
                 e = state.get(i, state.get(str(i)))
                 mb = None if e is None else e.get('momentum_buffer')
+                if mb is not None and tuple(mb.shape) != tuple(v.shape):
+                    raise ValueError('momentum_buffer %d has shape %s, parameter has %s' % (i, tuple(mb.shape), tuple(v.shape)))
+                staged.append((v, mb))
+        # ... then mutate
+        for g, s in zip(self.param_groups, sd['param_groups']):
+            g.update({k: v for k, v in s.items() if k != 'params'})
+        if 'momentum_arenas' in sd:
+            for st, b in zip(live, sd['momentum_arenas']):
+                self._momentum_buf(st).copy_(b)
+            return len(views)
+        restored = 0
+        with torch.no_grad():
+            for v, mb in staged:
                 if mb is None:
                     v.zero_()
-                    continue
-                if tuple(mb.shape) != tuple(v.shape):
-                    raise ValueError('momentum_buffer %d has shape %s, parameter has %s' % (i, tuple(mb.shape), tuple(v.shape)))
-                v.copy_(mb.to(device=v.device, dtype=v.dtype))
-                restored += 1
+                else:
+                    v.copy_(mb.to(device=v.device, dtype=v.dtype))
+                    restored += 1
         if restored != len(views):
             warnings.warn('optimizer state: %d of %d momentum buffers restored, the rest start at zero'
                           % (restored, len(views)))

@@ -104,6 +104,7 @@ class GradSync:
         todo = [(a, b) for a, b in bucket_ranges(flat.numel(), self.bucket_elems) if a >= lo and a not in works]
         if not todo:
             return
+        plan.store._sync_started = True          # from here on nothing may write this arena before the optimizer step
         with self._comm_stream(flat, getattr(plan, '_side', None)):
             for a, b in todo:
                 works[a] = self._all_reduce(flat, a, b)
@@ -125,7 +126,9 @@ class GradSync:
         return 1.0 / self.world
 
     def __call__(self, store):
-        return self.reduce_flat(store.grad)
+        scale = self.reduce_flat(store.grad)
+        store._sync_started = False
+        return scale
 
 
 class _null:

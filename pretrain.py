@@ -114,6 +114,7 @@ def parse_args(argv=None):
                    help='HIP engine arithmetic: fp32 = the reference\'s (parity mode); bf16 = bf16 activation storage (throughput mode)')
     p.add_argument('--steps', default=0, type=int, help='stop every epoch after this many iterations (0 = whole epoch)')
     p.add_argument('--epoch_size', default=1024, type=int, help='synthetic samples per epoch (whole job)')
+    p.add_argument('--warm_steps', default=20, type=int, help='steps excluded from the steady-state clips/s of an epoch')
     return p.parse_args(argv)
 
 
@@ -134,17 +135,87 @@ class SyntheticClips(torch.utils.data.Dataset):
 
 class SyntheticFrames(torch.utils.data.Dataset):
     """batch['frames']: what a video decoder hands over -- uint8 [seq_len, 128, 171, 3] (A.Scale((128, 171)) of
-    pretrain.py:494); every view of the sample is cut from these frames by the augmenting ingest."""
+    pretrain.py:494); every view of the sample is cut from these frames by the augmenting ingest.
+    The decoder itself is out of scope: samples are drawn from a pool of pre-generated "videos", so a
+    worker's cost per sample is what the REAL pipeline also pays after decoding -- the augmentation draws.  With `transform`
+    the DataLoader WORKER draws the sample's augmentation (the reference augments in its workers too, pretrain.py:491-564) and
+    returns it as table rows (`aug`, `blur`: dualvar_amd.utils.transforms.AUG_ROW / AUG_BLUR), `views` views per sample; the pixels
+    are only touched on the GPU."""
 
-    def __init__(self, args, length):
+    def __init__(self, args, length, transform=None, views=1, pool=64):
         self.shape, self.length, self.seed = (args.seq_len, 128, 171, 3), length, args.seed
+        rs = np.random.RandomState(args.seed)
+        self.pool = torch.from_numpy(rs.randint(0, 256, (min(length, pool),) + self.shape, dtype=np.uint8))
+        self.transform, self.views, self.size = transform, views, (args.img_dim, args.img_dim)
 
     def __len__(self):
         return self.length
 
     def __getitem__(self, i):
-        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
-        return {'frames': torch.randint(0, 256, self.shape, generator=g, dtype=torch.uint8)}
+        out = {'frames': self.pool[i % self.pool.shape[0]]}
+        if self.transform is not None:
+            from dualvar_amd.utils.transforms import ClipState
+            L, Hs, Ws = self.shape[:3]
+            rows, blurs = [], []
+            for _ in range(self.views):
+                st = self.transform(ClipState(range(L), Hs, Ws))
+                rows.append(st.rows(*self.size))
+                blurs.append(st.blur_rows())
+            out['aug'] = torch.from_numpy(np.concatenate(rows).view(np.uint8).copy())
+            out['blur'] = torch.from_numpy(np.concatenate(blurs).view(np.uint8).copy())
+        return out
+
+
+def collate_frames(samples):
+    """default collate + the source-frame indices of sample b's augmentation rows moved to its place in the batch (b * L)"""
+    batch = torch.utils.data.default_collate(samples)
+    if 'aug' in batch:
+        B, L = batch['frames'].shape[:2]
+        rows = batch['aug'].numpy().view(np.int32).reshape(B, -1, 16)            # AUG_ROW: 16 words, word 0 = source frame
+        rows[:, :, 0] += (np.arange(B, dtype=np.int32) * L)[:, None]
+        blur = batch['blur'].numpy().view(np.uint32).reshape(B, -1, 4)
+        batch['has_blur'] = bool(blur[:, :, 1].any())                             # AUG_BLUR.ww: 0 = this frame is not blurred
+    return batch
+
+
+def seed_worker(worker_id):
+    """the augmentation classes draw from `random` / `numpy.random` (as the reference's do, utils/augmentation.py): one stream per
+    DataLoader worker, derived from torch's per-worker seed (utils/utils.py:worker_init_fn of the reference)"""
+    s_ = torch.initial_seed() % (1 << 31)
+    random.seed(s_)
+    np.random.seed(s_)
+
+
+class DevicePrefetcher:
+    """Hands out batches that are already on the GPU: batch i + 1 is copied host -> device from pinned memory on a side HIP stream
+    while step i computes (the reference copies in line, `.cuda(non_blocking=True)`, pretrain.py:396-400)."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device('cuda', device)
+        self.stream = torch.cuda.Stream(self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        it = iter(self.loader)
+
+        def load():
+            try:
+                b = next(it)
+            except StopIteration:
+                return None
+            with torch.cuda.stream(self.stream):
+                return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in b.items()}
+        nxt = load()
+        while nxt is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self.stream)
+            for v in nxt.values():
+                if torch.is_tensor(v):
+                    v.record_stream(cur)
+            batch, nxt = nxt, load()
+            yield batch
 
 
 def gpu_transform(args):
@@ -214,11 +285,20 @@ def main_worker(gpu, ngpus_per_node, args):
     optimizer = SGD(params, lr=args.lr, weight_decay=args.wd, momentum=0.9, stores=model.stores(), grad_sync=gsync)
 
     per_rank = max(args.epoch_size // max(args.world_size, 1), args.batch_size)
-    dataset = (SyntheticFrames if args.dataset == 'synthetic-frames' else SyntheticClips)(args, per_rank * max(args.world_size, 1))
-    args.gpu_transform = gpu_transform(args) if args.dataset == 'synthetic-frames' else None
+    n_samples = per_rank * max(args.world_size, 1)
+    if args.dataset == 'synthetic-frames':
+        # every view's augmentation is drawn in the DataLoader workers and applied on the GPU by the ingest kernel
+        args.gpu_transform = gpu_transform(args)
+        dataset = SyntheticFrames(args, n_samples, transform=args.gpu_transform, views=args.num_seq * args.n_proto)
+    else:
+        dataset = SyntheticClips(args, n_samples)
     sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=True) if args.distributed else None
+    nw = min(args.workers, 4)
     loader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
-                                         num_workers=min(args.workers, 4), pin_memory=True, drop_last=True)
+                                         num_workers=nw, pin_memory=True, drop_last=True, worker_init_fn=seed_worker,
+                                         collate_fn=collate_frames if args.dataset == 'synthetic-frames' else None,
+                                         persistent_workers=nw > 0, prefetch_factor=4 if nw > 0 else None)
+    loader = DevicePrefetcher(loader, args.gpu)
 
     best_acc = 0
     if args.resume and os.path.isfile(args.resume):
@@ -288,16 +368,38 @@ def train_one_epoch(data_loader, model, optimizer, scheduler, transforms_cuda, e
 
     tic = end = time.time()
     clips = 0
+    warm = min(args.warm_steps, max(len(data_loader) // 4, 0)) if not args.steps else min(args.warm_steps, args.steps // 4)
+    t_steady, clips_steady = None, 0
+    pending = None          # (device scalars, heads, B) of the previous step: read back AFTER this step's launches are queued
+
+    def drain(p):
+        host_dev, heads, B = p
+        host = host_dev.cpu().tolist()
+        for i, h in enumerate(heads):
+            if h not in losses_meters:
+                losses_meters[h], acc_meters[h] = AverageMeter(f'{h}_loss', ':.3f'), AverageMeter(f'{h}_acc', ':.3f')
+            losses_meters[h].update(host[i], B)
+            acc_meters[h].update(host[len(heads) + i], B)
+
     for idx, batch in enumerate(data_loader):
         data_time.update(time.time() - end)
         if 'frames' in batch:        # decoded frames: every view is augmented inside the ingest kernel
             from dualvar_amd.utils.transforms import FrameBatch
-            fr = batch['frames'].cuda(args.gpu, non_blocking=True)                       # [B, L, Hs, Ws, 3] uint8
-            L_ = fr.size(1)
-            input_seq = FrameBatch.build(fr.view(-1, *fr.shape[2:]), [list(range(b * L_, b * L_ + args.seq_len)) for b in range(fr.size(0))],
-                                         args.gpu_transform, (args.img_dim, args.img_dim), views=nv)
+            fr = batch['frames']                                                         # [B, L, Hs, Ws, 3] uint8, on the GPU
+            if not fr.is_cuda:
+                fr = fr.cuda(args.gpu, non_blocking=True)
+            if 'aug' in batch:       # rows drawn by the DataLoader workers (SyntheticFrames with a transform)
+                shape = (fr.size(0), nv, 3, args.seq_len, args.img_dim, args.img_dim) if nv > 1 else \
+                        (fr.size(0), 3, args.seq_len, args.img_dim, args.img_dim)
+                input_seq = FrameBatch(fr.view(-1, *fr.shape[2:]), batch['aug'].cuda(args.gpu).view(-1), shape,
+                                       blur=batch['blur'].cuda(args.gpu).view(-1) if batch.get('has_blur', True) else None)
+            else:
+                L_ = fr.size(1)
+                input_seq = FrameBatch.build(fr.view(-1, *fr.shape[2:]), [list(range(b * L_, b * L_ + args.seq_len)) for b in range(fr.size(0))],
+                                             args.gpu_transform, (args.img_dim, args.img_dim), views=nv)
         else:
-            input_seq = tr(batch['seq'].cuda(args.gpu, non_blocking=True))
+            x = batch['seq']
+            input_seq = tr(x if x.is_cuda else x.cuda(args.gpu, non_blocking=True))
         B = input_seq.size(0)
         ret = model(input_seq)
         loss = 0
@@ -314,7 +416,9 @@ def train_one_epoch(data_loader, model, optimizer, scheduler, transforms_cuda, e
         optimizer.step()
         clips += B * input_seq.size(1)
 
-        # one device->host copy for every scalar of the step (the reference does 2 .item() per head)
+        # one device->host copy for every scalar of the step (the reference does 2 .item() per head, pretrain.py:410-411,431-432),
+        # taken one step LATE: the copy of step i waits for the GPU, so it is issued after step i + 1 has been queued -- the
+        # host never runs dry of work it could be launching
         scal = [ret[(h + '_contrast_loss') if (h + '_contrast_loss') in ret else (h + '_loss')].detach().reshape(1) for h in heads]
         top1 = []
         for h in heads:
@@ -325,24 +429,32 @@ def train_one_epoch(data_loader, model, optimizer, scheduler, transforms_cuda, e
                 top1.append((lg[:, 1:].max(dim=1).values < lg[:, 0]).float().mean().reshape(1))
             else:
                 top1.append(torch.zeros(1, device=loss.device))
-        host = torch.cat(scal + top1).cpu().tolist()
-        for i, h in enumerate(heads):
-            if h not in losses_meters:
-                losses_meters[h], acc_meters[h] = AverageMeter(f'{h}_loss', ':.3f'), AverageMeter(f'{h}_acc', ':.3f')
-            losses_meters[h].update(host[i], B)
-            acc_meters[h].update(host[len(heads) + i], B)
+        if pending is not None:
+            drain(pending)
+        pending = (torch.cat(scal + top1), heads, B)
         batch_time.update(time.time() - end)
         end = time.time()
+        if idx + 1 == warm:
+            torch.cuda.synchronize()
+            t_steady, clips_steady = time.time(), clips
         if (idx + 1) % args.print_freq == 0 and args.print:
             progress.meters = [batch_time, data_time] + list(losses_meters.values()) + list(acc_meters.values())
             progress.display(idx)
         args.iteration += 1
         if args.steps and idx + 1 >= args.steps:
             break
+    if pending is not None:
+        drain(pending)
+    torch.cuda.synchronize()
     dt = time.time() - tic
     world = max(args.world_size, 1)
     args.logger.info('Epoch: [{0}/{1}]\tT-epoch:{t:.2f}\tLoss:{loss:.4f}\tclips/s (whole job):{cps:.1f}'.format(
         epoch, args.epochs, t=dt, loss=sum(m.avg for m in losses_meters.values()), cps=clips * world / max(dt, 1e-9)))
+    if t_steady is not None and clips > clips_steady:
+        # steady state: after the first `warm` steps (plan building, first-touch allocation, DataLoader start-up)
+        args.steady_clips_per_s = (clips - clips_steady) * world / max(time.time() - t_steady, 1e-9)
+        args.logger.info('Epoch: [{0}/{1}]\tsteady-state clips/s (whole job, steps {w}..{n}):{cps:.1f}\tdata wait per step:{dw:.2f} ms'.format(
+            epoch, args.epochs, w=warm, n=idx + 1, cps=args.steady_clips_per_s, dw=data_time.avg * 1e3))
     scheduler.step()
     args.lr = optimizer.param_groups[0]['lr']
     return losses_meters['clip'].avg, acc_meters['clip'].avg

@@ -290,3 +290,114 @@ def test_bench_watchdog_names_the_stuck_phase():
     assert r.returncode != 0
     assert b'WATCHDOG' in r.stderr and b'launch-check all-reduce' in r.stderr
     assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')]
+
+
+@pytest.mark.parametrize('kind,net', [('SimCLR_TimeSeriesV4', 's3dg'), ('MoCo_Naked', 'r3d')])
+def test_optimizer_load_state_dict_is_all_or_nothing(kind, net):
+    """A state whose k-th momentum buffer has the wrong shape must leave the optimizer untouched -- lr / param_groups and every
+    momentum view as before (the reference's --resume path logs the failure and trains on, pretrain.py:287-306) -- and the
+    positional mapping torch index -> arena view holds for an S3D-G model and a MoCo model as well."""
+    import types
+    import torch
+    from dualvar_amd import model as M
+    from dualvar_amd.ops import DV_F32
+    from dualvar_amd.optim import SGD
+    from oracle import torch_ref as O
+    a = types.SimpleNamespace(shufflerank_theta=0.05)
+    mk = (lambda mod: mod.SimCLR_TimeSeriesV4(net, 128, 0.07, False, args=a)) if kind.startswith('SimCLR') else \
+         (lambda mod: mod.MoCo_Naked(net, 128, 256, 0.999, 0.07, False))
+    torch.manual_seed(0)
+    ref, mine = mk(O), mk(M)
+    for st in mine.stores():
+        st.materialize(torch.device('cpu'), DV_F32)
+    rparams = [p for p in ref.parameters() if p.requires_grad]
+    mparams = [p for p in mine.parameters() if p.requires_grad]
+    assert [tuple(p.shape) for p in mparams] == [tuple(p.shape) for p in rparams]     # same order, same shapes as the reference
+    ropt = torch.optim.SGD([{'params': [p]} for p in rparams], lr=0.003, momentum=0.9, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(5)
+    for p in rparams:
+        p.grad = torch.randn(p.shape, generator=g)
+    ropt.step()
+    opt = SGD([{'params': [p]} for p in mparams], lr=0.01, momentum=0.9, weight_decay=1e-4, stores=mine.stores())
+    for _, v in opt._momentum_views():
+        v.fill_(0.25)
+    import copy
+    sd = copy.deepcopy(ropt.state_dict())            # (state_dict() hands out the optimizer's own per-parameter dicts)
+    k = len(rparams) // 2
+    sd['state'][k]['momentum_buffer'] = torch.zeros(3, 5)                                # wrong shape in the MIDDLE
+    sd['param_groups'][0]['lr'] = 123.0
+    with pytest.raises(ValueError):
+        opt.load_state_dict(sd)
+    assert opt.param_groups[0]['lr'] == 0.01
+    assert all(bool((v == 0.25).all()) for _, v in opt._momentum_views()), 'a failed load must not touch the momentum'
+    # the intact state maps index for index
+    assert opt.load_state_dict(ropt.state_dict()) == len(rparams)
+    views = dict(opt._momentum_views())
+    for i, p in enumerate(rparams):
+        assert torch.equal(views[i], ropt.state[p]['momentum_buffer']), i
+
+
+def test_f32_exact_switch_is_parsed_like_the_library(monkeypatch):
+    from dualvar_amd import _lib
+    for v, want in [('1', True), ('2', True), ('01', True), ('0', False), ('', False), ('yes', False), (' 3', True)]:
+        monkeypatch.setenv('DUALVAR_F32_EXACT', v)
+        assert _lib.f32_exact() is want, (v, want)
+
+
+def test_failed_launch_rezeroes_ticket_workspaces():
+    from dualvar_amd import _lib
+    t = _lib.register_ticket_workspace(torch.ones(16))
+    with pytest.raises(_lib.DualVarHipError):
+        _lib.check(-1, 'rejected arguments: nothing was launched')
+    assert float(t.sum()) == 16.0
+    with pytest.raises(_lib.DualVarHipError):
+        _lib.check(700, 'a launch that failed')
+    assert float(t.sum()) == 0.0
+
+
+def test_overlapped_gradient_sync_refuses_a_second_backward():
+    """GradSync.attach starts bucket all-reduces from inside the backward pass; a further backward into the same arena before the
+    optimizer step would mix local gradients into cross-rank sums: the encoder's backward raises instead."""
+    from dualvar_amd.backbone.base import _BackboneFn
+
+    class _Store:
+        _sync_started = True
+
+    class _Plan:
+        store = _Store()
+
+    class _Ctx:
+        plan = _Plan()
+    with pytest.raises(RuntimeError, match='overlapped all-reduce'):
+        _BackboneFn.backward(_Ctx(), None)
+
+
+def test_worker_side_augmentation_rows_equal_the_in_line_build():
+    """pretrain.py --dataset synthetic-frames: the DataLoader workers draw every view's augmentation and ship it as table rows; the
+    collate moves the rows' source-frame indices to the sample's place in the batch.  Same seeds, same order of draws ->
+    byte-identical tables to FrameBatch.build on the stacked frames (the in-line path the GPU fixtures pin)."""
+    import random
+    import pretrain
+    from dualvar_amd.utils.transforms import FrameBatch
+    a = pretrain.parse_args(['--net', 's3dg', '--model', 'simclr_naked', '--batch_size', '4', '--seq_len', '8', '--img_dim', '112',
+                             '--dataset', 'synthetic-frames', '--rand_flip'])
+    tr = pretrain.gpu_transform(a)
+    ds = pretrain.SyntheticFrames(a, 16, transform=tr, views=2)
+    random.seed(7)
+    np.random.seed(7)
+    torch.manual_seed(7)
+    batch = pretrain.collate_frames([ds[i] for i in range(4)])
+    fr = batch['frames']
+    assert fr.shape == (4, 8, 128, 171, 3) and fr.dtype == torch.uint8
+    random.seed(7)
+    np.random.seed(7)
+    torch.manual_seed(7)
+    ref = FrameBatch.build(fr.view(-1, 128, 171, 3), [list(range(b * 8, b * 8 + 8)) for b in range(4)], tr, (112, 112), views=2, device='cpu')
+    assert torch.equal(batch['aug'].view(-1), ref.table.view(-1))
+    if ref.blur is not None:
+        assert batch['has_blur'] and torch.equal(batch['blur'].view(-1), ref.blur.view(-1))
+    else:
+        assert not batch['has_blur']
+    got = FrameBatch(fr.view(-1, 128, 171, 3), batch['aug'].view(-1), (4, 2, 3, 8, 112, 112),
+                     blur=batch['blur'].view(-1) if batch['has_blur'] else None)
+    assert tuple(got.shape) == tuple(ref.shape)

@@ -663,7 +663,7 @@ def test_r50_fp8_pointwise_mode_at_32x224(gpu):
 # optional plan: BatchNorm-backward reduce inside the consuming conv's data gradient (engine.FUSE_BN_REDUCE)
 @pytest.mark.parametrize('net,dtype', [('r3d', 'fp32'), ('r21d', 'fp32'), ('s3dg', 'bf16')])
 def test_fused_bn_reduce_plan_gives_the_same_gradients(gpu, monkeypatch, net, dtype):
-    """DUALVAR_FUSE_BN_REDUCE=1 moves the reduce of every conv -> BatchNorm -> conv chain with a single reader into
+    """engine.FUSE_BN_REDUCE = True moves the reduce of every conv -> BatchNorm -> conv chain with a single reader into
     dv_conv3d_dgrad_bn.  Same step, same gradients up to the order of the fp32 sums (the standalone reduce folds its per-block rows in
     block order; the fused form adds one value per column and tile with an atomic into a few replicas)."""
     from dualvar_amd import engine, model as M

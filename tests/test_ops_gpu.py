@@ -49,6 +49,11 @@ CONV_CASES = [
     ('full3', 2, 32, 4, 8, 8, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     ('big_n', 2, 160, 1, 3, 3, 320, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ('r50_stem', 1, 3, 8, 20, 20, 64, (5, 7, 7), (2, 2, 2), (2, 3, 3)),
+    # windows with taps that are padding for EVERY row (trim_dead_taps in csrc/conv.hip): one-frame maps under 3x1x1 / 3x3x3
+    ('tm3_t1', 3, 64, 1, 3, 3, 96, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ('tm3_t1_c24', 2, 24, 1, 4, 4, 48, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ('full3_t1', 2, 32, 1, 2, 2, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ('full3_t1_h1', 4, 48, 1, 1, 5, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
 ]
 
 
