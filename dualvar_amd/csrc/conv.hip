@@ -1717,7 +1717,7 @@ constexpr int wgrad_f32s_waves_per_simd(int bi, int bj, int rows, int ns) {
   return 163840 / wgrad_f32s_lds(bi, bj, rows, ns) >= 2 ? 2 : 1;
 }
 
-template <int BI, int BJ, int ROWS, int NS, int SGB_VALU = 0, int SGB_DSR = 1>
+template <int BI, int BJ, int ROWS, int NS>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(wgrad_f32s_waves_per_simd(BI, BJ, ROWS, NS)))) void conv_wgrad_f32s_kernel(WgradDmaArgs aa) {
   const WgradArgs& a = aa.w;
@@ -1895,8 +1895,8 @@ __attribute__((amdgpu_waves_per_eu(wgrad_f32s_waves_per_simd(BI, BJ, ROWS, NS)))
     }
   };
   // iteration s (-1 <= s < nsteps): multiply step s, split step s + 1, prefetch step s + 1 + D, make step s + 2 visible.
-  // STEADY: every part exists (0 <= s, s + 1 + D < nsteps) -- no conditions, so that the multiply and the split are ONE basic
-  // block the scheduler can interleave; the first and the last D + 1 iterations take the conditional form.
+  // Steady iterations (0 <= s, s + 1 + D < nsteps: every part exists, no conditions) run steady_hand below; the first and the
+  // last D + 1 iterations take the conditional form `iteration`.
   static_assert(PPC % NW == 0 && QPC % NW == 0, "every wave issues the same pieces per step (compile-time wait counts)");
   constexpr int PIECES = PPC / NW + QPC / NW;
   static_assert((D - 1) * PIECES <= 24, "counted wait");
@@ -2016,23 +2016,16 @@ __attribute__((amdgpu_waves_per_eu(wgrad_f32s_waves_per_simd(BI, BJ, ROWS, NS)))
     else wait_tail(D - 1);
     __syncthreads();
   };
-  auto iteration = [&](int s, const Split3 (&bcur)[NKS][TJ], Split3 (&bnext)[NKS][TJ], auto steady) {
-    constexpr bool STEADY = decltype(steady)::value;
+  // the first and the last D + 1 iterations: every part behind its condition (compiler-scheduled)
+  auto iteration = [&](int s, const Split3 (&bcur)[NKS][TJ], Split3 (&bnext)[NKS][TJ]) {
     const int sn = s + 1;
-    if ((STEADY || sn < nsteps) && (sn % SPR) == 0 && (sn + SPR) < nsteps) decode(sn / SPR + 1);
-    if (STEADY || sn + D < nsteps) issue(sn + D, (sn + D) % NS);  // its stage was last read by split_step(s), one barrier ago
-    if (STEADY || s >= 0) mma_step(s, bcur);
-    if (STEADY || sn < nsteps) split_step(sn, bnext);
-    if constexpr (STEADY) {
-      if constexpr (D == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-      else wait_tail(D - 1);
-    } else if (sn + 1 < nsteps) {
-      wait_tail(min(D - 1, nsteps - 2 - sn));                     // step s + 2 has landed (this wave's pieces)
-    }
+    if (sn < nsteps && (sn % SPR) == 0 && (sn + SPR) < nsteps) decode(sn / SPR + 1);
+    if (sn + D < nsteps) issue(sn + D, (sn + D) % NS);          // its stage was last read by split_step(s), one barrier ago
+    if (s >= 0) mma_step(s, bcur);
+    if (sn < nsteps) split_step(sn, bnext);
+    if (sn + 1 < nsteps) wait_tail(min(D - 1, nsteps - 2 - sn));  // step s + 2 has landed (this wave's pieces)
     __syncthreads();
   };
-  typedef std::integral_constant<bool, true> steady_t;
-  typedef std::integral_constant<bool, false> edge_t;
 
   decode(0);
   if (SPR < nsteps) decode(1);                       // (the loop decodes round r + 1 at the first step of round r, r >= 1)
@@ -2051,22 +2044,17 @@ __attribute__((amdgpu_waves_per_eu(wgrad_f32s_waves_per_simd(BI, BJ, ROWS, NS)))
   // steady iterations: s + 1 + D < nsteps, in pairs (the x fragments alternate between two register sets)
   const int n_steady = max(0, nsteps - 1 - D) & ~1;
   int s = 0;
-  if constexpr (SGB_VALU > 0) {
+  {
     int st_next = 1 % NS, st_issue = (1 + D) % NS;               // stages of steps s + 1 and s + 1 + D at s = 0
     auto adv = [&] { st_next = st_next + 1 == NS ? 0 : st_next + 1; st_issue = st_issue + 1 == NS ? 0 : st_issue + 1; };
     for (; s < n_steady; s += 2) {
       steady_hand(s, st_next, st_issue, b0, b1); adv();
       steady_hand(s + 1, st_next, st_issue, b1, b0); adv();
     }
-  } else {
-    for (; s < n_steady; s += 2) {
-      iteration(s, b0, b1, steady_t());
-      iteration(s + 1, b1, b0, steady_t());
-    }
   }
   for (; s < nsteps; s += 2) {
-    iteration(s, b0, b1, edge_t());
-    if (s + 1 < nsteps) iteration(s + 1, b1, b0, edge_t());
+    iteration(s, b0, b1);
+    if (s + 1 < nsteps) iteration(s + 1, b1, b0);
   }
 
 #pragma unroll
@@ -2595,11 +2583,8 @@ static const WgradCfg kWgF32[] = {{128, 128, 2, 2, 2}, {64, 128, 2, 2, 2}};
 // conv_wgrad_f32s_kernel<BI, BJ, ROWS, NS> instantiations (the fp32 split mode's second weight-gradient form)
 struct WgradF32sCfg { int BI, BJ, ROWS, NS; };
 static const WgradF32sCfg kWgF32s[] = {{64, 256, 16, 3}, {64, 256, 32, 3}, {128, 128, 16, 3}, {128, 128, 32, 3}, {128, 256, 16, 3},
-                                       {64, 128, 16, 3},
-                                       // 6..: the same tiles with the split interleaved between the MFMAs (sched_group_barrier)
-                                       {64, 256, 16, 3}, {64, 256, 32, 3}, {128, 128, 16, 3}, {128, 128, 32, 3}, {128, 256, 16, 3},
                                        {64, 128, 16, 3}};
-static const int kNWgF32s = 12;
+static const int kNWgF32s = 6;
 
 struct WgradPlan {
   int BI, BJ, nti, ntj, splits, rows_per_split, gvb, cfg;
@@ -2624,17 +2609,12 @@ static WgradPlan plan_wgrad(const dv_conv_desc* d) {
   int per_cu = 3;
   p.cfg = -1;
   p.f32s = -1;
-  // DUALVAR_WGRAD_F32S: -1 (default) = the measured rule below, -2 = never, 0 .. 11 = that configuration everywhere (sweeps).
-  // Rule (tools/wgrad_sweep.sh on MI355X, isolated launches): the hand-placed 128 x 128 tile where Cout fills 128-row tiles
-  // (Mixed_3b 1x3x3 146 -> 131 us, a 128 -> 128 3x3 at 28x28 756 -> 692 us), the hand-placed 64 x 256 tile for the 64-channel
-  // layers with a wide im2col row (the 7x1x1 stem conv 797 -> 736 us); everything else stays on the 64 x 128 form (Cout = 192:
-  // 128-row tiles would idle a third of the MFMAs, 256-column tiles pad J = 576 by a third).
+  // DUALVAR_WGRAD_F32S = 0 .. 5: conv_wgrad_f32s_kernel configuration kWgF32s[.] for every fp32 weight gradient (sweeps:
+  // tools/wgrad_sweep.sh).  Not selected by default: isolated it gains 8 - 10 % on the layers whose shape its tiles fit
+  // (128-channel layers on 128 x 128, the 7x1x1 stem conv on 64 x 256) and nothing elsewhere, and a per-layer rule built
+  // on that measured 19.39 vs 19.39 ms on the whole step ("fp32 weight gradient: what bounds it").
   static const int f32s_force = env_int("DUALVAR_WGRAD_F32S", -1);
-  int f32s_pick = f32s_force >= 0 && f32s_force < kNWgF32s ? f32s_force : -1;
-  if (f32s_force == -1 && p.dma && d->dtype == DV_F32 && !f32_exact() && M >= 8192) {
-    if (d->Cout % 128 == 0 && J >= 256) f32s_pick = 8;
-    else if (d->Cout == 64 && J >= 384 && (J + 255) / 256 * 256 - J <= J / 6) f32s_pick = 6;
-  }
+  const int f32s_pick = f32s_force >= 0 && f32s_force < kNWgF32s ? f32s_force : -1;
   if (p.dma && d->dtype == DV_F32 && !f32_exact() && f32s_pick >= 0) {
     const WgradF32sCfg& k = kWgF32s[f32s_pick];
     p.f32s = f32s_pick;
@@ -2743,8 +2723,8 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
     aa.dy_bytes = (int)(((int64_t)a.M - 1) * d->ldy * es + (int64_t)d->cout_pitch * es);
 #define WGD(T_, BI_, BJ_, WI_, WJ_, NS_, ...) \
   hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, BI_, BJ_, WI_, WJ_, NS_, ##__VA_ARGS__>), dim3(grid), dim3(WI_ * WJ_ * 64), 0, s, aa)
-#define WGS(BI_, BJ_, R_, NS_, ...) \
-  hipLaunchKernelGGL((conv_wgrad_f32s_kernel<BI_, BJ_, R_, NS_, ##__VA_ARGS__>), dim3(grid), dim3(256), 0, s, aa)
+#define WGS(BI_, BJ_, R_, NS_) \
+  hipLaunchKernelGGL((conv_wgrad_f32s_kernel<BI_, BJ_, R_, NS_>), dim3(grid), dim3(256), 0, s, aa)
     if (p.f32s >= 0) {
       switch (p.f32s) {
         case 0: WGS(64, 256, 16, 3); break;
@@ -2752,13 +2732,7 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
         case 2: WGS(128, 128, 16, 3); break;
         case 3: WGS(128, 128, 32, 3); break;
         case 4: WGS(128, 256, 16, 3); break;
-        case 5: WGS(64, 128, 16, 3); break;
-        case 6: WGS(64, 256, 16, 3, 7); break;
-        case 7: WGS(64, 256, 32, 3, 7); break;
-        case 8: WGS(128, 128, 16, 3, 4); break;
-        case 9: WGS(128, 128, 32, 3, 4); break;
-        case 10: WGS(128, 256, 16, 3, 4); break;
-        default: WGS(64, 128, 16, 3, 9); break;
+        default: WGS(64, 128, 16, 3); break;
       }
     } else if (d->dtype == DV_BF16) {
       switch (p.cfg) {

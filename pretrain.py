@@ -356,6 +356,7 @@ def train_one_epoch(data_loader, model, optimizer, scheduler, transforms_cuda, e
                     model_head=None, head_optimizer=None, head_scheduler=None):
     """pretrain.py:364-489 (signature as the reference defines it)."""
     batch_time, data_time = AverageMeter('Time', ':.2f'), AverageMeter('Data', ':.2f')
+    issue_time = AverageMeter('Issue', ':.4f')     # host time to build the input and queue the step's launches (no GPU wait inside)
     losses_meters, acc_meters = OrderedDict(clip=AverageMeter('VLoss', ':.4f')), OrderedDict(clip=AverageMeter('Vacc@1', ':.4f'))
     progress = ProgressMeter(len(data_loader), [batch_time, data_time], prefix='Epoch:[{}/{}] lr:{} '.format(
         epoch, args.epochs, optimizer.param_groups[0]['lr']), logger=args.logger)
@@ -372,9 +373,29 @@ def train_one_epoch(data_loader, model, optimizer, scheduler, transforms_cuda, e
     t_steady, clips_steady = None, 0
     pending = None          # (device scalars, heads, B) of the previous step: read back AFTER this step's launches are queued
 
+    # The scalars of a step go device -> host on a COPY STREAM, behind an event recorded where they are produced: a `.cpu()` on
+    # the main stream would queue behind every launch of the NEXT step (already issued when the copy is requested) and the
+    # host would find the GPU idle each time it comes back from it (measured: 23.1 instead of 20.x ms per step).
+    copy_stream = torch.cuda.Stream(args.gpu)
+    host_bufs = [None, None]
+
+    def stage(dev_vec, heads, B, slot):
+        if host_bufs[slot] is None or host_bufs[slot].numel() != dev_vec.numel():
+            host_bufs[slot] = torch.empty(dev_vec.numel(), dtype=torch.float32).pin_memory()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(args.gpu))
+        dev_vec.record_stream(copy_stream)
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ready)
+            host_bufs[slot].copy_(dev_vec, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(copy_stream)
+        return (done, host_bufs[slot], heads, B)
+
     def drain(p):
-        host_dev, heads, B = p
-        host = host_dev.cpu().tolist()
+        done, buf, heads, B = p
+        done.synchronize()
+        host = buf.tolist()
         for i, h in enumerate(heads):
             if h not in losses_meters:
                 losses_meters[h], acc_meters[h] = AverageMeter(f'{h}_loss', ':.3f'), AverageMeter(f'{h}_acc', ':.3f')
@@ -429,16 +450,18 @@ def train_one_epoch(data_loader, model, optimizer, scheduler, transforms_cuda, e
                 top1.append((lg[:, 1:].max(dim=1).values < lg[:, 0]).float().mean().reshape(1))
             else:
                 top1.append(torch.zeros(1, device=loss.device))
+        new_pending = stage(torch.cat(scal + top1), heads, B, idx & 1)
+        issue_time.update(time.time() - end)
         if pending is not None:
             drain(pending)
-        pending = (torch.cat(scal + top1), heads, B)
+        pending = new_pending
         batch_time.update(time.time() - end)
         end = time.time()
         if idx + 1 == warm:
             torch.cuda.synchronize()
             t_steady, clips_steady = time.time(), clips
-        if (idx + 1) % args.print_freq == 0 and args.print:
-            progress.meters = [batch_time, data_time] + list(losses_meters.values()) + list(acc_meters.values())
+        if (idx + 1) % args.print_freq == 0 and args.print and losses_meters['clip'].count > 0:     # (the meters run one step late)
+            progress.meters = [batch_time, data_time, issue_time] + list(losses_meters.values()) + list(acc_meters.values())
             progress.display(idx)
         args.iteration += 1
         if args.steps and idx + 1 >= args.steps:
@@ -454,7 +477,8 @@ def train_one_epoch(data_loader, model, optimizer, scheduler, transforms_cuda, e
         # steady state: after the first `warm` steps (plan building, first-touch allocation, DataLoader start-up)
         args.steady_clips_per_s = (clips - clips_steady) * world / max(time.time() - t_steady, 1e-9)
         args.logger.info('Epoch: [{0}/{1}]\tsteady-state clips/s (whole job, steps {w}..{n}):{cps:.1f}\tdata wait per step:{dw:.2f} ms'.format(
-            epoch, args.epochs, w=warm, n=idx + 1, cps=args.steady_clips_per_s, dw=data_time.avg * 1e3))
+            epoch, args.epochs, w=warm, n=idx + 1, cps=args.steady_clips_per_s, dw=data_time.avg * 1e3) +
+                         '\thost issue per step:%.2f ms' % (issue_time.avg * 1e3))
     scheduler.step()
     args.lr = optimizer.param_groups[0]['lr']
     return losses_meters['clip'].avg, acc_meters['clip'].avg

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Development aid: correctness (op tests) and speed (tools/conv_microbench.py, wgrad pass) of every conv_wgrad_f32s_kernel
-# configuration against the default fp32 weight gradient.  usage: tools/wgrad_sweep.sh <outdir> [configs...]
+# configuration against the default fp32 weight gradient.  usage: tools/wgrad_sweep.sh <outdir> [configs...]   (0..5)
 OUT=${1:-gpurun_out/wg}; shift
 CFGS=${@:-"0 1 2 3 4 5"}
 mkdir -p $OUT
