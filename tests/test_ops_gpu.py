@@ -54,6 +54,10 @@ CONV_CASES = [
     ('tm3_t1_c24', 2, 24, 1, 4, 4, 48, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
     ('full3_t1', 2, 32, 1, 2, 2, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     ('full3_t1_h1', 4, 48, 1, 1, 5, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    # the pixel-pair stem's geometry: 8 channels (= half a K tile of 16 f32), even kernel width, padding-free, stride (1, 2, 1):
+    # (generic gather: a K tile spans two taps)
+    ('pair_stem', 2, 8, 4, 20, 22, 64, (1, 7, 4), (1, 2, 1), (0, 0, 0)),
+    ('pair_stem_t', 1, 8, 9, 12, 10, 64, (5, 7, 4), (2, 2, 1), (2, 0, 0)),
 ]
 
 
