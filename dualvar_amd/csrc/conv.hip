@@ -2353,6 +2353,23 @@ extern "C" int dv_conv3d_tile_shape(const dv_conv_desc* d, int32_t dgrad, int32_
   return DV_OK;
 }
 
+extern "C" int dv_conv3d_ksplit_cols(const dv_conv_desc* d, int32_t dgrad) {
+  if (!d || check_desc(d)) return 0;
+  if (dgrad && (d->st > 1 || d->sh > 1 || d->sw > 1)) return 0;
+  ConvArgs a;
+  fill_geom(d, dgrad ? MODE_DGRAD : MODE_FWD, a.g);
+  a.M = dgrad ? d->N * d->Ti * d->Hi * d->Wi : d->N * d->To * d->Ho * d->Wo;
+  a.N = dgrad ? d->Cin : d->Cout;
+  a.NP = dgrad ? d->cin_pitch : d->cout_pitch;
+  a.flags = d->flags & DV_W3;
+  a.cls_on = 0;
+  a.bn_x = nullptr;
+  trim_dead_taps(a, dgrad ? MODE_DGRAD : MODE_FWD, d->dtype);
+  int bm, bn;
+  pick_tile(d->dtype, a.M, a.NP, bm, bn);
+  return ks_tile(d->dtype, a, bm);
+}
+
 extern "C" int dv_conv3d_stat_tiles(const dv_conv_desc* d) {
   if (!d) return DV_EINVAL;
   const int64_t m = (int64_t)d->N * d->To * d->Ho * d->Wo;

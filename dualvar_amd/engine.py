@@ -434,6 +434,15 @@ class HostStep:
         self.call()
 
 
+def _conv_kname(lib, d, dgrad, dt, gv=16):
+    """label of the kernel dv_conv3d_fwd / dv_conv3d_dgrad will launch for this descriptor (bench.py / profiles group by it)"""
+    ks = int(lib.dv_conv3d_ksplit_cols(C.byref(d), int(dgrad)))
+    mode = 'DGRAD' if dgrad else 'FWD'
+    if ks:
+        return 'conv_gemm_ks<%s,%s,64,%d>' % (dt, mode, ks)
+    return 'conv_gemm<%s,%s,%d,%d,%d>' % ((dt, mode, gv) + _tile_shape(lib, d, dgrad))
+
+
 def _tile_shape(lib, d, dgrad):
     """(rows, cols) of the GEMM tile the library will pick: only for the per-launch profiling labels."""
     r, c = C.c_int32(0), C.c_int32(0)
@@ -797,7 +806,7 @@ class ConvOp(Op):
         flops = 2 * y.rows * sl.Cout * kdim
         wbytes = sl.Cout * kdim * es
         gv = 8 if (self.dtype == DV_BF16 and sl.cin_pitch % 8) else 16
-        kf = 'conv_gemm<%s,FWD,%d,%d,%d>' % ((_dt(self.dtype), gv) + _tile_shape(lib, self.d, 0))
+        kf = _conv_kname(lib, self.d, 0, _dt(self.dtype), gv)
         shp = 'M%d Cin%d Cout%d k%s s%s' % (y.rows, sl.Cin, sl.Cout, 'x'.join(map(str, self.k)), 'x'.join(map(str, self.s)))
         f = [Launch('conv_fwd', kf, lib.dv_conv3d_fwd,
                     (C.byref(self.d), x.ptr, self._wf, 0, y.ptr, self.stats.data_ptr() if self.stats is not None else 0),
@@ -826,7 +835,7 @@ class ConvOp(Op):
                 acc = bool(self.acc.get('x'))
                 wdp, wdflag = st.w_dgrad(sl, strided=max(self.s) > 1)
                 self.d_g = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=(DV_ACCUM if acc else 0) | wdflag)
-                kd = 'conv_gemm<%s,DGRAD,16,%d,%d>' % ((_dt(self.dtype),) + _tile_shape(lib, self.d_g, 1))
+                kd = _conv_kname(lib, self.d_g, 1, _dt(self.dtype))
                 if self.bn_fuse is not None:
                     m = self.bn_fuse
                     r = self._bn_reduce = L.BnReduce()

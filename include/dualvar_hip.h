@@ -96,6 +96,9 @@ int dv_conv3d_tile_rows(const dv_conv_desc* d);
 /* the GEMM tile (rows x columns) dv_conv3d_fwd (dgrad = 0) or dv_conv3d_dgrad (dgrad = 1) will use for this
  * problem: informational (profiling labels, grid size = ceil(M/rows) * ceil(Npitch/cols)) */
 int dv_conv3d_tile_shape(const dv_conv_desc* d, int32_t dgrad, int32_t* rows, int32_t* cols);
+/* informational: the column tile (32 / 64) of the "K split over the waves" kernel when dv_conv3d_fwd (dgrad = 0) / dv_conv3d_dgrad
+ * (1) will run this problem on it (few rows, long K: the 1 152- and 12 544-row levels of S3D-G), else 0 */
+int dv_conv3d_ksplit_cols(const dv_conv_desc* d, int32_t dgrad);
 /* y = conv(x, w) [+bias][act]; with DV_STATS also stats[2][Cout][tiles] = (sum, M2 about the
  * tile mean) of the values as stored.  */
 int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w_fwd, const float* bias,

@@ -45,6 +45,12 @@ def short(name):
         if len(g) == 3:                                             # garbled bf16 dgrad form
             g = ('1',) + g
         return 'conv_gemm<%s,%s,%s,%s,%s>' % (_dt(n), 'DGRAD' if g[0] == '1' else 'FWD', g[1], g[2], g[3])
+    m = re.search(r'conv_gemm_ks_kernelILi(\d)ELi(\d+)E', n) or re.search(r'conv_gemm_ks_kernel<(\d), (\d+)', n)
+    if m:
+        return 'conv_gemm_ks<f32,%s,64,%s>' % ('DGRAD' if m.group(1) == '1' else 'FWD', m.group(2))
+    m = re.search(r'conv_wgrad_f32s_kernelILi(\d+)ELi(\d+)E', n) or re.search(r'conv_wgrad_f32s_kernel<(\d+), (\d+)', n)
+    if m:
+        return 'conv_wgrad<f32,16,%s,%s>' % (m.group(1), m.group(2))
     for key, pat in (('bn_bwd_reduce_multi', r'bn_bwd_reduce_multi'), ('bn_bwd_apply_multi', r'bn_bwd_apply_multi'),
                      ('bn_apply_multi', r'bn_apply_multi'), ('bn_bwd_reduce', r'bn_bwd_reduce_kernel'),
                      ('bn_bwd_apply', r'bn_bwd_apply_kernel'), ('bn_apply_maxpool', r'bn_apply_maxpool'), ('bn_apply', r'bn_apply_kernel'),
