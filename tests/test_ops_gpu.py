@@ -14,6 +14,8 @@ from dualvar_amd import ops  # noqa: E402
 from dualvar_amd.ops import DV_BF16, DV_F32  # noqa: E402
 
 TOL = {DV_F32: 2e-5, DV_BF16: 1.5e-2}
+from dualvar_amd import _lib as _L  # noqa: E402
+_EXACT = _L.f32_exact()          # A/B runs of the whole suite on the exact-f32 MFMA kernels
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -142,7 +144,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, dtype, case):
     close(local[Cout:2 * Cout] / M, var_ref, DV_F32, name + ' var', factor=20)
     assert float(local[2 * Cout]) == M
 
-    if dtype == DV_F32:
+    if dtype == DV_F32 and not _EXACT:          # (DUALVAR_F32_EXACT=1: the exact-f32 kernels take no pre-split weights)
         # the same forward with the weights handed over pre-split in fragment order (DV_W3, dv_pack_w3): the engine's fp32 path
         from dualvar_amd._lib import DV_W3
         wide3 = ops.new_act(N, To, Ho, Wo, ops.cp8(Cout) + 16, dtype, gpu, zero=True)
@@ -178,7 +180,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, dtype, case):
         d3 = ops.conv_desc(dtype, xa, dya, k, s, p, flags=ops.DV_ACCUM)
         ops.conv_dgrad(d3, dya, wd, dxa)
         close(ops.act_to_ncdhw(dxa), 2 * xr.grad, dtype, name + ' dgrad accum', factor=2)
-        if dtype == DV_F32 and max(s) == 1:
+        if dtype == DV_F32 and max(s) == 1 and not _EXACT:
             from dualvar_amd._lib import DV_W3
             dx3 = ops.new_act(N, T, H, W, Cin, dtype, gpu, zero=True)
             ops.conv_dgrad(ops.conv_desc(dtype, xa, dya, k, s, p, flags=DV_W3), dya, ops.pack_w3(wd.view(Cin, -1)), dx3)
@@ -1148,6 +1150,8 @@ def test_fp32_conv_at_headline_tile_sizes_against_cpu_conv3d(gpu, case):
     from dualvar_amd._lib import DV_W3
     import ctypes as C
     from dualvar_amd import _lib as L
+    if _EXACT:
+        pytest.skip('the pre-split-weight instantiations do not exist under DUALVAR_F32_EXACT=1')
     name, N, Cin, T, H, W, Cout, k, s, p = case
     x = rnd(N, Cin, T, H, W, seed=1).relu_()
     w = rnd(Cout, Cin, *k, seed=2, scale=(Cin * k[0] * k[1] * k[2]) ** -0.5)
