@@ -58,6 +58,10 @@ CONV_CASES = [
     ('full3_t1_h1', 4, 48, 1, 1, 5, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     # the pixel-pair stem's geometry: 8 channels (= half a K tile of 16 f32), even kernel width, padding-free, stride (1, 2, 1):
     # (generic gather: a K tile spans two taps)
+    # the few-row K-split kernel (conv_gemm_ks): its 64-column form (more than 256 tiles of 32 columns), and together with a
+    # trimmed window (Mixed_5c's 3x1x1 on one-frame maps: weights addressed at the live tap)
+    ('ks64', 4, 64, 4, 20, 20, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('tm3_t1_ks', 4, 384, 1, 3, 3, 384, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
     ('pair_stem', 2, 8, 4, 20, 22, 64, (1, 7, 4), (1, 2, 1), (0, 0, 0)),
     ('pair_stem_t', 1, 8, 9, 12, 10, 64, (5, 7, 4), (2, 2, 1), (2, 0, 0)),
 ]
@@ -150,6 +154,10 @@ def test_conv_fwd_dgrad_wgrad(gpu, dtype, case):
         wide3 = ops.new_act(N, To, Ho, Wo, ops.cp8(Cout) + 16, dtype, gpu, zero=True)
         y3 = wide3.slice(8, Cout)
         d3 = ops.conv_desc(dtype, xa, y3, k, s, p, flags=ops.DV_STATS | DV_W3)
+        if name in ('ks64', 'tm3_t1_ks', 'big_n', 'sp3'):
+            import ctypes as C
+            want = 64 if name == 'ks64' else 32
+            assert _L.load().dv_conv3d_ksplit_cols(C.byref(d3), 0) == want, name
         stats3 = torch.zeros(2, Cout, tiles, device=gpu)
         ops.conv_fwd(d3, xa, ops.pack_w3(wp.view(Cout, -1)), None, y3, stats3)
         torch.cuda.synchronize()
