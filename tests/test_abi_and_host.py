@@ -401,3 +401,42 @@ def test_worker_side_augmentation_rows_equal_the_in_line_build():
     got = FrameBatch(fr.view(-1, 128, 171, 3), batch['aug'].view(-1), (4, 2, 3, 8, 112, 112),
                      blur=batch['blur'].view(-1) if batch['has_blur'] else None)
     assert tuple(got.shape) == tuple(ref.shape)
+
+
+def test_kernel_choice_queries_on_the_host():
+    """dv_conv3d_ksplit_cols / dv_conv3d_tile_shape are pure host logic: the few-row layers of S3D-G at the headline batch
+    (128 clips of 8x112x112: Mixed_5 = 1 152 rows, Mixed_4 = 12 544 rows) go to the K-split kernel when K is long, the big layers
+    do not, and neither do the cases the kernel does not implement (bf16, no pre-split weights, strided, short K)."""
+    import ctypes as C
+    from dualvar_amd import _lib as L
+    lib = L.load()
+
+    def desc(N, T, H, W, Cin, Cout, k, s=(1, 1, 1), p=None, dtype=L.DV_F32, flags=L.DV_W3):
+        p = p if p is not None else tuple(kk // 2 for kk in k)
+        d = L.ConvDesc()
+        d.dtype, d.N, d.Ti, d.Hi, d.Wi, d.Cin = dtype, N, T, H, W, Cin
+        d.To, d.Ho, d.Wo = [(i + 2 * pp - kk) // ss + 1 for i, kk, ss, pp in zip((T, H, W), k, s, p)]
+        d.Cout = Cout
+        d.kt, d.kh, d.kw = k
+        d.st, d.sh, d.sw = s
+        d.pt, d.ph, d.pw = p
+        d.cin_pitch, d.cout_pitch = (Cin + 7) & ~7, (Cout + 7) & ~7
+        d.ldx, d.ldy, d.flags = d.cin_pitch, d.cout_pitch, flags
+        return d
+
+    ks = lambda d, dg=0: lib.dv_conv3d_ksplit_cols(C.byref(d), dg)      # noqa: E731
+    m5 = desc(128, 1, 3, 3, 192, 384, (1, 3, 3))               # Mixed_5c 1x3x3: 1 152 rows, K = 1 728
+    assert ks(m5, 0) == 32 and ks(m5, 1) == 32
+    m5t = desc(128, 1, 3, 3, 384, 384, (3, 1, 1))              # its 3x1x1 on ONE frame: two taps trimmed, K = 384 left
+    assert ks(m5t, 0) == 32
+    m4 = desc(128, 2, 7, 7, 512, 64, (1, 1, 1))                # Mixed_4 entry piece: 12 544 rows, 64 columns -> the 64-column form
+    assert ks(m4, 0) == 64
+    assert ks(desc(128, 2, 7, 7, 160, 320, (1, 3, 3)), 0) == 0      # 12 544 rows x 320 columns: too many tiles for one round
+    assert ks(desc(128, 4, 28, 28, 64, 192, (1, 3, 3)), 0) == 0     # Conv_2c: 401 408 rows
+    assert ks(desc(128, 1, 3, 3, 64, 64, (3, 1, 1)), 0) == 0        # short K (after trimming: 4 tiles)
+    assert ks(desc(128, 1, 3, 3, 192, 384, (1, 3, 3), dtype=L.DV_BF16, flags=0), 0) == 0
+    assert ks(desc(128, 1, 3, 3, 192, 384, (1, 3, 3), flags=0), 0) == 0               # no pre-split weights
+    assert ks(desc(128, 2, 6, 6, 192, 384, (1, 3, 3), s=(1, 2, 2)), 1) == 0            # strided data gradient
+    r, c = C.c_int32(), C.c_int32()
+    assert lib.dv_conv3d_tile_shape(C.byref(desc(128, 4, 28, 28, 64, 192, (1, 3, 3))), 0, C.byref(r), C.byref(c)) == 0
+    assert (r.value, c.value) == (256, 64)
