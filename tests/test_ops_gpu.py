@@ -1223,3 +1223,19 @@ def test_fp32_conv_at_headline_tile_sizes_against_cpu_conv3d(gpu, case):
           'wgrad splits', sp_.value)
     for k_ in got:
         assert got[k_] <= max(4 * cpu[k_], 2e-6), (name, k_, got[k_], cpu[k_])
+
+
+@pytest.mark.parametrize('cfg', [0, 2])
+def test_second_fp32_weight_gradient_form_stays_correct(gpu, cfg):
+    """conv_wgrad_f32s_kernel is opt-in (DUALVAR_WGRAD_F32S, read once per process: DESIGN section 4 explains why it is not the
+    default).  The weight-gradient op tests of this file under it, in a child process: 64 x 256 and 128 x 128 tiles."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DUALVAR_WGRAD_F32S=str(cfg))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k',
+                        'conv_wgrad_row_splits or (conv_fwd_dgrad_wgrad and (sp3 or tm3 or full3 or big_n))'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=500,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0 and ' passed' in tail, tail
