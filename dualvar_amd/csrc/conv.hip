@@ -82,6 +82,7 @@ struct ConvArgs {
   const float* sc_a;     // fp8 GEMMs: device scalars, result = acc * sc_a[0] * sc_b[0] (per-tensor scales of the operands)
   const float* sc_b;
   int src_bytes, w_bytes; // extents for the buffer descriptors (< 2 GiB)
+  int out_bytes;          // extent of the output rows [0, M) from `out` (0: not known to be < 2 GiB -> staged epilogue)
   FastDiv fCP;           // k -> (tap, c)
   ConvGeom g;
   // Strided dgrad, one launch per PARITY CLASS (cls_on): input positions t = t'*cst + cot (same for h, w) only receive
@@ -728,6 +729,48 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
     constexpr int SROWS = (NW * 32 * SP <= (int)sizeof(smem)) ? 32 : 16;   // strip height that fits the tile buffers
     static_assert(NW * SROWS * SP <= (int)sizeof(smem), "staging fits the tile buffers");
     constexpr int RPS = SROWS / 2;                   // accumulator registers per strip (16 cover 32 rows)
+    // fp32 outputs whose rows are the tensor's rows (no parity-class row map): straight from the accumulators.  One register
+    // of a 32x32 block is 32 consecutive floats of a row per half wave (two 128-byte segments per store instruction: full
+    // rate); the row of register r is a wave-uniform offset (soffset: scalar arithmetic only), the lane's part of the address
+    // is fixed per column block, rows >= M fall outside the buffer descriptor and are dropped by the hardware.  No LDS staging,
+    // no barrier, no per-element address arithmetic (what made the per-element form of round 1 slow).
+    bool direct = false;
+    if constexpr (EO == 4) direct = a.out_bytes > 0 && a.cls_on != 1 && a.bn_x == nullptr;
+    if (direct) {
+      const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+      const unsigned ldo4 = (unsigned)a.ldo * 4u;
+      const bool plain32 = !(flags & (DV_BIAS | DV_RELU | DV_SIGMOID));
+      const unsigned rbase = (unsigned)(m0 + wm0 + 4 * h) * ldo4;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + j * 32 + l31;
+        const float bv = ((flags & DV_BIAS) && col < a.N) ? a.bias[col] : 0.f;
+        const unsigned vo = col < a.NP ? rbase + (unsigned)col * 4u : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          unsigned old[16];
+          if (flags & DV_ACCUM) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              old[r] = __builtin_amdgcn_raw_buffer_load_b32(orsrc, (int)vo, (int)((unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo4), 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2);
+            float v = acc[i][j][r];
+            if (!plain32) {
+              v = act_apply(v + bv, flags);
+              if (col >= a.N) v = 0.f;
+            }
+            if (!full_tile && m0 + wm0 + i * 32 + rl + 4 * h >= a.M) v = 0.f;
+            acc[i][j][r] = v;                        // as stored: feeds the two-pass statistics
+            if (flags & DV_ACCUM) v += __builtin_bit_cast(float, old[r]);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, (int)vo, (int)((unsigned)(i * 32 + rl) * ldo4), 0);
+          }
+        }
+      }
+    }
+    if (!direct) {
     __syncthreads();                                 // every wave is done reading the last K tile
     unsigned char* stg = smem + wave * (SROWS * SP);
     const bool plain = EO == 2 && !(flags & (DV_BIAS | DV_RELU | DV_SIGMOID));
@@ -781,6 +824,7 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
         }
       }
     }
+    }   // !direct
     // BatchNorm-backward reduce fused into the data gradient (ConvArgs::bn_x, dv_conv3d_dgrad_bn).  A pass of its own over the
     // tile this workgroup has just written (read back from L2) and the matching tile of the BatchNorm's input: at this point
     // the accumulators are dead, so it costs the kernel no registers -- inside the store loop it took 20-30 VGPRs and a
@@ -2403,6 +2447,10 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
     if (sb >= (1ll << 31) || wb >= (1ll << 31) || d->kt > 32 || d->kh > 32 || d->kw > 32 || d->kt * d->kh * d->kw > 256)
       return DV_EUNSUPPORTED;
     a.src_bytes = (int)sb; a.w_bytes = (int)wb;
+    {
+      const int64_t ob = (((int64_t)a.M - 1) * a.ldo + a.NP) * 4;       // fp32 outputs: direct-store epilogue
+      a.out_bytes = (d->dtype == DV_F32 && ob < (1ll << 31)) ? (int)ob : 0;
+    }
     a.fCP = make_fastdiv((uint32_t)a.g.CP);
   }
   const int gvb = gather_bytes(d->dtype, d->cin_pitch);
@@ -2461,6 +2509,7 @@ extern "C" int dv_conv3d_fwd_fp8(const dv_conv_desc* d, const void* x8, const vo
   const int64_t sb = ((int64_t)a.M - 1) * d->ldx + d->cin_pitch, wb = (int64_t)d->Cout * a.g.Ktot;
   if (sb >= (1ll << 31) || wb >= (1ll << 31)) return DV_EUNSUPPORTED;
   a.src_bytes = (int)sb; a.w_bytes = (int)wb;
+  a.out_bytes = 0;
   a.fCP = make_fastdiv((uint32_t)a.g.CP);
   int bm, bn;
   pick_tile(DV_BF16, a.M, a.NP, bm, bn);
@@ -2486,6 +2535,7 @@ extern "C" int dv_conv3d_dgrad_fp8(const dv_conv_desc* d, const void* dy8, const
   const int64_t sb = ((int64_t)a.M - 1) * d->ldy + d->cout_pitch, wb = (int64_t)d->Cin * a.g.Ktot;
   if (sb >= (1ll << 31) || wb >= (1ll << 31)) return DV_EUNSUPPORTED;
   a.src_bytes = (int)sb; a.w_bytes = (int)wb;
+  a.out_bytes = 0;
   a.fCP = make_fastdiv((uint32_t)a.g.CP);
   int bm, bn;
   pick_tile(DV_BF16, a.M, a.NP, bm, bn);
@@ -2530,6 +2580,10 @@ static int dgrad_impl(const dv_conv_desc* d, const void* dy, const void* wd, voi
     if (sb >= (1ll << 31) || wb >= (1ll << 31) || d->kt > 32 || d->kh > 32 || d->kw > 32 || d->kt * d->kh * d->kw > 256)
       return DV_EUNSUPPORTED;
     a.src_bytes = (int)sb; a.w_bytes = (int)wb;
+    {
+      const int64_t ob = (((int64_t)a.M - 1) * a.ldo + a.NP) * 4;       // fp32 outputs: direct-store epilogue
+      a.out_bytes = (d->dtype == DV_F32 && ob < (1ll << 31)) ? (int)ob : 0;
+    }
     a.fCP = make_fastdiv((uint32_t)a.g.CP);
   }
   hipStream_t s = (hipStream_t)stream;
