@@ -54,6 +54,13 @@ class BnReduce(C.Structure):
                 [(n, C.c_int32) for n in ('ldx', 'n_rep', 'flags', '_pad')])
 
 
+class BnBwd(C.Structure):
+    """dv_bn_bwd: the BatchNorm behind a conv whose input needs no gradient, for dv_conv3d_wgrad_bn"""
+    _fields_ = ([(n, C.c_void_p) for n in ('x', 'mean', 'invstd', 'gamma', 'scale', 'shift', 'sums', 'dgamma', 'dbeta')] +
+                [('inv_count', C.c_float), ('dparam_scale', C.c_float)] +
+                [(n, C.c_int32) for n in ('ldx', 'n_rep', 'flags', '_pad')])
+
+
 class W3Desc(C.Structure):
     _fields_ = [('src_off', C.c_int64), ('dst_off', C.c_int64), ('N', C.c_int32), ('Ktot', C.c_int32)]
 
@@ -83,6 +90,8 @@ SIGNATURES = {
     'dv_conv3d_wgrad_workspace': [CD],
     'dv_conv3d_wgrad_tile': [CD, P, P, P],
     'dv_conv3d_wgrad': [CD, P, P, P, P, I64, P],
+    'dv_conv3d_wgrad_bn_ok': [CD],
+    'dv_conv3d_wgrad_bn': [CD, P, P, P, P, I64, P, P],
     'dv_quantize_fp8_workspace': [],
     'dv_quantize_fp8': [I32, P, I64, I32, I32, I32, P, I32, P, P, P],
     'dv_conv3d_fwd_fp8': [CD, P, P, P, P, P, P, P],

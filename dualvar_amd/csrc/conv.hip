@@ -1422,6 +1422,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 struct WgradDmaArgs {
   WgradArgs w;
   int x_bytes, dy_bytes;
+  // BNA (dv_conv3d_wgrad_bn): the dY operand is formed from g = w.dy and the BatchNorm's input bn_x (same rows / pitch)
+  const void* bn_x;
+  const float *bn_mean, *bn_invstd, *bn_gamma, *bn_scale, *bn_shift, *bn_sums;
+  float *bn_dgamma, *bn_dbeta;
+  float bn_inv_count, bn_dscale;
+  int bn_rep, bn_mask;
 };
 
 // rows of RB bytes: four consecutive rows must fall on four different 64-byte bank groups of the 256-byte LDS line
@@ -1461,11 +1467,16 @@ constexpr int wgrad_waves_per_simd(int es, int bi, int bj, int nw, int ns) {
 // fetched as ds_read_b128); each wave splits only its own 32 columns of x.  Three fragments per wave and step instead of the
 // six of the 2 x 2 layout (where the two waves of a row / column each split the fragments they share): the kernel is bound
 // by the count of exactly those vector instructions.  12 KB of LDS more: still two workgroups per CU.
-template <typename T, int BI, int BJ, int WVI, int WVJ, int NS, bool SPLIT = false, bool SHARE = false>
+// BNA (SHARE only; dv_conv3d_wgrad_bn): the dY tile is dv_bn_bwd_apply's output formed on the fly -- a third DMA tile carries
+// the BatchNorm's input beside dL/dy, and the thread that splits a dY fragment (its column = its channel: k1, k2, k3, scale and
+// shift are per-thread constants) first forms k1*g' + k2*x + k3 with dv_bn_bwd_apply's expression.  8 KB of LDS more per
+// stage; the row tables shrink to 128 rows per round so that two workgroups still fit a CU (80 896 bytes each).
+template <typename T, int BI, int BJ, int WVI, int WVJ, int NS, bool SPLIT = false, bool SHARE = false, bool BNA = false>
 __global__ __launch_bounds__(WVI * WVJ * 64)
 __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI * WVJ, NS)))) void conv_wgrad_dma_kernel(WgradDmaArgs aa) {
   static_assert(!SPLIT || sizeof(T) == 4, "the bf16 split is the fp32 mode's product");
   static_assert(!SHARE || SPLIT, "the shared split belongs to the fp32 split mode");
+  static_assert(!BNA || (SHARE && BI == 64), "the fused BatchNorm backward rides on the shared dY split (one channel per lane)");
   const WgradArgs& a = aa.w;
   constexpr int ES = (int)sizeof(T);
   constexpr int EPV = 16 / ES;                       // elements per 16-byte DMA slot
@@ -1474,10 +1485,10 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
   constexpr int RBP = BI * ES, RBQ = BJ * ES;        // row bytes of the dY (P) and im2col (Q) tiles
   static_assert(RBP % 128 == 0 && RBQ % 128 == 0, "row bytes (swizzle, 1 KiB DMA pieces)");
   constexpr int DP = RBP / 16, DQ = RBQ / 16;        // 16-byte slots per row
-  constexpr int QOFF = ROWS * RBP, BUFB = ROWS * (RBP + RBQ);
-  constexpr int PPC = QOFF / 1024, QPC = (BUFB - QOFF) / 1024;                   // 1 KiB DMA pieces per tile
+  constexpr int QOFF = ROWS * RBP, YOFF = ROWS * (RBP + RBQ), BUFB = YOFF + (BNA ? ROWS * RBP : 0);
+  constexpr int PPC = QOFF / 1024, QPC = (YOFF - QOFF) / 1024;                   // 1 KiB DMA pieces per tile
   constexpr int NPW = (PPC + NW - 1) / NW, NQW = (QPC + NW - 1) / NW;             // ... per wave (the last round may be partial)
-  constexpr int RT = NT;                             // rows per decode round: one row per thread
+  constexpr int RT = BNA ? NT / 2 : NT;              // rows per decode round: one row per thread (BNA: per thread of the first half)
   constexpr int SPR = RT / ROWS;                     // steps per round
   constexpr int WI = BI / WVI, WJ = BJ / WVJ, TI = WI / 32, TJ = WJ / 32;
   static_assert(TI >= 1 && TJ >= 1, "wave tile");
@@ -1504,6 +1515,7 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
   const int m_end = min(a.M, m_begin + a.rows_per_split);      // (the host sizes the splits so that none is empty)
 
   const dma_rsrc_t x_rsrc = dma_make_rsrc(a.x, (unsigned)aa.x_bytes), dy_rsrc = dma_make_rsrc(a.dy, (unsigned)aa.dy_bytes);
+  const dma_rsrc_t bnx_rsrc = dma_make_rsrc(BNA ? aa.bn_x : a.dy, (unsigned)aa.dy_bytes);
   const unsigned smem_base = lds_addr(smem);
   const unsigned ldxb = (unsigned)a.ldx * ES, ldyb = (unsigned)a.ldy * ES;
 
@@ -1537,6 +1549,7 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
 
   // decode RT rows of round `rnd` (one per thread) into rowtab[rnd & 1]
   auto decode = [&](int rnd) {
+    if (RT < NT && tid >= RT) return;
     const int q = m_begin + rnd * RT + tid;          // position in the row sequence
     uint2 e = make_uint2(0u, 0u);
     unsigned dyo = kOOB;
@@ -1567,6 +1580,13 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
       const unsigned off = (dyo[u] != kOOB && pcolb[u] != kOOB) ? dyo[u] + pcolb[u] : kOOB;
       dma_load16(dy_rsrc, smem_base + buf * BUFB + (wave + NW * u) * 1024, off);
     }
+    if constexpr (BNA) {                             // the BatchNorm's input: same rows, same pitch, its own tile
+#pragma unroll
+      for (int u = 0; u < NPW; ++u) {
+        const unsigned off = (dyo[u] != kOOB && pcolb[u] != kOOB) ? dyo[u] + pcolb[u] : kOOB;
+        dma_load16(bnx_rsrc, smem_base + buf * BUFB + YOFF + (wave + NW * u) * 1024, off);
+      }
+    }
     const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(rowtab[(s / SPR) & 1] + (s % SPR) * ROWS);
     unsigned long long e[NQW];
 #pragma unroll
@@ -1582,7 +1602,7 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
   // pieces this wave issues per step (wave-uniform)
   int my_pieces = 0;
 #pragma unroll
-  for (int u = 0; u < NPW; ++u) my_pieces += (wave + NW * u < PPC) ? 1 : 0;
+  for (int u = 0; u < NPW; ++u) my_pieces += (wave + NW * u < PPC) ? (BNA ? 2 : 1) : 0;
 #pragma unroll
   for (int u = 0; u < NQW; ++u) my_pieces += (wave + NW * u < QPC) ? 1 : 0;
 
@@ -1595,6 +1615,23 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int h = lane >> 5, l31 = lane & 31;
+  // BNA: this thread's channel (= its column of the dY tile) and dv_bn_bwd_apply's coefficients for it, same expressions
+  float bk1 = 0.f, bk2 = 0.f, bk3 = 0.f, bsc = 0.f, bsh = 0.f;
+  if constexpr (BNA) {
+    const int c = i0 + lane, cpb = (a.Cout + 7) & ~7;
+    if (c < a.Cout) {
+      float sg = 0.f, sgx = 0.f;
+      for (int r = 0; r < aa.bn_rep; ++r) { sg += aa.bn_sums[(size_t)r * 2 * cpb + c]; sgx += aa.bn_sums[(size_t)r * 2 * cpb + cpb + c]; }
+      bk1 = aa.bn_gamma[c] * aa.bn_invstd[c];
+      bk2 = -bk1 * aa.bn_invstd[c] * sgx * aa.bn_inv_count;
+      bk3 = -bk1 * sg * aa.bn_inv_count - bk2 * aa.bn_mean[c];
+      if (aa.bn_mask) { bsc = aa.bn_scale[c]; bsh = aa.bn_shift[c]; }
+      if (split == 0 && tile_j == 0 && wave == 0 && aa.bn_dgamma) {       // one workgroup per channel tile: dgamma, dbeta
+        aa.bn_dbeta[c] += aa.bn_dscale * sg;
+        aa.bn_dgamma[c] += aa.bn_dscale * sgx;
+      }
+    }
+  }
   const int nsteps = (m_end - m_begin + ROWS - 1) / ROWS;
   constexpr int D = NS - 1;                          // prefetch distance (the row table runs one round = SPR steps ahead)
   static_assert(D >= 1 && D < SPR, "stages");
@@ -1629,10 +1666,22 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
       // rows of a column, 16-byte writes of the three planes
       {
         const int kh = wave, col = lane;
-        const unsigned char* src = tp + ((kh >> 1) * 16 + 8 * (kh & 1)) * RBP + col * 4;
+        const int rr0 = (kh >> 1) * 16 + 8 * (kh & 1);
+        const unsigned char* src = tp + rr0 * RBP + col * 4;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(src + e * RBP);
+        if constexpr (BNA) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            // (rows past the end of the split need no special case: their im2col rows are zero-filled too, so whatever this forms
+            // for them -- k3 -- is multiplied by zeros)
+            const float xv = *reinterpret_cast<const float*>(src + YOFF + e * RBP);
+            const float act = xv * bsc + bsh;              // the forward's expression (dv_bn_apply), same rounding
+            const float gg = (aa.bn_mask && !(act > 0.f)) ? 0.f : v[e];
+            v[e] = bk1 * gg + bk2 * xv + bk3;              // dv_bn_bwd_apply's expression
+          }
+        }
         const Split3 s3 = split3w(v);
         uint4* dst = planes + kh * 3 * BI + col;
         dst[0] = __builtin_bit_cast(uint4, s3.hi);
@@ -2761,13 +2810,30 @@ extern "C" int64_t dv_conv3d_wgrad_workspace(const dv_conv_desc* d) {
   return p.splits > 1 ? (int64_t)p.splits * p.slab_stride * 4 : 0;
 }
 
-extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace,
-                               int64_t workspace_bytes, void* stream) {
+// the plan runs on conv_wgrad_dma_kernel<float, 64, 128, 1, 4, 2, true, true>, the form that can carry dv_conv3d_wgrad_bn
+static bool wgrad_plan_is_share(const dv_conv_desc* d, const WgradPlan& p) {
+  return p.dma && d->dtype == DV_F32 && !f32_exact() && p.f32s < 0 && p.cfg == 1;
+}
+extern "C" int dv_conv3d_wgrad_bn_ok(const dv_conv_desc* d) {
+  if (!d || check_desc(d)) return 0;
+  return wgrad_plan_is_share(d, plan_wgrad(d)) ? 1 : 0;
+}
+
+static int wgrad_impl(const dv_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace,
+                      int64_t workspace_bytes, const dv_bn_bwd* bn, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!x || !dy || !dw) return DV_EINVAL;
   if (!aligned16(dy) || !aligned16(dw) || (reinterpret_cast<uintptr_t>(x) & 7)) return DV_EALIGN;
   const WgradPlan p = plan_wgrad(d);
+  if (bn) {
+    if (!bn->x || !bn->mean || !bn->invstd || !bn->gamma || !bn->sums || bn->n_rep <= 0) return DV_EINVAL;
+    if ((bn->dgamma == nullptr) != (bn->dbeta == nullptr)) return DV_EINVAL;
+    if (!(bn->flags & DV_NO_RELU_MASK) && (!bn->scale || !bn->shift)) return DV_EINVAL;
+    if (bn->ldx != d->ldy) return DV_EINVAL;
+    if (!aligned16(bn->x)) return DV_EALIGN;
+    if (!wgrad_plan_is_share(d, p)) return DV_EUNSUPPORTED;
+  }
   const int64_t need = p.splits > 1 ? (int64_t)p.splits * p.slab_stride * 4 : 0;
   if (need && (!workspace || workspace_bytes < need)) return DV_EINVAL;
   if (need && !aligned16(workspace)) return DV_EALIGN;
@@ -2792,6 +2858,13 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
     aa.w = a;
     aa.x_bytes = (int)(((int64_t)d->N * d->Ti * d->Hi * d->Wi - 1) * d->ldx * es + (int64_t)d->cin_pitch * es);
     aa.dy_bytes = (int)(((int64_t)a.M - 1) * d->ldy * es + (int64_t)d->cout_pitch * es);
+    aa.bn_x = nullptr;
+    if (bn) {
+      aa.bn_x = bn->x; aa.bn_mean = bn->mean; aa.bn_invstd = bn->invstd; aa.bn_gamma = bn->gamma; aa.bn_scale = bn->scale;
+      aa.bn_shift = bn->shift; aa.bn_sums = bn->sums; aa.bn_dgamma = bn->dgamma; aa.bn_dbeta = bn->dbeta;
+      aa.bn_inv_count = bn->inv_count; aa.bn_dscale = bn->dparam_scale; aa.bn_rep = bn->n_rep;
+      aa.bn_mask = (bn->flags & DV_NO_RELU_MASK) ? 0 : 1;
+    }
 #define WGD(T_, BI_, BJ_, WI_, WJ_, NS_, ...) \
   hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, BI_, BJ_, WI_, WJ_, NS_, ##__VA_ARGS__>), dim3(grid), dim3(WI_ * WJ_ * 64), 0, s, aa)
 #define WGS(BI_, BJ_, R_, NS_) \
@@ -2817,7 +2890,8 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
         if (p.cfg == 1) WGD(float, 64, 128, 2, 2, 2);
         else WGD(float, 128, 128, 2, 2, 2);
       } else {
-        if (p.cfg == 1) WGD(float, 64, 128, 1, 4, 2, true, true);
+        if (bn) WGD(float, 64, 128, 1, 4, 2, true, true, true);
+        else if (p.cfg == 1) WGD(float, 64, 128, 1, 4, 2, true, true);
         else WGD(float, 128, 128, 2, 2, 2, true);
       }
     }
@@ -2840,4 +2914,15 @@ extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void*
                        p.splits, dw, n4);
   }
   return dv_launch_status();
+}
+
+extern "C" int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+  return wgrad_impl(d, x, dy, dw, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int dv_conv3d_wgrad_bn(const dv_conv_desc* d, const void* x, const void* g, float* dw, void* workspace,
+                                  int64_t workspace_bytes, const dv_bn_bwd* bn, void* stream) {
+  if (!bn) return DV_EINVAL;
+  return wgrad_impl(d, x, g, dw, workspace, workspace_bytes, bn, stream);
 }

@@ -296,7 +296,7 @@ __device__ __forceinline__ void column_reduce(int64_t r_begin, int64_t r_end, in
       for (int e = 0; e < V; ++e) acc[s][e] = 0.f;
     if (my_rg < rg) {
       pre((cvb + my_cv) * V);                       // per-thread constants of this channel vector
-#pragma unroll 2
+#pragma unroll 4
       for (int64_t r = r_begin + my_rg; r < r_end; r += rg) f(r, (cvb + my_cv) * V, acc);
     }
     __syncthreads();
@@ -373,19 +373,20 @@ __device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)
 
 __device__ __forceinline__ void fold_rows(const float* __restrict__ rows, int n, int NO, int C, int CP, float* __restrict__ dst,
                                           bool coherent_dst) {
+  // all the loads of a batch are in flight together (one trip to the coherence point per kFoldBatch rows, not per row); a
+  // short batch re-reads its last row and adds nothing for it, so the order of the additions is the row order
+  constexpr int kFoldBatch = 32;
   for (int i = threadIdx.x; i < NO; i += blockDim.x) {
     const int c = i < CP ? i : i - CP;
     float t = 0.f;
     if (c < C) {
-      int b = 0;
-      for (; b + 8 <= n; b += 8) {
-        float v[8];
+      for (int b = 0; b < n; b += kFoldBatch) {
+        float v[kFoldBatch];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = coherent_load(rows + (size_t)(b + u) * NO + i);
+        for (int u = 0; u < kFoldBatch; ++u) v[u] = coherent_load(rows + (size_t)min(b + u, n - 1) * NO + i);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t += v[u];
+        for (int u = 0; u < kFoldBatch; ++u) t += (b + u < n) ? v[u] : 0.f;
       }
-      for (; b < n; ++b) t += coherent_load(rows + (size_t)b * NO + i);
     }
     if (coherent_dst) coherent_store(dst + i, t);
     else dst[i] = t;
@@ -394,8 +395,9 @@ __device__ __forceinline__ void fold_rows(const float* __restrict__ rows, int n,
 __device__ __forceinline__ void ordered_fold(float* __restrict__ ws, uint32_t bid, uint32_t nblk, int C, int CP, float* __restrict__ out) {
   __shared__ uint32_t last;
   const int NO = 2 * CP;
-  const uint32_t ngrp = (nblk + kFoldGroup - 1) / kFoldGroup, grp = bid / kFoldGroup;
-  const uint32_t gsize = min((uint32_t)kFoldGroup, nblk - grp * kFoldGroup);
+  constexpr uint32_t gfold = kFoldGroup;
+  const uint32_t ngrp = (nblk + gfold - 1) / gfold, grp = bid / gfold;
+  const uint32_t gsize = min(gfold, nblk - grp * gfold);
   float* grows = ws + (size_t)nblk * NO;
   uint32_t* tick = reinterpret_cast<uint32_t*>(grows + (size_t)ngrp * NO);
   stores_done();                                     // this block's row has reached the coherence point ...
@@ -403,7 +405,12 @@ __device__ __forceinline__ void ordered_fold(float* __restrict__ ws, uint32_t bi
   if (threadIdx.x == 0) last = (atomicAdd(tick + grp, 1u) == gsize - 1) ? 1u : 0u;       // ... before its ticket is taken
   __syncthreads();
   if (!last) return;
-  fold_rows(ws + (size_t)grp * kFoldGroup * NO, (int)gsize, NO, C, CP, grows + (size_t)grp * NO, true);
+  if (ngrp == 1) {                                   // one group: its last block writes the result (0 + the group row: same bits)
+    fold_rows(ws, (int)gsize, NO, C, CP, out, false);
+    if (threadIdx.x == 0) __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  fold_rows(ws + (size_t)grp * gfold * NO, (int)gsize, NO, C, CP, grows + (size_t)grp * NO, true);
   if (threadIdx.x == 0) __hip_atomic_store(tick + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   stores_done();
   __syncthreads();

@@ -45,6 +45,10 @@ FUSE_BN_POOL = True
 # 1.36 -> 0.66 / 1.07 -> 0.55 ms per step, but the data gradients that carry them grow by 0.62 / 0.52 ms (a serial tail per
 # workgroup that re-reads its tile and the BatchNorm input), and they sit on the critical path: 20.47 -> 20.77 / 9.79 -> 9.98 ms.
 FUSE_BN_REDUCE = False        # (module switch, no environment variable: tests/test_models_gpu.py monkeypatches it)
+# BatchNorm-backward APPLY inside the weight gradient of a conv whose input needs no gradient (the first conv of a network:
+# dL/d(conv output) has that weight gradient as its only reader): dv_conv3d_wgrad_bn forms it on the fly from dL/dy and the
+# conv output -- one read of each instead of read + read + write (apply) + read (wgrad).  fp32 split mode only.
+FUSE_BN_WGRAD = os.environ.get('DUALVAR_FUSE_BN_WGRAD', '1') != '0'      # (A/B switch; tests monkeypatch the module attribute)
 
 
 class Slot:
@@ -613,6 +617,20 @@ class Plan:
                             or a.rows != y.rows or cop.bn_fuse is not None):
                         continue
                     cop.bn_fuse, m.reduce_fused = m, True
+        if self.with_grad and self.training and FUSE_BN_WGRAD and self.dtype == DV_F32:
+            for op in self.ops:
+                if not isinstance(op, BNGroupOp) or len(op.members) != 1:
+                    continue
+                m = op.members[0]
+                cop = m.conv
+                if (not isinstance(cop, ConvOp) or cop.need_dx or cop.fp8 or cop.bn_apply is not None or m.res is not None
+                        or (m.relu and not m.mask_from_x) or m.x.buf is not cop.y.buf or m.x.off != cop.y.off
+                        or m.x.C != cop.y.C or m.x.grad is None or m.y.grad is None or m.x.ld != m.y.grad.ld):
+                    continue
+                d = ops.conv_desc(cop.dtype, cop.x, cop.y, cop.k, cop.s, cop.p, flags=0)
+                if d.ldy != m.y.grad.ld or not self.lib.dv_conv3d_wgrad_bn_ok(C.byref(d)):
+                    continue
+                cop.bn_apply, m.apply_fused = m, True
         # scratch of the deterministic weight gradients (row-split partial tiles): ONE buffer per plan, sized for the
         # largest layer -- the plan's weight gradients all run on one stream (the side stream), each followed by its
         # reduce, so they can share it
@@ -790,6 +808,7 @@ class ConvOp(Op):
         self.alg_k = None
         self.zero_pad_taps = None
         self.bn_fuse = None          # BNMember whose backward reduce this conv's data gradient carries (Plan.finalize)
+        self.bn_apply = None         # BNMember (of this conv's output) whose backward apply this conv's weight gradient carries
 
     def grad_targets(self):
         return [('x', self.x)] if self.need_dx else []
@@ -820,11 +839,26 @@ class ConvOp(Op):
             L.check(lib.dv_conv3d_wgrad_tile(C.byref(self.d_w), C.byref(tr), C.byref(tc), C.byref(tsp)), 'dv_conv3d_wgrad_tile')
             tile = '%d,%d' % (tr.value, tc.value)
             ws = p.wgrad_ws
-            b.append(Launch('conv_wgrad', 'conv_wgrad<%s,%d,%s>' % (_dt(self.dtype), gv, tile), lib.dv_conv3d_wgrad,
-                            (C.byref(self.d_w), x.ptr, y.grad.ptr, st.w_grad(sl), ws.data_ptr() if ws is not None else 0,
-                             ws.numel() if ws is not None else 0),
-                            _abytes(x) + _abytes(y) + sl.Cout * kdim * 4, flops, shp))
-            b[-1].gend = sl.off + sl.size
+            if self.bn_apply is not None:
+                m = self.bn_apply
+                gs, bs = st.slot(m.bn.weight), st.slot(m.bn.bias)
+                r = self._bn_bwd = L.BnBwd()
+                r.x, r.ldx = y.ptr, y.ld
+                r.mean, r.invstd, r.scale, r.shift = (t.data_ptr() for t in (m.mean, m.invstd, m.scale, m.shift))
+                r.gamma, r.dgamma, r.dbeta = st.w_master(gs), st.w_grad(gs), st.w_grad(bs)
+                r.sums, r.n_rep, r.flags = p.zero_ptr(m.sums_off), BN_REPLICAS, (0 if m.relu else DV_NO_RELU_MASK)
+                r.inv_count, r.dparam_scale = 1.0 / (m.M * p.comm.world), 1.0 / p.comm.world
+                b.append(Launch('conv_wgrad', 'conv_wgrad<%s,%d,%s>+bn_bwd_apply' % (_dt(self.dtype), gv, tile), lib.dv_conv3d_wgrad_bn,
+                                (C.byref(self.d_w), x.ptr, m.y.grad.ptr, st.w_grad(sl), ws.data_ptr() if ws is not None else 0,
+                                 ws.numel() if ws is not None else 0, C.byref(r)),
+                                _abytes(x) + 2 * _abytes(y) + sl.Cout * kdim * 4, flops, shp + ' +bn_bwd_apply'))
+                b[-1].gend = max(sl.off + sl.size, _gend(gs, bs))
+            else:
+                b.append(Launch('conv_wgrad', 'conv_wgrad<%s,%d,%s>' % (_dt(self.dtype), gv, tile), lib.dv_conv3d_wgrad,
+                                (C.byref(self.d_w), x.ptr, y.grad.ptr, st.w_grad(sl), ws.data_ptr() if ws is not None else 0,
+                                 ws.numel() if ws is not None else 0),
+                                _abytes(x) + _abytes(y) + sl.Cout * kdim * 4, flops, shp))
+                b[-1].gend = sl.off + sl.size
             if self.zero_pad_taps is not None:
                 rows, pitch, c0, nc = self.zero_pad_taps
                 b.append(Launch('stem_pad_taps', 'fill_cols', lib.dv_fill_cols_f32, (st.w_grad(sl), rows, pitch, c0, nc, 0.0)))
@@ -915,6 +949,7 @@ class BNMember:
         self.conv_bias = None        # Plan.bn(conv_bias=...)
         self.fused_pool = None       # the PoolOp that consumes y on the fly (Plan.maxpool(sole_consumer=True))
         self.reduce_fused = False    # the backward reduce runs in the epilogue of the consuming conv's data gradient
+        self.apply_fused = False     # the backward apply runs inside the producing conv's weight gradient (dv_conv3d_wgrad_bn)
         self.mask_from_x = bool(relu) and residual is None
         self.sums_off = plan.reserve_zero(BN_REPLICAS * 2 * self.CP) if plan.with_grad else 0
         self.sums_len = BN_REPLICAS * 2 * self.CP
@@ -983,7 +1018,7 @@ class BNGroupOp(Op):
                 it.inv_count, it.dparam_scale = 1.0 / (m.M * R), 1.0 / R
                 it.bwd_flags = mflag | (DV_ACCUM if (dres is not None and self.acc.get('res%d' % i)) else 0)
                 ends[2] += 0 if m.reduce_fused else lib.dv_bn_bwd_blocks(m.M, m.C)
-                ends[3] += max(1, min(2048, (total + 255) // 256))
+                ends[3] += 0 if m.apply_fused else max(1, min(2048, (total + 255) // 256))
                 it.blk_red, it.blk_bapply = ends[2], ends[3]
         self._items = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(p.device)
         p.bytes += self._items.numel()
@@ -1003,8 +1038,9 @@ class BNGroupOp(Op):
             b_red = [Launch('bn_bwd_reduce_multi', 'bn_bwd_reduce_multi<%s>' % dt, lib.dv_bn_bwd_reduce_multi,
                             (p.dtype, tab, n, ends[2]), tot(b_red, 'bytes'))] if ends[2] else []
             b_app = [Launch('bn_bwd_apply_multi', 'bn_bwd_apply_multi<%s>' % dt, lib.dv_bn_bwd_apply_multi,
-                            (p.dtype, tab, n, ends[3], max(m.C for m in self.members)), tot(b_app, 'bytes'))]
-            b_app[0].gend = _gend(*[st.slot(t) for m in self.members for t in (m.bn.weight, m.bn.bias)])
+                            (p.dtype, tab, n, ends[3], max(m.C for m in self.members)), tot(b_app, 'bytes'))] if ends[3] else []
+            if b_app:
+                b_app[0].gend = _gend(*[st.slot(t) for m in self.members for t in (m.bn.weight, m.bn.bias)])
         return f_red, f_app, b_red, b_app
 
     def _eval_launches(self):
@@ -1076,6 +1112,8 @@ class BNGroupOp(Op):
                 dres = res.grad if (res is not None and res.grad is not None) else None
                 bflags = mflag | (DV_ACCUM if (dres is not None and self.acc.get('res%d' % i)) else 0)
                 nres = 0 if dres is None else (2 if bflags & DV_ACCUM else 1)
+                if m.apply_fused:
+                    continue
                 b_app.append(Launch('bn_bwd_apply', 'bn_bwd_apply<%s>' % dt, lib.dv_bn_bwd_apply,
                                     (p.dtype, dy.ptr, dy.ld, y.ptr, y.ld, x.ptr, x.ld, m.mean.data_ptr(), m.invstd.data_ptr(),
                                      st.w_master(gs), sums, BN_REPLICAS, 1.0 / (M * R), 1.0 / R, st.w_grad(gs), st.w_grad(bs),

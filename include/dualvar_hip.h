@@ -35,7 +35,8 @@ extern "C" {
 /* Bumped on every incompatible change of a signature or struct below; dv_abi_version() returns the value the library was
    built with and a consumer must refuse a library whose value differs from the header it was compiled against.
    2: dv_conv3d_wgrad (workspace, workspace_bytes), dv_bn_bwd_reduce (ws), dv_infonce_fwd (workspace, bytes),
-      dv_augment_ingest (blur, blur_scratch) gained arguments; dv_bn_item grew by red_ws (round 2 of this build). */
+      dv_augment_ingest (blur, blur_scratch) gained arguments; dv_bn_item grew by red_ws (round 2 of this build).
+   (dv_conv3d_ksplit_cols, dv_conv3d_wgrad_bn, dv_conv3d_wgrad_bn_ok were ADDED under version 2: additions do not bump it.) */
 #define DV_ABI_VERSION 2
 
 enum { DV_F32 = 0, DV_BF16 = 1 };
@@ -133,6 +134,30 @@ int64_t dv_conv3d_wgrad_workspace(const dv_conv_desc* d);
 int dv_conv3d_wgrad_tile(const dv_conv_desc* d, int32_t* rows, int32_t* cols, int32_t* splits);
 int dv_conv3d_wgrad(const dv_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace,
                     int64_t workspace_bytes, void* stream);
+/* The same weight gradient for a conv whose output feeds y = [relu](BatchNorm(conv)) and whose INPUT needs no gradient (the
+ * first conv of a network: backbone/s3dg.py:151 conv1 on the clip): then dL/d(conv output) -- what dv_bn_bwd_apply would
+ * write -- has this launch as its only reader, and it is formed on the fly instead: `g` is dL/dy (the BatchNorm's incoming
+ * gradient), bn->x the conv's forward output (same dims and pitch as g), and the kernel multiplies
+ *   k1*g' + k2*x + k3,   g' = g masked by (x*scale + shift > 0),   k1..k3 from the GLOBAL sums as in dv_bn_bwd_apply
+ * with dv_bn_bwd_apply's own expression (bit-identical operand, bit-identical dw), and adds dgamma / dbeta.  One read of g and
+ * x instead of a read of both, a write of dx and a read of dx.  fp32 split mode only (dv_conv3d_wgrad_bn_ok says whether
+ * this problem runs on the kernel that carries it; otherwise DV_EUNSUPPORTED: call dv_bn_bwd_apply + dv_conv3d_wgrad). */
+typedef struct dv_bn_bwd {
+  const void* x;                 /* BatchNorm input = conv output, [M][ldx], d->dtype; ldx must equal d->ldy */
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* scale;            /* gamma*invstd, beta - mean*scale: the forward's affine map (ReLU mask) */
+  const float* shift;
+  const float* sums;             /* [n_rep][2][cp8(Cout)]: dv_bn_bwd_reduce's result (all-reduced over the ranks) */
+  float* dgamma;                 /* += dparam_scale * sum g*xhat (NULL: skip both) */
+  float* dbeta;
+  float inv_count, dparam_scale; /* 1 / (rows over all ranks), 1 / ranks */
+  int32_t ldx, n_rep, flags, _pad; /* flags: DV_NO_RELU_MASK */
+} dv_bn_bwd;
+int dv_conv3d_wgrad_bn_ok(const dv_conv_desc* d);
+int dv_conv3d_wgrad_bn(const dv_conv_desc* d, const void* x, const void* g, float* dw, void* workspace,
+                       int64_t workspace_bytes, const dv_bn_bwd* bn, void* stream);
 
 /* ---- fp8 pointwise path (BASELINE configs[4]: "fp8 MFMA pointwise convs" of the 2D3D-ResNet-50 bottlenecks,
  * resnet_2d3d.py:130,167,173).  A 1x1x1 stride-1 conv is the GEMM Y[M, Cout] = X[M, Cin] W[Cout, Cin]^T; with OCP fp8

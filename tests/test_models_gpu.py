@@ -690,6 +690,35 @@ def test_fused_bn_reduce_plan_gives_the_same_gradients(gpu, monkeypatch, net, dt
     assert err <= tol, (err, tol)
 
 
+@pytest.mark.parametrize('net', ['s3dg', 'r21d', 'r3d'])
+def test_first_conv_weight_gradient_carrying_the_batchnorm_backward_gives_the_same_bits(gpu, monkeypatch, net):
+    """engine.FUSE_BN_WGRAD: the first conv's input needs no gradient, so dL/d(conv output) -- the BatchNorm backward's dx --
+    has the conv's weight gradient as its only reader and dv_conv3d_wgrad_bn forms it on the fly (same expression as
+    dv_bn_bwd_apply): every gradient of the step must be bit-identical to the two-launch plan's, twice in a row."""
+    from dualvar_amd import engine, model as M
+    from dualvar_amd import _lib
+    if _lib.f32_exact():
+        pytest.skip('the fused form rides on the split-mode kernel')
+    block = torch.randn(4, 2, 3, 8, 64, 64, generator=torch.Generator().manual_seed(3)).to(gpu)
+    grads, fused = [], []
+    for on in (False, True, True):
+        monkeypatch.setattr(engine, 'FUSE_BN_WGRAD', on)
+        torch.manual_seed(0)
+        m = M.SimCLR_Naked(net, 128, 0.07, False)
+        m.set_compute_dtype('fp32').train().to(gpu)
+        ret = m(block)
+        for st in m.stores():
+            st.zero_grad()
+        ret['clip_contrast_loss'].backward()
+        torch.cuda.synchronize()
+        grads.append(torch.cat([st.grad.detach().float().flatten().clone() for st in m.stores()]))
+        plans = [pl for lst in m.encoder_q[0]._plans.values() for pl in lst]
+        fused.append(sum(1 for pl in plans for op in pl.ops if getattr(op, 'bn_apply', None) is not None))
+    assert fused[0] == 0 and fused[1] == fused[2] and fused[1] == (1 if net == 's3dg' else fused[1]), fused      # (only where the first conv's weight gradient runs on the kernel that carries it)
+    assert torch.equal(grads[1], grads[2]), float((grads[1] - grads[2]).abs().max())
+    assert torch.equal(grads[0], grads[1]), float((grads[0] - grads[1]).abs().max())
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # run-to-run reproducibility: no float atomics left on the training path (weight gradients: row-split slabs; BatchNorm
 # backward sums and MoCo's K-split dq: per-block partials folded in block order by the last block; gating / pooling
