@@ -33,7 +33,9 @@ def short(name):
     n = name
     m = re.search(r'conv_wgrad_dma_kernelI(?:DF16b|f)Li(\d+)ELi(\d+)E', n) or re.search(r'conv_wgrad_dma_kernel<[^,]+, (\d+), (\d+)', n)
     if m:
-        return 'conv_wgrad<%s,16,%s,%s>' % (_dt(n), m.group(1), m.group(2))
+        # the form that carries the BatchNorm backward's apply (dv_conv3d_wgrad_bn) is a family of its own
+        bna = re.search(r'conv_wgrad_dma_kernelI\S*Lb1ELb1ELb1EE', n) or re.search(r'conv_wgrad_dma_kernel<[^>]*true, true, true>', n)
+        return 'conv_wgrad<%s,16,%s,%s>%s' % (_dt(n), m.group(1), m.group(2), '+bn_bwd_apply' if bna else '')
     m = re.search(r'conv_wgrad_kernelI(?:DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)E', n) or re.search(r'conv_wgrad_kernel<[^,]+, (\d+), (\d+), (\d+)', n)
     if m:
         return 'conv_wgrad<%s,%s,%s,%s>' % ((_dt(n),) + m.groups())
