@@ -59,6 +59,7 @@ def main():
     ap.add_argument('--no-stats', action='store_true', help='forward without the fused BatchNorm partials')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--w3', action='store_true', help='fp32: weights pre-split in fragment order (DV_W3), as the engine runs them')
+    ap.add_argument('--data', default='relu', choices=['relu', 'normal', 'zeros'], help='activation values (power, hence clocks, depend on them)')
     args = ap.parse_args()
     L.require_device()
     dev = torch.device('cuda:0')
@@ -69,11 +70,17 @@ def main():
     for name in names:
         N, T, H, W, Ci, Co, k, s, p = LAYERS[name]
         x = ops.new_act(N, T, H, W, Ci, DT, dev)
-        x.buf.normal_().relu_()                 # post-ReLU activations: half zeros, as inside the real step (clocks depend on it)
+        x.buf.normal_()                         # post-ReLU activations: half zeros, as inside the real step (clocks depend on it)
+        if args.data == 'relu':
+            x.buf.relu_()
+        elif args.data == 'zeros':
+            x.buf.zero_()
         To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
         y = ops.new_act(N, To, Ho, Wo, Co, DT, dev)
         dy = y.like()
         dy.buf.normal_()
+        if args.data == 'zeros':
+            dy.buf.zero_()
         dx = x.like()
         taps = k[0] * k[1] * k[2]
         w = torch.randn(Co, taps * x.cpitch, device=dev).to(tdt)
