@@ -215,15 +215,34 @@ def self_launch(args):
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print('[bench] --gpus %d without WORLD_SIZE: launching %s' % (args.gpus, ' '.join(cmd[1:8])), file=sys.stderr, flush=True)
     limit = float(os.environ.get('DUALVAR_BENCH_TIMEOUT', 1500))
+    # a session (= process group) of its own: on a timeout the launcher AND its N ranks are signalled -- killing only the
+    # torch.distributed.run parent would orphan the ranks with their GPUs and a possibly hung collective
+    import signal
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, start_new_session=True)
     try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=limit)
-    except subprocess.TimeoutExpired as e:
-        sys.stdout.write((e.stdout or b'').decode(errors='replace'))
-        print(f'[bench] the {args.gpus}-rank job did not finish within {limit:.0f} s', file=sys.stderr, flush=True)
+        out, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        for sig, grace in ((signal.SIGTERM, 10), (signal.SIGKILL, 5)):
+            try:
+                os.killpg(proc.pid, sig)             # (the session leader's pid is the group id)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        try:
+            out = proc.stdout.read() or b''
+        except Exception:
+            out = b''
+        sys.stdout.write(out.decode(errors='replace'))
+        print(f'[bench] the {args.gpus}-rank job did not finish within {limit:.0f} s: its process group was terminated',
+              file=sys.stderr, flush=True)
         sys.exit(4)
-    for line in r.stdout.decode(errors='replace').splitlines():      # the JSON line to stdout, library chatter to stderr
+    for line in out.decode(errors='replace').splitlines():      # the JSON line to stdout, library chatter to stderr
         print(line, file=sys.stdout if line.startswith('{') else sys.stderr, flush=True)
-    sys.exit(r.returncode)
+    sys.exit(proc.returncode)
 
 
 WD = None

@@ -218,6 +218,8 @@ _ticket_ws = []
 
 
 def register_ticket_workspace(t):
+    if len(_ticket_ws) >= 64 and len(_ticket_ws) % 64 == 0:     # plans come and go: drop the references of freed workspaces
+        _ticket_ws[:] = [r for r in _ticket_ws if r() is not None]
     _ticket_ws.append(_weakref.ref(t))
     return t
 

@@ -11,6 +11,9 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdualvar_hip.so')
 SOURCES = ['conv.hip', 'elementwise.hip', 'loss.hip', 'augment.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-comment', '-Wno-inline-asm', '-ffp-contract=off']
+# every compile also reports registers / LDS / scratch per kernel; the report is kept next to the object (csrc/<name>.res) and
+# tests/test_abi_and_host.py fails on any kernel with scratch > 0 (a spill arrived silently in round 3)
+RES_FLAG = '-Rpass-analysis=kernel-resource-usage'
 
 
 def _stale(target, deps):
@@ -18,6 +21,28 @@ def _stale(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def res_path(src):
+    return os.path.join(CSRC, src.replace('.hip', '.res'))
+
+
+def parse_resources(text):
+    """hipcc -Rpass-analysis=kernel-resource-usage remarks -> [{'name', 'VGPRs', 'AGPRs', 'TotalSGPRs', 'ScratchSize', 'Occupancy', 'LDS Size'}]"""
+    import re
+    rows, cur = [], None
+    for line in text.splitlines():
+        m = re.search(r': +(Function Name|Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|'
+                      r'LDS Size \[bytes/block\]): (\S+)', line)
+        if not m:
+            continue
+        k, v = m.group(1).strip(), m.group(2).strip()
+        if k in ('Function Name', 'Name'):
+            cur = {'name': v}
+            rows.append(cur)
+        elif cur is not None:
+            cur[k.split(' [')[0]] = v
+    return rows
 
 
 def build_lib(force=False, verbose=False):
@@ -29,8 +54,8 @@ def build_lib(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+        if force or _stale(o, [s] + hdrs) or not os.path.exists(res_path(src)):
+            cmd = [hipcc] + FLAGS + [RES_FLAG, '-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), file=sys.stderr)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -38,6 +63,8 @@ def build_lib(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError('hipcc failed on %s:\n%s' % (src, out.decode(errors='replace')))
+        with open(res_path(src), 'w') as f:
+            f.write(out.decode(errors='replace'))
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)

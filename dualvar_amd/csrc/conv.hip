@@ -732,10 +732,13 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
     // fp32 outputs whose rows are the tensor's rows (no parity-class row map): straight from the accumulators.  One register
     // of a 32x32 block is 32 consecutive floats of a row per half wave (two 128-byte segments per store instruction: full
     // rate); the row of register r is a wave-uniform offset (soffset: scalar arithmetic only), the lane's part of the address
-    // is fixed per column block, rows >= M fall outside the buffer descriptor and are dropped by the hardware.  No LDS staging,
-    // no barrier, no per-element address arithmetic (what made the per-element form of round 1 slow).
+    // is fixed per column block.  FULL tiles only: the row term sits in soffset, which the buffer range check does NOT cover
+    // (only voffset + the immediate offset are checked), so on a partial last tile rows >= M would be written behind the
+    // tensor -- such tiles take the staged path below, which tests every row (the sentinel test is
+    // tests/test_ops_gpu.py::test_fp32_partial_tiles_do_not_write_behind_the_output).  No LDS staging, no barrier, no
+    // per-element address arithmetic (what made the per-element form of round 1 slow).
     bool direct = false;
-    if constexpr (EO == 4) direct = a.out_bytes > 0 && a.cls_on != 1 && a.bn_x == nullptr;
+    if constexpr (EO == 4) direct = full_tile && a.out_bytes > 0 && a.cls_on != 1 && a.bn_x == nullptr;
     if (direct) {
       const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
       const unsigned ldo4 = (unsigned)a.ldo * 4u;
@@ -762,7 +765,6 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
               v = act_apply(v + bv, flags);
               if (col >= a.N) v = 0.f;
             }
-            if (!full_tile && m0 + wm0 + i * 32 + rl + 4 * h >= a.M) v = 0.f;
             acc[i][j][r] = v;                        // as stored: feeds the two-pass statistics
             if (flags & DV_ACCUM) v += __builtin_bit_cast(float, old[r]);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, (int)vo, (int)((unsigned)(i * 32 + rl) * ldo4), 0);

@@ -296,7 +296,11 @@ __device__ __forceinline__ void column_reduce(int64_t r_begin, int64_t r_end, in
       for (int e = 0; e < V; ++e) acc[s][e] = 0.f;
     if (my_rg < rg) {
       pre((cvb + my_cv) * V);                       // per-thread constants of this channel vector
-#pragma unroll 4
+      // four rows in flight for 4-element (fp32) vectors, two for 8-element (bf16) ones: the same 16 values per sum and thread.
+      // (unroll 4 for bf16 needed > 128 VGPRs: with the 1 024-thread default bound the reduce kernels spilled 112 B per lane and
+      // their traffic went 1.08x -> 1.55x algorithmic -- round 3's bf16 regression; tests/test_abi_and_host.py now fails on
+      // any kernel with scratch.)
+#pragma unroll(V == 4 ? 4 : 2)
       for (int64_t r = r_begin + my_rg; r < r_end; r += rg) f(r, (cvb + my_cv) * V, acc);
     }
     __syncthreads();
@@ -474,7 +478,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const T* __restrict__ dy, int
 }
 
 template <typename T>
-__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
                                      const T* __restrict__ x, int ldx, const float* __restrict__ mean,
                                      const float* __restrict__ invstd, int64_t M, int C, int CP, int flags,
                                      int64_t rows_per_block, float* __restrict__ sums_all, int n_rep, float* __restrict__ ws) {
@@ -483,7 +487,7 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T
 }
 
 template <typename T>
-__global__ void bn_bwd_reduce_multi_kernel(const dv_bn_item* __restrict__ items, int n) {
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_multi_kernel(const dv_bn_item* __restrict__ items, int n) {
   uint32_t bid = blockIdx.x, nblk;
   const int i = find_item(n, bid, nblk, [&](int k) { return items[k].blk_red; });
   const dv_bn_item& it = items[i];
@@ -870,7 +874,7 @@ __device__ __forceinline__ void pool_gather(const PoolArgs& a, const T* __restri
 }
 
 template <typename T>
-__global__ void bn_bwd_reduce_maxpool_kernel(PoolArgs a, const T* __restrict__ dyp, const uint8_t* __restrict__ idx,
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_maxpool_kernel(PoolArgs a, const T* __restrict__ dyp, const uint8_t* __restrict__ idx,
                                              const T* __restrict__ x, const float* __restrict__ mean,
                                              const float* __restrict__ invstd, const float* __restrict__ scale,
                                              const float* __restrict__ shift, int64_t M, int C, int CP, int64_t rows_per_block,

@@ -260,6 +260,14 @@ class ParamStore:
             self.grad.zero_()
 
     def zero_grad(self):
+        # bucket all-reduces started from inside a backward whose optimizer step never ran (parallel.GradSync._on_ready): wait
+        # for them and re-arm, or every later backward would be refused as "gradient accumulation" 
+        if getattr(self, '_sync_started', False):
+            owner = getattr(self, '_sync_owner', None)
+            if owner is not None:
+                owner.abandon(self)
+            self._sync_started = False
+        self.pending_backward = 0
         if self.grad is not None:
             self.grad.zero_()
 

@@ -105,6 +105,7 @@ class GradSync:
         if not todo:
             return
         plan.store._sync_started = True          # from here on nothing may write this arena before the optimizer step
+        plan.store._sync_owner = self             # (ParamStore.zero_grad abandons a step whose optimizer step never came)
         with self._comm_stream(flat, getattr(plan, '_side', None)):
             for a, b in todo:
                 works[a] = self._all_reduce(flat, a, b)
@@ -129,6 +130,19 @@ class GradSync:
         scale = self.reduce_flat(store.grad)
         store._sync_started = False
         return scale
+
+    def abandon(self, store):
+        """A step whose bucket all-reduces were started from inside the backward but whose optimizer step never came (an
+        exception, a skipped / NaN step, zero_grad() and retry): wait for what is in flight -- it writes the arena -- forget it
+        and re-arm the arena for the next backward.  Every rank must take the same decision, as with any collective."""
+        flat = store.grad
+        works = self._works.pop(id(flat), {}) if flat is not None else {}
+        for w in works.values():
+            if w is not None:
+                w.wait()
+        if works and self._stream is not None and flat is not None and flat.is_cuda:
+            torch.cuda.current_stream(flat.device).wait_stream(self._stream)
+        store._sync_started = False
 
 
 class _null:

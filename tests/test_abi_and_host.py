@@ -38,6 +38,24 @@ def test_library_exports_every_declared_symbol():
     assert lib.dv_abi_version() == declared == _lib.ABI_VERSION >= 2
 
 
+def test_no_kernel_of_the_library_spills():
+    """Every kernel of libdualvar_hip.so keeps its working set in registers: the build keeps hipcc's resource report next to
+    each object (dualvar_amd/build.py: csrc/<name>.res) and any `ScratchSize > 0` fails here.  Round 3 shipped two BatchNorm
+    backward reduce kernels that spilled 112 B per lane after an unroll change (bf16 leg -4.4 %, traffic 1.08x -> 1.55x)
+    and nobody saw it."""
+    from dualvar_amd import build as B
+    B.build_lib()
+    seen = 0
+    for src in B.SOURCES:
+        assert os.path.exists(B.res_path(src)), f'no resource report for {src}'
+        rows = B.parse_resources(open(B.res_path(src)).read())
+        assert rows, f'empty resource report for {src}'
+        for r in rows:
+            assert int(r.get('ScratchSize', '0')) == 0, f"{src}: {r['name']} spills {r['ScratchSize']} B/lane"
+            seen += 1
+    assert seen >= 250          # conv 170+, elementwise 80+, loss, augment
+
+
 def test_argument_validation_without_gpu():
     """rejected arguments return DV_E* before anything is launched, so this is safe on a CPU-only host"""
     from dualvar_amd import _lib
@@ -370,6 +388,37 @@ def test_overlapped_gradient_sync_refuses_a_second_backward():
         plan = _Plan()
     with pytest.raises(RuntimeError, match='overlapped all-reduce'):
         _BackboneFn.backward(_Ctx(), None)
+
+
+def test_zero_grad_rearms_an_arena_whose_overlapped_sync_was_never_finished():
+    """backward (bucket all-reduces started from inside it) -> no optimizer step (exception / skipped step) -> zero_grad():
+    the pending works are waited for and dropped, the flag is cleared and the next backward is accepted."""
+    from dualvar_amd.engine import ParamStore
+    from dualvar_amd.parallel import GradSync
+
+    class _Work:
+        waited = 0
+
+        def wait(self):
+            _Work.waited += 1
+    st = ParamStore.__new__(ParamStore)
+    st.grad = torch.ones(8)
+    st.pending_backward = 2
+    gs = GradSync.__new__(GradSync)
+    gs._works, gs._stream = {id(st.grad): {0: _Work(), 4: None}}, None
+    st._sync_started, st._sync_owner = True, gs
+    st.zero_grad()
+    assert st._sync_started is False and st.pending_backward == 0 and _Work.waited == 1
+    assert gs._works == {} and float(st.grad.abs().sum()) == 0.0
+    st.zero_grad()                       # idempotent
+
+
+def test_ticket_workspace_registry_drops_dead_references():
+    from dualvar_amd import _lib
+    before = len(_lib._ticket_ws)
+    for _ in range(200):
+        _lib.register_ticket_workspace(torch.zeros(1))          # freed at once
+    assert len(_lib._ticket_ws) <= before + 130
 
 
 def test_worker_side_augmentation_rows_equal_the_in_line_build():

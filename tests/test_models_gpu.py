@@ -714,9 +714,14 @@ def test_first_conv_weight_gradient_carrying_the_batchnorm_backward_gives_the_sa
         grads.append(torch.cat([st.grad.detach().float().flatten().clone() for st in m.stores()]))
         plans = [pl for lst in m.encoder_q[0]._plans.values() for pl in lst]
         fused.append(sum(1 for pl in plans for op in pl.ops if getattr(op, 'bn_apply', None) is not None))
-    assert fused[0] == 0 and fused[1] == fused[2] and fused[1] == (1 if net == 's3dg' else fused[1]), fused      # (only where the first conv's weight gradient runs on the kernel that carries it)
+    assert fused[0] == 0 and fused[1] == fused[2] and fused[1] in (0, 1), fused
+    if net == 's3dg':
+        assert fused[1] == 1, fused
+    print(net, 'first-conv weight gradients carrying the BatchNorm backward:', fused[1])
     assert torch.equal(grads[1], grads[2]), float((grads[1] - grads[2]).abs().max())
     assert torch.equal(grads[0], grads[1]), float((grads[0] - grads[1]).abs().max())
+    if fused[1] == 0:      # (only where the first conv's weight gradient runs on the kernel that carries it: the comparison above was
+        pytest.skip('FUSE_BN_WGRAD does not engage on %s: both plans are the two-launch plan' % net)      # of two identical plans)
 
 
 # ---------------------------------------------------------------------------------------------------------------

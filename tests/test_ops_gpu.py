@@ -1,8 +1,9 @@
 """GPU parity of every HIP kernel against the fp32 PyTorch-CPU op the oracle is made of.
 
-Tolerances: DV_F32 path -> 2e-5 relative to the tensor's max (exact-fp32 MFMA, different
-summation order only); DV_BF16 path -> inputs are rounded to bf16 first, outputs compared at
-1.5e-2 of the tensor's max (bf16 storage rounding, fp32 accumulation)."""
+Tolerances: DV_F32 path -> 2e-5 relative to the tensor's max (fp32 storage, statistics and accumulation; products as six
+exact bf16 partial products on the matrix cores -- error at fp32 rounding level -- or, under DUALVAR_F32_EXACT=1, the
+f32-input MFMA); DV_BF16 path -> inputs are rounded to bf16 first, outputs compared at 1.5e-2 of the tensor's max
+(bf16 storage rounding, fp32 accumulation)."""
 import numpy as np
 import pytest
 import torch
@@ -1344,6 +1345,60 @@ def test_fp32_conv_at_headline_tile_sizes_against_cpu_conv3d(gpu, case):
           'wgrad splits', sp_.value)
     for k_ in got:
         assert got[k_] <= max(4 * cpu[k_], 2e-6), (name, k_, got[k_], cpu[k_])
+
+
+SENTINEL_CASES = [
+    # name, N, Cin, T, H, W, Cout: pointwise convs whose ROW COUNT is not a multiple of the tile height (nor of 32): the last tile
+    # is partial.  256 x 64 tiles (>= 512 tiles of 256 rows), 128 x 128 tiles (>= 1 024 tiles of 128 rows), 64-row tiles.
+    ('t256', 1, 16, 3, 121, 121, 192),
+    ('t128', 1, 16, 3, 211, 211, 128),
+    ('t64', 1, 32, 1, 37, 27, 96),
+    ('t64_c40', 1, 16, 1, 33, 31, 40),
+]
+
+
+@pytest.mark.parametrize('case', SENTINEL_CASES, ids=[c[0] for c in SENTINEL_CASES])
+def test_fp32_partial_tiles_do_not_write_behind_the_output(gpu, case):
+    """the register-direct fp32 epilogue put the row term of its store addresses into soffset, which the
+    buffer range check does not cover, so a partial last tile stored (zeros) up to 31+ rows BEHIND the tensor.  Forward, data
+    gradient and `+=` data gradient with M % 32 != 0 into a view of a larger buffer whose trailing rows hold a sentinel:
+    the sentinel survives, the values are right."""
+    from dualvar_amd._lib import DV_W3
+    name, N, Cin, T, H, W, Cout = case
+    k, s_, p_ = (1, 1, 1), (1, 1, 1), (0, 0, 0)
+    M = N * T * H * W
+    assert M % 32 != 0
+    x = rnd(N, Cin, T, H, W, seed=1)
+    w = rnd(Cout, Cin, 1, 1, 1, seed=2, scale=Cin ** -0.5)
+    yr = F.conv3d(x, w)
+    gy = rnd(*yr.shape, seed=3)
+    dxr = F.conv_transpose3d(gy, w)
+    SENT, EXTRA = 12345.0, 300
+
+    def guarded(C_):
+        ld = ops.cp8(C_)
+        buf = torch.full((M + EXTRA, ld), SENT, dtype=torch.float32, device=gpu)
+        buf[:M] = 0
+        return ops.Act(buf[:M], N, T, H, W, C_, ld, 0, DV_F32, ld), buf
+    xa = ops.act_from_ncdhw(x.to(gpu), DV_F32)
+    wp = ops.pack_weight(w.to(gpu), ops.cp8(Cin))
+    wd = torch.zeros(Cin, 1, ops.cp8(Cout), device=gpu)
+    wd[:, :, :Cout] = w.to(gpu).reshape(Cout, Cin, 1).permute(1, 2, 0)
+    for w3 in ((False, True) if not _EXACT else (False,)):
+        ya, ybuf = guarded(Cout)
+        d = ops.conv_desc(DV_F32, xa, ya, k, s_, p_, flags=DV_W3 if w3 else 0)
+        ops.conv_fwd(d, xa, ops.pack_w3(wp.view(Cout, -1)) if w3 else wp, None, ya, None)
+        torch.cuda.synchronize()
+        assert bool((ybuf[M:] == SENT).all()), (name, w3, 'forward wrote behind row M')
+        close(ops.act_to_ncdhw(ya), yr, DV_F32, name + ' fwd')
+        dya = ops.act_from_ncdhw(gy.to(gpu), DV_F32)
+        dxa, dbuf = guarded(Cin)
+        for flags in (0, ops.DV_ACCUM):
+            d2 = ops.conv_desc(DV_F32, dxa, dya, k, s_, p_, flags=flags | (DV_W3 if w3 else 0))
+            ops.conv_dgrad(d2, dya, ops.pack_w3(wd.view(Cin, -1)) if w3 else wd, dxa)
+            torch.cuda.synchronize()
+            assert bool((dbuf[M:] == SENT).all()), (name, w3, flags, 'data gradient wrote behind row M')
+        close(ops.act_to_ncdhw(dxa), 2 * dxr, DV_F32, name + ' dgrad, then +=', factor=2)
 
 
 @pytest.mark.parametrize('cfg', [0, 2])
