@@ -267,7 +267,8 @@ class ParamStore:
             if owner is not None:
                 owner.abandon(self)
             self._sync_started = False
-        self.pending_backward = 0
+        # (pending_backward is NOT reset here: the reference's loop -- and ours -- calls zero_grad() between the forward and the
+        # backward of a step, pretrain.py:447-448; the optimizer step resets it)
         if self.grad is not None:
             self.grad.zero_()
 

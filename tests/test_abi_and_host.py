@@ -408,7 +408,7 @@ def test_zero_grad_rearms_an_arena_whose_overlapped_sync_was_never_finished():
     gs._works, gs._stream = {id(st.grad): {0: _Work(), 4: None}}, None
     st._sync_started, st._sync_owner = True, gs
     st.zero_grad()
-    assert st._sync_started is False and st.pending_backward == 0 and _Work.waited == 1
+    assert st._sync_started is False and st.pending_backward == 2 and _Work.waited == 1
     assert gs._works == {} and float(st.grad.abs().sum()) == 0.0
     st.zero_grad()                       # idempotent
 
