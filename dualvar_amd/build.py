@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdualvar_hip.so')
-SOURCES = ['conv.hip', 'elementwise.hip', 'loss.hip', 'augment.hip']
+SOURCES = ['conv.hip', 'conv_tap.hip', 'conv_experiments.hip', 'elementwise.hip', 'loss.hip', 'augment.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-comment', '-Wno-inline-asm', '-ffp-contract=off']
 # every compile also reports registers / LDS / scratch per kernel; the report is kept next to the object (csrc/<name>.res) and
 # tests/test_abi_and_host.py fails on any kernel with scratch > 0 (a spill arrived silently in round 3)
@@ -47,7 +47,7 @@ def parse_resources(text):
 
 def build_lib(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', 'hipcc')
-    hdrs = [os.path.join(CSRC, 'common.hpp'), os.path.join(HERE, '..', 'include', 'dualvar_hip.h')]
+    hdrs = [os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'conv_common.hpp'), os.path.join(HERE, '..', 'include', 'dualvar_hip.h')]
     objs = []
     procs = []
     for src in SOURCES:

@@ -13,354 +13,13 @@
 //
 // MFMA: v_mfma_f32_32x32x16_bf16 (bf16 storage) / v_mfma_f32_32x32x2_f32 (f32 parity mode);
 // both share the 32x32 C/D layout  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-#include "common.hpp"
-#include <algorithm>
-#include <cmath>
-#include <cstdlib>
-#include <type_traits>
-#include <utility>
+#include "conv_common.hpp"
+
+// the LDS-staged input-tile kernels for stride-1 "same" 1x3x3 / 3x1x1 convs (conv_tap.hip); the argument is a ConvArgs*
+int dvt_conv_tap_kind(const void* conv_args, int mode);
+int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream);
 
 namespace {
-
-enum { MODE_FWD = 0, MODE_DGRAD = 1 };
-
-struct ConvGeom {
-  // "row space" (what m enumerates) and "source space" (the tensor the gather reads)
-  int rT, rH, rW;        // row-space dims
-  int sT, sH, sW;        // source dims
-  int kt, kh, kw;
-  int st, sh, sw;        // strides (conv strides)
-  int pt, ph, pw;
-  int CP;                // channel pitch used to decode k -> (tap, c)
-  int Ktot;              // kt*kh*kw*CP
-  FastDiv dW, dH, dT;    // fast division by rW, rH, rT
-};
-
-// Row ORDER of a launch whose window has taps along t (on): rows are enumerated
-//   for clip n: for 32-pixel chunk c of the (h, w) plane: for t: rows (n, t, c*32 .. c*32+31)
-// instead of the tensor's [n][t][h][w] order, so the rows a tap reads at t-1 / t+1 are rows the neighbouring steps of the
-// weight-gradient kernel read at their own t: L2 hits.  In tensor order they are a whole plane (784 .. 3 136 rows)
-// away and every tap fetched its own copy of the activation: PMC 2.2x the algorithmic bytes on the 3x1x1 / 7x1x1 weight
-// gradients (1.0 - 1.25x with this order, and 3 - 9 % faster).  A sum over rows: any fixed bijection of [0, M) will do.
-// (The same order for the tiles of the forward / data-gradient GEMMs was measured 2 - 6 % SLOWER: not used there.)
-struct RowPerm {
-  int on, pT, pS, nfull, full_span;
-  FastDiv fB, f32T, fwt;
-};
-static RowPerm make_row_perm(bool on, int T, int S) {
-  RowPerm p;
-  p.on = on ? 1 : 0; p.pT = T; p.pS = S; p.nfull = S / 32; p.full_span = p.nfull * 32 * T;
-  p.fB = make_fastdiv((uint32_t)(T * S)); p.f32T = make_fastdiv((uint32_t)(32 * T));
-  p.fwt = make_fastdiv((uint32_t)(S % 32 ? S % 32 : 1));
-  return p;
-}
-__device__ __forceinline__ uint32_t perm_row(const RowPerm& a, uint32_t q) {
-  uint32_t n, p, t, pix;
-  fd_divmod(q, a.fB, n, p);
-  if (p < (uint32_t)a.full_span) {
-    uint32_t c, w;
-    fd_divmod(p, a.f32T, c, w);
-    t = w >> 5; pix = c * 32 + (w & 31);
-  } else {
-    uint32_t r;
-    fd_divmod(p - (uint32_t)a.full_span, a.fwt, t, r);
-    pix = (uint32_t)a.nfull * 32 + r;
-  }
-  return (n * (uint32_t)a.pT + t) * (uint32_t)a.pS + pix;
-}
-
-struct ConvArgs {
-  const void* src;       // gathered tensor (x for fwd, dy for dgrad)
-  const void* w;         // [N rows][Ktot] K-contiguous, pitch ldw
-  void* out;             // [M][ldo]
-  const float* bias;
-  float* stats;          // [2][N][m_tiles]
-  int M, N, NP;          // rows, real cols, cols to write (zeros beyond N)
-  int lds_, ldo, ldw;    // pitches in elements (src, out, weights)
-  int ntn;               // number of N tiles
-  int flags;
-  const float* sc_a;     // fp8 GEMMs: device scalars, result = acc * sc_a[0] * sc_b[0] (per-tensor scales of the operands)
-  const float* sc_b;
-  int src_bytes, w_bytes; // extents for the buffer descriptors (< 2 GiB)
-  int out_bytes;          // extent of the output rows [0, M) from `out` (0: not known to be < 2 GiB -> staged epilogue)
-  FastDiv fCP;           // k -> (tap, c)
-  ConvGeom g;
-  // Strided dgrad, one launch per PARITY CLASS (cls_on): input positions t = t'*cst + cot (same for h, w) only receive
-  // the kernel taps d = crt + cst*j, so in (t', j) coordinates the class is a dense stride-1 problem -- `g` describes
-  // it (row space = the class's sub-lattice, kernel = its taps, padding (cot + pt - crt) / cst) -- instead of gathering
-  // all taps and multiplying zeros for the (st*sh*sw - 1)/(st*sh*sw) that miss.  The weights are not repacked: a class tap
-  // reads the ORIGINAL tap ((crt+cst*jt)*oKH + crh+csh*jh)*oKW + crw+csw*jw; output rows map back to the full input.
-  // cls_on == 2: only the TAPS are remapped (cst = csh = csw = 1, crt / crh / crw = first live tap): a window whose outer taps
-  // fall into the padding for EVERY row (3x1x1 with padding 1 on a one-frame map: two of three taps) runs as the smaller
-  // window of its live taps -- trim_dead_taps() on the host.
-  int cls_on, cst, csh, csw, cot, coh, cow, crt, crh, crw, oKH, oKW, oT, oH, oW;
-  // dgrad whose output is dL/dy of y = relu(x_bn * scale + shift), the BatchNorm in front of this conv, and is that
-  // gradient's only contribution (dv_conv3d_dgrad_bn): the epilogue also accumulates the BatchNorm backward's
-  // sum(g), sum(g * xhat) into bn_sums[tile_m % bn_rep][2][CP] -- what dv_bn_bwd_reduce would compute from a second read of
-  // dL/dy.  bn_x == nullptr: plain dgrad.
-  const void* bn_x;
-  const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
-  float* bn_sums;
-  int bn_ldx, bn_rep, bn_mask;
-};
-
-template <int BYTES> struct VecB;
-template <> struct VecB<16> { typedef uint4 type; static __device__ __forceinline__ uint4 zero() { return make_uint4(0, 0, 0, 0); } };
-template <> struct VecB<8> { typedef uint2 type; static __device__ __forceinline__ uint2 zero() { return make_uint2(0, 0); } };
-
-// Per-thread cursor over the k axis of the im2col matrix for one fixed vector slot.
-struct KCursor {
-  int c, dt, dh, dw, tap;
-  __device__ __forceinline__ void init(int k0, const ConvGeom& g) {
-    tap = k0 / g.CP;
-    c = k0 - tap * g.CP;
-    dw = tap % g.kw;
-    int t2 = tap / g.kw;
-    dh = t2 % g.kh;
-    dt = t2 / g.kh;
-  }
-  __device__ __forceinline__ void advance(int step, const ConvGeom& g) {
-    c += step;
-    while (c >= g.CP) {
-      c -= g.CP;
-      ++tap;
-      if (++dw == g.kw) {
-        dw = 0;
-        if (++dh == g.kh) { dh = 0; ++dt; }
-      }
-    }
-  }
-};
-
-// Row of the im2col matrix: decoded once per thread.
-struct RowPos {
-  int base;      // n * sT*sH*sW
-  int t0, h0, w0;
-  bool valid;
-};
-
-template <int MODE>
-__device__ __forceinline__ RowPos decode_row(uint32_t m, int M, const ConvGeom& g) {
-  RowPos r;
-  r.valid = (int)m < M;
-  uint32_t q, wo, ho, to, n;
-  fd_divmod(m, g.dW, q, wo);
-  fd_divmod(q, g.dH, q, ho);
-  fd_divmod(q, g.dT, n, to);
-  r.base = (int)n * g.sT * g.sH * g.sW;
-  if (MODE == MODE_FWD) {
-    r.t0 = (int)to * g.st - g.pt;
-    r.h0 = (int)ho * g.sh - g.ph;
-    r.w0 = (int)wo * g.sw - g.pw;
-  } else {
-    r.t0 = (int)to + g.pt;
-    r.h0 = (int)ho + g.ph;
-    r.w0 = (int)wo + g.pw;
-  }
-  return r;
-}
-
-// source position (in elements/ld units) of (row, tap) or -1
-template <int MODE>
-__device__ __forceinline__ int src_pos(const RowPos& r, const KCursor& k, const ConvGeom& g) {
-  int t, h, w;
-  if (MODE == MODE_FWD) {
-    t = r.t0 + k.dt; h = r.h0 + k.dh; w = r.w0 + k.dw;
-  } else {
-    t = r.t0 - k.dt; h = r.h0 - k.dh; w = r.w0 - k.dw;
-    // strides are 1 or 2 (checked on the host)
-    if (((t & (g.st - 1)) | (h & (g.sh - 1)) | (w & (g.sw - 1))) != 0) return -1;
-    if ((t | h | w) < 0) return -1;
-    t >>= (g.st - 1); h >>= (g.sh - 1); w >>= (g.sw - 1);
-  }
-  bool ok = r.valid && (k.dt < g.kt) && (unsigned)t < (unsigned)g.sT && (unsigned)h < (unsigned)g.sH &&
-            (unsigned)w < (unsigned)g.sW;
-  return ok ? r.base + (t * g.sH + h) * g.sW + w : -1;
-}
-
-// Blocks are dealt round-robin over the 8 XCDs (private L2 each): blocks b and b+8 share an XCD.  Remap so that each
-// XCD gets a CONTIGUOUS range of logical tiles -- the tiles that re-read the same rows (all N tiles of one M tile,
-// all (i,j) tiles of one wgrad row split) then hit the same L2.  Bijective for any grid size.  Speed only.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7;
-  const int xcd = bid & 7, idx = bid >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-// ---- global -> LDS DMA (buffer_load_dwordx4 ... lds) as inline assembly -------------------------------------------
-// The __builtin_amdgcn_raw_ptr_buffer_load_lds form is tracked by the compiler's wait-count pass, which cannot prove
-// that the following ds_reads touch the OTHER buffer and therefore drains vmcnt(0) in front of them: the prefetch of
-// tile k+1 is then waited for before tile k is even read, i.e. no overlap inside a workgroup.  Issued as opaque
-// assembly the load is invisible to that pass; the kernels wait for it themselves (dma_wait_all) right before the
-// barrier that publishes the tile.  One wave instruction moves 64 lanes x 16 B to LDS [m0, m0 + 1 KiB).
-typedef __attribute__((ext_vector_type(4))) unsigned int dma_rsrc_t;
-__device__ __forceinline__ dma_rsrc_t dma_make_rsrc(const void* p, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)p;
-  dma_rsrc_t r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
-  return r;
-}
-__device__ __forceinline__ void dma_load16(dma_rsrc_t rsrc, unsigned lds_base, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :
-               : "s"(lds_base), "v"(voff), "s"(rsrc)
-               : "memory", "m0");
-}
-__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// wait until at most n (wave-uniform, <= 24) of this wave's DMA pieces are still in flight
-__device__ __forceinline__ void dma_wait_upto(int n) {
-#define DV_W(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
-  switch (n) {
-    DV_W(1) DV_W(2) DV_W(3) DV_W(4) DV_W(5) DV_W(6) DV_W(7) DV_W(8) DV_W(9) DV_W(10) DV_W(11) DV_W(12)
-    DV_W(13) DV_W(14) DV_W(15) DV_W(16) DV_W(17) DV_W(18) DV_W(19) DV_W(20) DV_W(21) DV_W(22) DV_W(23) DV_W(24)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef DV_W
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
-}
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  // one K-tile = 64 bytes = 32 bf16 per row: two 32x32x16 steps
-  // sa / sb: XOR masks on the 16-byte slot index (0 for the padded layout, (row>>2)&3 for the swizzled DMA layout)
-  static __device__ __forceinline__ void tile(const unsigned char* a_row, const unsigned char* b_row, int h, int sa, int sb,
-                                               f32x16& acc) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a = *reinterpret_cast<const bf16x8*>(a_row + ((2 * ks + h) ^ sa) * 16);
-      bf16x8 b = *reinterpret_cast<const bf16x8*>(b_row + ((2 * ks + h) ^ sb) * 16);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-    }
-  }
-};
-template <> struct Mma<float> {
-  // one K-tile = 64 bytes = 16 f32 per row: eight 32x32x2 steps
-  static __device__ __forceinline__ void tile(const unsigned char* a_row, const unsigned char* b_row, int h, int sa, int sb,
-                                               f32x16& acc) {
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      f32x4 a = *reinterpret_cast<const f32x4*>(a_row + (gq ^ sa) * 16);
-      f32x4 b = *reinterpret_cast<const f32x4*>(b_row + (gq ^ sb) * 16);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a.y : a.x, h ? b.y : b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a.w : a.z, h ? b.w : b.z, acc, 0, 0, 0);
-    }
-  }
-};
-
-// fp8 operands (1x1x1 convs of the bottleneck blocks, BASELINE configs[4]): one K tile = 64 bytes = 64 fp8 per row = ONE
-// v_mfma_f32_32x32x64_f8f6f4 (twice the bf16 rate per clock); lane (r = lane&31, h = lane>>5) holds k = 32h .. 32h+31 of
-// its row in eight VGPRs.  FA / FB: 0 = e4m3, 1 = e5m2 (cbsz / blgp).  Scales 0 select the unscaled form of the instruction.
-template <int FA, int FB>
-__device__ __forceinline__ void mma_fp8(const unsigned char* a_row, const unsigned char* b_row, int h, int sa, int sb, f32x16& acc) {
-  const i32x4 a0 = *reinterpret_cast<const i32x4*>(a_row + ((2 * h) ^ sa) * 16), a1 = *reinterpret_cast<const i32x4*>(a_row + ((2 * h + 1) ^ sa) * 16);
-  const i32x4 b0 = *reinterpret_cast<const i32x4*>(b_row + ((2 * h) ^ sb) * 16), b1 = *reinterpret_cast<const i32x4*>(b_row + ((2 * h + 1) ^ sb) * 16);
-  const i32x8 a = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, b = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, FA, FB, 0, 0, 0, 0);
-}
-template <> struct Mma<fp8e4_t> {       // forward: x (e4m3) * w (e4m3)
-  static __device__ __forceinline__ void tile(const unsigned char* a_row, const unsigned char* b_row, int h, int sa, int sb, f32x16& acc) {
-    mma_fp8<0, 0>(a_row, b_row, h, sa, sb, acc);
-  }
-};
-template <> struct Mma<fp8e5_t> {       // data gradient: dy (e5m2) * w (e4m3)
-  static __device__ __forceinline__ void tile(const unsigned char* a_row, const unsigned char* b_row, int h, int sa, int sb, f32x16& acc) {
-    mma_fp8<1, 0>(a_row, b_row, h, sa, sb, acc);
-  }
-};
-template <typename T> struct OutOf { typedef T type; };
-template <> struct OutOf<fp8e4_t> { typedef bf16_t type; };          // fp8 GEMMs write bf16 activations / gradients
-template <> struct OutOf<fp8e5_t> { typedef bf16_t type; };
-
-// ---- fp32 operands on the bf16 matrix cores ("3 x bf16 split") ----------------------------------------------------
-// gfx950 has no xf32 / TF32 path and its f32-input MFMA runs at the vector rate, 1/16 of the bf16 MFMA.  An fp32 value
-// is EXACTLY hi + mid + lo with three bf16 (8 significant bits each = fp32's 24; round-to-nearest residues), and a
-// product a*b is the sum of nine partial products of which the six of weight >= 2^-16 are kept: the three dropped ones
-// are <= 2^-24 |a||b| each, i.e. at the level of fp32's own rounding of the product.  Every partial product of two bf16
-// is exact in fp32 and the MFMA accumulates in fp32, small terms first.  Six bf16 MFMAs (32 cycles each) replace eight
-// 32x32x2 f32 MFMAs (64 cycles each) per 32x32x16 block: 2.67x less matrix-pipe time at fp32-level accuracy
-// (DUALVAR_F32_EXACT=1 selects the exact-f32 MFMA kernels instead; tests/test_ops_gpu.py compares both with torch fp32).
-struct Split3 { bf16x8 hi, mid, lo; };
-__device__ __forceinline__ Split3 split3(const float (&v)[8]) {
-  Split3 s;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const bf16_t h = (bf16_t)v[e];
-    const float r1 = v[e] - (float)h;
-    const bf16_t m = (bf16_t)r1;
-    const float r2 = r1 - (float)m;
-    s.hi[e] = h; s.mid[e] = m; s.lo[e] = (bf16_t)r2;
-  }
-  return s;
-}
-// The weight-gradient kernels' split (they are bound by the vector-instruction count of exactly this function):
-// hi = bf16(x), rounded to nearest (one v_cvt_pk_bf16_f32 per pair); r1 = x - hi is exact, has <= 16 significant bits and a
-// sign that does not follow x's; mid = the TOP 16 BITS of r1 (truncated: the bf16 is the upper half of the fp32 word, so the
-// pair is one v_perm_b32 and widening it back is one v_and per value); lo = r1 - mid has <= 8 significant bits and is exact
-// in bf16 (again the upper half).  Per pair of values: 1 conversion, 2 widenings, 2 v_and, 2 packed subtractions, 2 v_perm =
-// 36 vector instructions per 8 values; rounding mid and lo as well takes 42, and these kernels are bound by that count
-// (weight gradients -6.6 %, step -1.1 %).  The forward / data-gradient kernels keep the fully rounded split3 above: they are
-// MFMA bound, and with the truncated mid the loss after two SGD steps moved from 1.1e-3 to 1.6e-3 of the reference's on the
-// R(2+1)D fixture (a weight gradient enters the next step scaled by the learning rate; an activation enters it directly).  Truncating hi too would cost the same 36 but biases every dropped partial product
-// (mid*lo, lo*mid, lo*lo) towards the sign of x*y: in the long, cancelling sums of a weight gradient that bias showed as
-// 1e-1 relative differences between a batch and its two halves (1e-3 .. 1e-2 with the rounded hi).
-// one pair of values -> the pair's dword of each of the three planes (the step split3w repeats four times)
-__device__ __forceinline__ void split3w_pair(float x0, float x1, unsigned& H, unsigned& Mi, unsigned& Lo) {
-  typedef __attribute__((ext_vector_type(2))) float f32x2;
-  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-  const u32x2 mask = {0xffff0000u, 0xffff0000u};
-  const f32x2 x = {x0, x1};
-  const bf16x2 hb = __builtin_convertvector(x, bf16x2);              // one v_cvt_pk_bf16_f32
-  const unsigned hw = __builtin_bit_cast(unsigned, hb);
-  const u32x2 hwide = {hw << 16, hw & 0xffff0000u};
-  const f32x2 r1 = x - __builtin_bit_cast(f32x2, hwide);
-  const u32x2 rb = __builtin_bit_cast(u32x2, r1);
-  const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, rb & mask);
-  const u32x2 qb = __builtin_bit_cast(u32x2, r2);
-  H = hw;
-  Mi = __builtin_amdgcn_perm(rb.y, rb.x, 0x07060302u);
-  Lo = __builtin_amdgcn_perm(qb.y, qb.x, 0x07060302u);
-}
-__device__ __forceinline__ Split3 split3w(const float (&v)[8]) {
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
-  u32x4v H, Mi, Lo;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    unsigned h_, m_, l_;
-    split3w_pair(v[2 * p], v[2 * p + 1], h_, m_, l_);
-    H[p] = h_; Mi[p] = m_; Lo[p] = l_;
-  }
-  Split3 s;
-  s.hi = __builtin_bit_cast(bf16x8, H); s.mid = __builtin_bit_cast(bf16x8, Mi); s.lo = __builtin_bit_cast(bf16x8, Lo);
-  return s;
-}
-// compile-time loop: f(std::integral_constant<int, 0>()) ... f(std::integral_constant<int, N - 1>())
-template <class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>()), ...); }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>()); }
-__device__ __forceinline__ void mma_split3(const Split3& a, const Split3& b, f32x16& acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
-}
-// K-contiguous LDS row (64 bytes = 16 f32 per K tile, 16-byte slots XOR-swizzled by s): the 8 floats k = 8h .. 8h+7
-__device__ __forceinline__ Split3 split3_row(const unsigned char* row, int h, int s) {
-  const f32x4 lo4 = *reinterpret_cast<const f32x4*>(row + ((2 * h) ^ s) * 16);
-  const f32x4 hi4 = *reinterpret_cast<const f32x4*>(row + ((2 * h + 1) ^ s) * 16);
-  const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-  return split3(v);
-}
-
-__device__ __forceinline__ float act_apply(float v, int flags) {
-  if (flags & DV_RELU) v = fmaxf(v, 0.f);
-  if (flags & DV_SIGMOID) v = 1.f / (1.f + __expf(-v));
-  return v;
-}
 
 // ------------------------------------------------------------------------------------------
 // fwd / dgrad kernel.  256 threads = 4 waves arranged WAVES_M x WAVES_N over a BM x BN tile.
@@ -1181,34 +840,6 @@ __global__ __launch_bounds__(256) void conv_gemm_ks_kernel(ConvArgs a) {
 // tile with plain stores into slab[split] (caller-owned scratch, [splits][Cout][J]) and wgrad_reduce_kernel adds the
 // slabs to dW in a fixed order -- no float atomics (their order changed results from run to run, and at ~1.3 TB/s
 // chip-wide they were ~40 % of a mid-size launch).  With one split the tile is added to dW directly.
-struct WgradArgs {
-  const void* x;
-  const void* dy;
-  float* dw;
-  float* slab;            // [splits][slab_stride] partial sums, or nullptr (splits == 1: dW += tile)
-  long long slab_stride;  // elements between consecutive splits (>= Cout * ldw)
-  int M, Cout, CoutP, J;  // rows, output channels (padded), J = taps*CP
-  int ldx, ldy, ldw;
-  int nti, ntj;
-  int rows_per_split;
-  ConvGeom g;
-  RowPerm perm;           // row order of the DMA kernel (see RowPerm)
-};
-
-// one 32x32 accumulator block -> slab / dW.  Per register a half wave stores 32 consecutive floats (128 B).
-__device__ __forceinline__ void wgrad_store_block(const WgradArgs& a, int split, int row0, int col, int h, const f32x16& acc) {
-  if (col >= a.J) return;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (row < a.Cout) {
-      const size_t e = (size_t)row * a.ldw + col;
-      if (a.slab) a.slab[(size_t)split * a.slab_stride + e] = acc[r];
-      else a.dw[e] += acc[r];
-    }
-  }
-}
-
 // dW[e] += sum_s slab[s][e], s ascending inside each of the 16 interleaved groups, groups combined in ascending order:
 // a fixed summation tree, so the result does not depend on scheduling.  Thread (cx, sg) of a block sums slabs
 // sg, sg+16, ... of float4 column blockIdx*16 + cx (16 lanes = 256 contiguous bytes per slab).
@@ -1421,16 +1052,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 //  * wave tiles are 64 x 64 (2 x 2 MFMA blocks: 8 MFMAs per 32-row step and wave instead of 4, for the same barrier),
 //    workgroup tiles 128 x 128 or 64 x 256 (f32: 64 x 128 with 32 x 64 wave tiles): half the dY / im2col re-reads of
 //    the 128 x 64 tiles this replaces.
-struct WgradDmaArgs {
-  WgradArgs w;
-  int x_bytes, dy_bytes;
-  // BNA (dv_conv3d_wgrad_bn): the dY operand is formed from g = w.dy and the BatchNorm's input bn_x (same rows / pitch)
-  const void* bn_x;
-  const float *bn_mean, *bn_invstd, *bn_gamma, *bn_scale, *bn_shift, *bn_sums;
-  float *bn_dgamma, *bn_dbeta;
-  float bn_inv_count, bn_dscale;
-  int bn_rep, bn_mask;
-};
 
 // rows of RB bytes: four consecutive rows must fall on four different 64-byte bank groups of the 256-byte LDS line
 // (RB a multiple of 256: XOR the 64-byte chunk index with row&3; RB = 128 mod 256, i.e. 128 or 384: rows 0/1 already
@@ -1791,375 +1412,6 @@ __attribute__((amdgpu_waves_per_eu(wgrad_waves_per_simd(sizeof(T), BI, BJ, WVI *
 
 
 // ------------------------------------------------------------------------------------------
-// fp32 weight gradient, second form ("f32s"): products on the bf16 matrix cores as above, but laid out around the count of
-// vector instructions the operand SPLITS cost, which is what bounded conv_wgrad_dma_kernel<float, 64, 128, 1, 4, 2, true, true>
-// (PMC: vector issue 77 % busy, matrix pipe 42 %; ~210 vector instructions against 24 MFMAs per wave and 32-row step):
-//  * 1 x 4 waves, wave tiles BI x BJ/4 with BJ/4 = 64 (or 32): a wave splits its OWN x columns once per step and uses each
-//    fragment for TI = BI/32 blocks; the dY fragments, which every wave needs, are split once per WORKGROUP (a 64-lane
-//    "fragment op" per 8 rows x 64 columns, dealt over the waves) and shared through LDS planes in fragment order
-//    ([k group][hi|mid|lo][column] bf16x8: conflict-free ds_write_b128 / ds_read_b128).  Split instructions per MFMA:
-//    64x256: 3.75, 128x128: 3.0, 128x256: 2.25 (the 64x128 form above: 4.5, and its 2x2 predecessor 9);
-//  * ONE barrier per step instead of two: the planes are double buffered, and the loop is rotated -- iteration s multiplies
-//    step s (planes[s & 1], the x fragments split one iteration earlier) and, in the same basic block, splits step s + 1
-//    (vector ALU and LDS work the scheduler can place between the MFMAs), then waits for the DMA of step s + 2 and meets the
-//    barrier.  Three LDS stages of fp32 tiles (prefetch distance 2): a tile has a whole iteration to land;
-//  * ROWS = 16 rows per step keep a workgroup at <= 80 KB of LDS, i.e. two workgroups per CU whose phases interleave.
-// Everything else (row table, tap masks, t-inner row order, slab epilogue) is the DMA kernel's.
-constexpr int wgrad_f32s_lds(int bi, int bj, int rows, int ns) {
-  return ns * rows * (bi + bj) * 4 + 2 * (rows / 8) * 3 * bi * 16 + 2 * 256 * 12;
-}
-constexpr int wgrad_f32s_waves_per_simd(int bi, int bj, int rows, int ns) {
-  return 163840 / wgrad_f32s_lds(bi, bj, rows, ns) >= 2 ? 2 : 1;
-}
-
-template <int BI, int BJ, int ROWS, int NS>
-__global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(wgrad_f32s_waves_per_simd(BI, BJ, ROWS, NS)))) void conv_wgrad_f32s_kernel(WgradDmaArgs aa) {
-  const WgradArgs& a = aa.w;
-  constexpr int NW = 4, NT = 256;
-  constexpr int RBP = BI * 4, RBQ = BJ * 4;          // row bytes of the dY (P) and im2col (Q) tiles
-  constexpr int DP = RBP / 16, DQ = RBQ / 16;        // 16-byte slots per row
-  constexpr int QOFF = ROWS * RBP, BUFB = ROWS * (RBP + RBQ);
-  static_assert(QOFF % 1024 == 0 && BUFB % 1024 == 0, "1 KiB DMA pieces");
-  constexpr int PPC = QOFF / 1024, QPC = (BUFB - QOFF) / 1024;
-  constexpr int NPW = (PPC + NW - 1) / NW, NQW = (QPC + NW - 1) / NW;
-  constexpr int RT = NT, SPR = RT / ROWS;
-  constexpr int WJ = BJ / NW, TI = BI / 32, TJ = WJ / 32;
-  constexpr int NKS = ROWS / 16, NKH = ROWS / 8;     // MFMA k steps / 8-row k groups per step
-  constexpr int NPF = NKH * (BI / 64);               // dY fragment ops (8 rows x 64 columns) per step
-  constexpr int PLN = NKH * 3 * BI;                  // uint4 entries of one planes buffer
-  constexpr int D = NS - 1;
-  static_assert(TI >= 1 && TJ >= 1 && BI % 64 == 0 && ROWS % 16 == 0, "tile");
-  static_assert(D >= 2 && D < SPR, "the rotated loop needs a prefetch distance of two steps");
-  constexpr unsigned kOOB = 0x80000000u;
-
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * BUFB];
-  __shared__ uint2 rowtab[2][RT];
-  __shared__ unsigned rowdy[2][RT];
-  __shared__ uint4 planes[2 * PLN];
-
-  const ConvGeom& g = a.g;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int tile_j = bid % a.ntj; bid /= a.ntj;
-  const int tile_i = bid % a.nti;
-  const int split = bid / a.nti;
-  const int i0 = tile_i * BI, j0 = tile_j * BJ;
-  const int wj0 = wave * WJ;
-  const int m_begin = split * a.rows_per_split;
-  const int m_end = min(a.M, m_begin + a.rows_per_split);
-
-  const dma_rsrc_t x_rsrc = dma_make_rsrc(a.x, (unsigned)aa.x_bytes), dy_rsrc = dma_make_rsrc(a.dy, (unsigned)aa.dy_bytes);
-  const unsigned smem_base = lds_addr(smem);
-  const unsigned ldxb = (unsigned)a.ldx * 4u, ldyb = (unsigned)a.ldy * 4u;
-
-  int prow[NPW]; unsigned pcolb[NPW];
-#pragma unroll
-  for (int u = 0; u < NPW; ++u) {
-    const int sl = (wave + NW * u) * 64 + lane;
-    prow[u] = sl / DP;
-    const int n = i0 + (sl % DP) * 4;
-    pcolb[u] = n < a.CoutP ? (unsigned)n * 4u : kOOB;
-  }
-  int qrow[NQW]; unsigned qtb[NQW], qbit[NQW];
-#pragma unroll
-  for (int u = 0; u < NQW; ++u) {
-    const int sl = (wave + NW * u) * 64 + lane;
-    qrow[u] = sl / DQ;
-    const int col = j0 + (sl % DQ) * 4;
-    if (col < a.J) {
-      const int tap = col / g.CP, c = col - tap * g.CP;
-      const int dw = tap % g.kw, t2 = tap / g.kw, dh = t2 % g.kh, dt = t2 / g.kh;
-      qbit[u] = (1u << dt) | (1u << (8 + dh)) | (1u << (16 + dw));
-      qtb[u] = (unsigned)((dt * g.sH + dh) * g.sW + dw) * ldxb + (unsigned)c * 4u;
-    } else {
-      qbit[u] = 0xffffffffu;
-      qtb[u] = 0;
-    }
-  }
-
-  auto decode = [&](int rnd) {
-    const int q = m_begin + rnd * RT + tid;
-    uint2 e = make_uint2(0u, 0u);
-    unsigned dyo = kOOB;
-    if (q < m_end) {
-      const uint32_t m = a.perm.on ? perm_row(a.perm, (uint32_t)q) : (uint32_t)q;
-      dyo = m * ldyb;
-      const RowPos r = decode_row<MODE_FWD>(m, a.M, g);
-      auto range = [](int x0, int k, int lim) -> unsigned {
-        const int lo = max(0, -x0), hi = min(k, lim - x0);
-        return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
-      };
-      const unsigned bt = range(r.t0, g.kt, g.sT), bh = range(r.h0, g.kh, g.sH), bw = range(r.w0, g.kw, g.sW);
-      e.x = (unsigned)(r.base + (r.t0 * g.sH + r.h0) * g.sW + r.w0) * ldxb;
-      e.y = (bt && bh && bw) ? (bt | (bh << 8) | (bw << 16)) : 0u;
-    }
-    rowtab[rnd & 1][tid] = e;
-    rowdy[rnd & 1][tid] = dyo;
-  };
-  auto issue = [&](int s, int buf) {
-    const unsigned* dtab = rowdy[(s / SPR) & 1] + (s % SPR) * ROWS;
-    unsigned dyo[NPW];
-#pragma unroll
-    for (int u = 0; u < NPW; ++u) dyo[u] = dtab[prow[u]];
-#pragma unroll
-    for (int u = 0; u < NPW; ++u) {
-      if (PPC % NW != 0 && wave + NW * u >= PPC) break;
-      const unsigned off = (dyo[u] != kOOB && pcolb[u] != kOOB) ? dyo[u] + pcolb[u] : kOOB;
-      dma_load16(dy_rsrc, smem_base + buf * BUFB + (wave + NW * u) * 1024, off);
-    }
-    const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(rowtab[(s / SPR) & 1] + (s % SPR) * ROWS);
-    unsigned long long e[NQW];
-#pragma unroll
-    for (int u = 0; u < NQW; ++u) e[u] = tab[qrow[u] & (ROWS - 1)];
-#pragma unroll
-    for (int u = 0; u < NQW; ++u) {
-      if (QPC % NW != 0 && wave + NW * u >= QPC) break;
-      const unsigned ex = (unsigned)e[u], ey = (unsigned)(e[u] >> 32);
-      const unsigned off = ((ey & qbit[u]) == qbit[u]) ? ex + qtb[u] : kOOB;
-      dma_load16(x_rsrc, smem_base + buf * BUFB + QOFF + (wave + NW * u) * 1024, off);
-    }
-  };
-  int my_pieces = 0;
-#pragma unroll
-  for (int u = 0; u < NPW; ++u) my_pieces += (wave + NW * u < PPC) ? 1 : 0;
-#pragma unroll
-  for (int u = 0; u < NQW; ++u) my_pieces += (wave + NW * u < QPC) ? 1 : 0;
-
-  f32x16 acc[TI][TJ];
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int h = lane >> 5, l31 = lane & 31;
-  const int nsteps = (m_end - m_begin + ROWS - 1) / ROWS;
-
-  // split step s: this wave's share of the dY fragment ops -> planes[s & 1]; its own x fragments -> bq
-  auto split_step = [&](int s, Split3 (&bq)[NKS][TJ]) {
-    const unsigned char* tp = smem + (s % NS) * BUFB;
-    const unsigned char* tq = tp + QOFF;
-    uint4* pl = planes + (s & 1) * PLN;
-    static_assert(NPF % NW == 0 || NW % NPF == 0, "fragment ops deal evenly over the waves");
-#pragma unroll
-    for (int f0 = 0; f0 < NPF; f0 += NW) {
-      // fewer ops than waves: the spare waves repeat one (same values to the same place) rather than branch around it --
-      // the step takes as long as its slowest wave either way, and a branch would cut the block the scheduler interleaves
-      const int f = NPF % NW == 0 ? f0 + wave : (f0 + wave) % NPF;
-      {
-        const int kh = f % NKH, col = (f / NKH) * 64 + lane;
-        const unsigned char* src = tp + (kh * 8) * RBP + col * 4;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(src + e * RBP);
-        const Split3 s3 = split3w(v);
-        uint4* dst = pl + kh * 3 * BI + col;
-        dst[0] = __builtin_bit_cast(uint4, s3.hi);
-        dst[BI] = __builtin_bit_cast(uint4, s3.mid);
-        dst[2 * BI] = __builtin_bit_cast(uint4, s3.lo);
-      }
-    }
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(tq + (ks * 16 + 8 * h + e) * RBQ + (wj0 + j * 32 + l31) * 4);
-        bq[ks][j] = split3w(v);
-      }
-  };
-  auto mma_step = [&](int s, const Split3 (&bq)[NKS][TJ]) {
-    const uint4* pl = planes + (s & 1) * PLN;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      const int kh = ks * 2 + h;
-#pragma unroll
-      for (int i = 0; i < TI; ++i) {
-        const uint4* pa = pl + kh * 3 * BI + i * 32 + l31;
-        Split3 af;
-        af.hi = __builtin_bit_cast(bf16x8, pa[0]);
-        af.mid = __builtin_bit_cast(bf16x8, pa[BI]);
-        af.lo = __builtin_bit_cast(bf16x8, pa[2 * BI]);
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) mma_split3(af, bq[ks][j], acc[i][j]);
-      }
-    }
-  };
-  // iteration s (-1 <= s < nsteps): multiply step s, split step s + 1, prefetch step s + 1 + D, make step s + 2 visible.
-  // Steady iterations (0 <= s, s + 1 + D < nsteps: every part exists, no conditions) run steady_hand below; the first and the
-  // last D + 1 iterations take the conditional form `iteration`.
-  static_assert(PPC % NW == 0 && QPC % NW == 0, "every wave issues the same pieces per step (compile-time wait counts)");
-  constexpr int PIECES = PPC / NW + QPC / NW;
-  static_assert((D - 1) * PIECES <= 24, "counted wait");
-  auto wait_tail = [&](int tiles) { dma_wait_upto(tiles * PIECES); };
-  // The steady iteration in HAND-PLACED order (HAND): an in-order wave only fills the 24 idle issue cycles behind an MFMA
-  // with what follows it in ITS OWN instruction stream, and the compiler's scheduler clusters the MFMAs of a block (24 back to
-  // back, then the ~190 vector instructions of the split: matrix pipe and vector ALU take turns, PMC: matrix pipe 52 % busy
-  // with two waves per SIMD).  Here every MFMA is followed by one UNIT of the next step's work -- a pair of values split
-  // (9 vector instructions), the three plane stores of a dY fragment, or one DMA piece's address and issue -- and a
-  // sched_barrier(0) pins that order.  All LDS reads of the iteration are issued up front.
-  constexpr int NPFW = NPF >= NW ? NPF / NW : 1;                   // dY fragment ops per wave and step
-  constexpr int NM = NKS * TI * TJ * 6;                            // MFMAs per wave and step
-  constexpr int U_P = NPFW * 5, U_Q = NKS * TJ * 4, U_ALL = U_P + U_Q + PIECES;
-  auto steady_hand = [&](int s, int st_next, int st_issue, const Split3 (&bcur)[NKS][TJ], Split3 (&bnext)[NKS][TJ]) {
-    const int sn = s + 1;
-    if ((sn % SPR) == 0 && (sn + SPR) < nsteps) decode(sn / SPR + 1);
-    const uint4* pl = planes + (s & 1) * PLN;
-    uint4* pln = planes + (sn & 1) * PLN;
-    const unsigned char* tp = smem + st_next * BUFB;
-    const unsigned char* tq = tp + QOFF;
-    Split3 af[NKS][TI];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-      for (int i = 0; i < TI; ++i) {
-        const uint4* pa = pl + (ks * 2 + h) * 3 * BI + i * 32 + l31;
-        af[ks][i].hi = __builtin_bit_cast(bf16x8, pa[0]);
-        af[ks][i].mid = __builtin_bit_cast(bf16x8, pa[BI]);
-        af[ks][i].lo = __builtin_bit_cast(bf16x8, pa[2 * BI]);
-      }
-    float pv[NPFW][8], qv[NKS][TJ][8];
-    int pdst[NPFW];
-#pragma unroll
-    for (int f0 = 0; f0 < NPFW; ++f0) {
-      const int f = NPF % NW == 0 ? f0 * NW + wave : wave % NPF;
-      const int kh = f % NKH, col = (f / NKH) * 64 + lane;
-      pdst[f0] = kh * 3 * BI + col;
-      const unsigned char* src = tp + (kh * 8) * RBP + col * 4;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pv[f0][e] = *reinterpret_cast<const float*>(src + e * RBP);
-    }
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          qv[ks][j][e] = *reinterpret_cast<const float*>(tq + (ks * 16 + 8 * h + e) * RBQ + (wj0 + j * 32 + l31) * 4);
-    const int si = sn + D;
-    const unsigned* dtab = rowdy[(si / SPR) & 1] + (si % SPR) * ROWS;
-    const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(rowtab[(si / SPR) & 1] + (si % SPR) * ROWS);
-    unsigned dyo[NPW];
-    unsigned long long te[NQW];
-#pragma unroll
-    for (int u = 0; u < NPW; ++u) dyo[u] = dtab[prow[u]];
-#pragma unroll
-    for (int u = 0; u < NQW; ++u) te[u] = tab[qrow[u] & (ROWS - 1)];
-    const unsigned stage_base = smem_base + st_issue * BUFB;
-    __builtin_amdgcn_sched_barrier(0);
-    unsigned PH[NPFW][4], PM[NPFW][4], PL[NPFW][4], QH[NKS][TJ][4], QM[NKS][TJ][4], QL[NKS][TJ][4];
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
-    auto unit = [&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      if constexpr (k < U_P) {
-        constexpr int f = k / 5, q = k % 5;
-        if constexpr (q < 4) {
-          split3w_pair(pv[f][2 * q], pv[f][2 * q + 1], PH[f][q], PM[f][q], PL[f][q]);
-        } else {
-          uint4* dst = pln + pdst[f];
-          dst[0] = make_uint4(PH[f][0], PH[f][1], PH[f][2], PH[f][3]);
-          dst[BI] = make_uint4(PM[f][0], PM[f][1], PM[f][2], PM[f][3]);
-          dst[2 * BI] = make_uint4(PL[f][0], PL[f][1], PL[f][2], PL[f][3]);
-        }
-      } else if constexpr (k < U_P + U_Q) {
-        constexpr int idx = k - U_P, fr = idx / 4, q = idx % 4, ks = fr / TJ, j = fr % TJ;
-        split3w_pair(qv[ks][j][2 * q], qv[ks][j][2 * q + 1], QH[ks][j][q], QM[ks][j][q], QL[ks][j][q]);
-        // (pin the results HERE: their only reader is the next iteration, and the machine-sink pass otherwise moves the whole split
-        // behind the barrier into the successor block -- correct, but it is this placement between the MFMAs that is wanted)
-        asm volatile("" : "+v"(QH[ks][j][q]), "+v"(QM[ks][j][q]), "+v"(QL[ks][j][q]));
-        if constexpr (q == 3) {
-          const u32x4v vh = {QH[ks][j][0], QH[ks][j][1], QH[ks][j][2], QH[ks][j][3]};
-          const u32x4v vm = {QM[ks][j][0], QM[ks][j][1], QM[ks][j][2], QM[ks][j][3]};
-          const u32x4v vl = {QL[ks][j][0], QL[ks][j][1], QL[ks][j][2], QL[ks][j][3]};
-          bnext[ks][j].hi = __builtin_bit_cast(bf16x8, vh);
-          bnext[ks][j].mid = __builtin_bit_cast(bf16x8, vm);
-          bnext[ks][j].lo = __builtin_bit_cast(bf16x8, vl);
-        }
-      } else {
-        constexpr int u = k - U_P - U_Q;
-        if constexpr (u < NPW) {
-          const unsigned off = (dyo[u] != kOOB && pcolb[u] != kOOB) ? dyo[u] + pcolb[u] : kOOB;
-          dma_load16(dy_rsrc, stage_base + (wave + NW * u) * 1024, off);
-        } else {
-          constexpr int v = u - NPW;
-          const unsigned ex = (unsigned)te[v], ey = (unsigned)(te[v] >> 32);
-          const unsigned off = ((ey & qbit[v]) == qbit[v]) ? ex + qtb[v] : kOOB;
-          dma_load16(x_rsrc, stage_base + QOFF + (wave + NW * v) * 1024, off);
-        }
-      }
-    };
-    static_for<NM>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      constexpr int blk = m / 6, prod = m % 6, j = blk % TJ, i = (blk / TJ) % TI, ks = blk / (TJ * TI);
-      const Split3& A = af[ks][i];
-      const Split3& B = bcur[ks][j];
-      if constexpr (prod == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.mid, B.mid, acc[i][j], 0, 0, 0);
-      if constexpr (prod == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.lo, acc[i][j], 0, 0, 0);
-      if constexpr (prod == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.lo, B.hi, acc[i][j], 0, 0, 0);
-      if constexpr (prod == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.mid, acc[i][j], 0, 0, 0);
-      if constexpr (prod == 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.mid, B.hi, acc[i][j], 0, 0, 0);
-      if constexpr (prod == 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.hi, B.hi, acc[i][j], 0, 0, 0);
-      constexpr int k0 = (m * U_ALL + NM - 1) / NM, k1 = ((m + 1) * U_ALL + NM - 1) / NM;     // units of this slot
-      static_for<(k1 - k0)>([&](auto dc) { unit(std::integral_constant<int, k0 + decltype(dc)::value>()); });
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    if constexpr (D == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-    else wait_tail(D - 1);
-    __syncthreads();
-  };
-  // the first and the last D + 1 iterations: every part behind its condition (compiler-scheduled)
-  auto iteration = [&](int s, const Split3 (&bcur)[NKS][TJ], Split3 (&bnext)[NKS][TJ]) {
-    const int sn = s + 1;
-    if (sn < nsteps && (sn % SPR) == 0 && (sn + SPR) < nsteps) decode(sn / SPR + 1);
-    if (sn + D < nsteps) issue(sn + D, (sn + D) % NS);          // its stage was last read by split_step(s), one barrier ago
-    if (s >= 0) mma_step(s, bcur);
-    if (sn < nsteps) split_step(sn, bnext);
-    if (sn + 1 < nsteps) wait_tail(min(D - 1, nsteps - 2 - sn));  // step s + 2 has landed (this wave's pieces)
-    __syncthreads();
-  };
-
-  decode(0);
-  if (SPR < nsteps) decode(1);                       // (the loop decodes round r + 1 at the first step of round r, r >= 1)
-  __syncthreads();
-  for (int t = 0; t < D && t < nsteps; ++t) issue(t, t);
-  wait_tail(min(D - 1, nsteps - 1));                 // step 0 has landed
-  __syncthreads();
-  Split3 b0[NKS][TJ], b1[NKS][TJ];
-  {
-    // iteration -1 without its decode (round 1 is decoded above)
-    if (D < nsteps) issue(D, D % NS);
-    split_step(0, b0);
-    if (1 < nsteps) wait_tail(min(D - 1, nsteps - 2));
-    __syncthreads();
-  }
-  // steady iterations: s + 1 + D < nsteps, in pairs (the x fragments alternate between two register sets)
-  const int n_steady = max(0, nsteps - 1 - D) & ~1;
-  int s = 0;
-  {
-    int st_next = 1 % NS, st_issue = (1 + D) % NS;               // stages of steps s + 1 and s + 1 + D at s = 0
-    auto adv = [&] { st_next = st_next + 1 == NS ? 0 : st_next + 1; st_issue = st_issue + 1 == NS ? 0 : st_issue + 1; };
-    for (; s < n_steady; s += 2) {
-      steady_hand(s, st_next, st_issue, b0, b1); adv();
-      steady_hand(s + 1, st_next, st_issue, b1, b0); adv();
-    }
-  }
-  for (; s < nsteps; s += 2) {
-    iteration(s, b0, b1);
-    if (s + 1 < nsteps) iteration(s + 1, b1, b0);
-  }
-
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-      wgrad_store_block(a, split, i0 + i * 32, j0 + wj0 + j * 32 + l31, h, acc[i][j]);
-}
-
-// ------------------------------------------------------------------------------------------
 // host side
 static bool fill_geom(const dv_conv_desc* d, int mode, ConvGeom& g) {
   g.kt = d->kt; g.kh = d->kh; g.kw = d->kw;
@@ -2426,8 +1678,38 @@ static void launch_ks(int bn, ConvArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL((conv_gemm_ks_kernel<MODE, 64, 3>), dim3(grid), dim3(256), 0, s, a);
 }
 
+// the ConvArgs fields the kernel-choice queries look at (no pointers: nothing is launched)
+static void query_args(const dv_conv_desc* d, int dgrad, ConvArgs& a) {
+  fill_geom(d, dgrad ? MODE_DGRAD : MODE_FWD, a.g);
+  a.M = dgrad ? d->N * d->Ti * d->Hi * d->Wi : d->N * d->To * d->Ho * d->Wo;
+  a.N = dgrad ? d->Cin : d->Cout;
+  a.NP = dgrad ? d->cin_pitch : d->cout_pitch;
+  a.ldo = dgrad ? d->ldx : d->ldy;
+  a.flags = d->flags & (dgrad ? (DV_W3 | DV_ACCUM) : (DV_W3 | DV_BIAS | DV_RELU | DV_SIGMOID | DV_STATS));
+  a.cls_on = 0;
+  a.bn_x = nullptr;
+  const int64_t ob = (((int64_t)a.M - 1) * a.ldo + a.NP) * 4;
+  a.out_bytes = (d->dtype == DV_F32 && ob < (1ll << 31)) ? (int)ob : 0;
+}
+
+// 0: conv_gemm / conv_gemm_ks; 1 / 2: the LDS-staged input-tile kernel (conv_tap.hip), spatial / temporal form
+static int tap_choice(const dv_conv_desc* d, int dgrad) {
+  if (d->dtype != DV_F32 || f32_exact() || !(d->flags & DV_W3)) return 0;
+  if (d->st > 1 || d->sh > 1 || d->sw > 1) return 0;
+  ConvArgs a;
+  query_args(d, dgrad, a);
+  trim_dead_taps(a, dgrad ? MODE_DGRAD : MODE_FWD, d->dtype);
+  return dvt_conv_tap_kind(&a, dgrad ? MODE_DGRAD : MODE_FWD);
+}
+
+extern "C" int dv_conv3d_tap_kind(const dv_conv_desc* d, int32_t dgrad) {
+  if (!d || check_desc(d)) return 0;
+  return tap_choice(d, dgrad);
+}
+
 extern "C" int dv_conv3d_tile_rows(const dv_conv_desc* d) {
   if (!d) return DV_EINVAL;
+  if (!check_desc(d) && tap_choice(d, 0)) return 256;
   const int64_t m = (int64_t)d->N * d->To * d->Ho * d->Wo;
   int bm, bn;
   pick_tile(d->dtype, (int)m, d->cout_pitch, bm, bn);
@@ -2509,6 +1791,7 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   const int esz = d->dtype == DV_F32 ? 4 : 2;
   if ((d->ldx * esz) % gvb || (a.ldw * esz) % gvb) return DV_EALIGN;
   trim_dead_taps(a, MODE_FWD, d->dtype);
+  if (d->dtype == DV_F32 && w3 && dvt_conv_tap_launch(&a, MODE_FWD, stream)) return dv_launch_status();
   int bm, bn;
   pick_tile(d->dtype, a.M, a.NP, bm, bn);
   a.ntn = (a.NP + bn - 1) / bn;
@@ -2671,6 +1954,7 @@ static int dgrad_impl(const dv_conv_desc* d, const void* dy, const void* wd, voi
     return dv_launch_status();
   }
   trim_dead_taps(a, MODE_DGRAD, d->dtype);
+  if (d->dtype == DV_F32 && w3 && dvt_conv_tap_launch(&a, MODE_DGRAD, stream)) return dv_launch_status();
   int bm, bn;
   pick_tile(d->dtype, a.M, a.NP, bm, bn);
   a.ntn = (a.NP + bn - 1) / bn;
@@ -2702,15 +1986,14 @@ static const WgradCfg kWgBf16[] = {{128, 128, 2, 2, 3}, {64, 256, 1, 4, 3}, {128
 // (f32 split mode: a two-wave 64 x 128 workgroup with 64 x 64 wave tiles -- one fragment split per 32x32 block instead of
 // 1.5 -- was measured slower than the four-wave one with 32 x 64 wave tiles: 950 vs 827 us on the 7x1x1 stem layer)
 static const WgradCfg kWgF32[] = {{128, 128, 2, 2, 2}, {64, 128, 2, 2, 2}};
-// conv_wgrad_f32s_kernel<BI, BJ, ROWS, NS> instantiations (the fp32 split mode's second weight-gradient form)
-struct WgradF32sCfg { int BI, BJ, ROWS, NS; };
-static const WgradF32sCfg kWgF32s[] = {{64, 256, 16, 3}, {64, 256, 32, 3}, {128, 128, 16, 3}, {128, 128, 32, 3}, {128, 256, 16, 3},
-                                       {64, 128, 16, 3}};
-static const int kNWgF32s = 6;
+// conv_wgrad_f32s_kernel (the fp32 split mode's second weight-gradient form) lives in conv_experiments.hip: opt-in only
+int dvx_wgrad_f32s_lds_bytes(int cfg);
+void dvx_wgrad_f32s_tile(int cfg, int* bi, int* bj);
+void dvx_launch_wgrad_f32s(int cfg, const void* args, int grid, void* stream);
 
 struct WgradPlan {
   int BI, BJ, nti, ntj, splits, rows_per_split, gvb, cfg;
-  int f32s;                   // >= 0: conv_wgrad_f32s_kernel configuration kWgF32s[f32s]
+  int f32s;                   // >= 0: conv_wgrad_f32s_kernel configuration (conv_experiments.hip)
   bool dma;
   long long slab_stride;      // elements
 };
@@ -2731,17 +2014,16 @@ static WgradPlan plan_wgrad(const dv_conv_desc* d) {
   int per_cu = 3;
   p.cfg = -1;
   p.f32s = -1;
-  // DUALVAR_WGRAD_F32S = 0 .. 5: conv_wgrad_f32s_kernel configuration kWgF32s[.] for every fp32 weight gradient (sweeps:
-  // tools/wgrad_sweep.sh).  Not selected by default: isolated it gains 8 - 10 % on the layers whose shape its tiles fit
-  // (128-channel layers on 128 x 128, the 7x1x1 stem conv on 64 x 256) and nothing elsewhere, and a per-layer rule built
-  // on that measured 19.39 vs 19.39 ms on the whole step ("fp32 weight gradient: what bounds it").
+  // DUALVAR_WGRAD_F32S = 0 | 2: conv_wgrad_f32s_kernel (conv_experiments.hip) in its 64 x 256 / 128 x 128 form for every fp32
+  // weight gradient (sweeps: tools/wgrad_sweep.sh).  Not selected by default: isolated it gains 8 - 10 % on the layers whose
+  // shape its tiles fit (128-channel layers on 128 x 128, the 7x1x1 stem conv on 64 x 256) and nothing elsewhere, and a
+  // per-layer rule built on that measured 19.39 vs 19.39 ms on the whole step ("Round 3").
   static const int f32s_force = env_int("DUALVAR_WGRAD_F32S", -1);
-  const int f32s_pick = f32s_force >= 0 && f32s_force < kNWgF32s ? f32s_force : -1;
+  const int f32s_pick = (f32s_force == 0 || f32s_force == 2) ? f32s_force : -1;
   if (p.dma && d->dtype == DV_F32 && !f32_exact() && f32s_pick >= 0) {
-    const WgradF32sCfg& k = kWgF32s[f32s_pick];
     p.f32s = f32s_pick;
-    p.BI = k.BI; p.BJ = k.BJ;
-    per_cu = std::max(1, std::min(2, 163840 / wgrad_f32s_lds(k.BI, k.BJ, k.ROWS, k.NS)));
+    dvx_wgrad_f32s_tile(f32s_pick, &p.BI, &p.BJ);
+    per_cu = std::max(1, std::min(2, 163840 / dvx_wgrad_f32s_lds_bytes(f32s_pick)));
   } else if (p.dma) {
     // candidate with the least estimated time: LDS-fill bytes at ~18 TB/s chip-wide against padded MFMA work at ~2/3 of
     // peak; a configuration whose tiles cannot even fill the chip once (few rows) pays for the idle CUs
@@ -2869,17 +2151,8 @@ static int wgrad_impl(const dv_conv_desc* d, const void* x, const void* dy, floa
     }
 #define WGD(T_, BI_, BJ_, WI_, WJ_, NS_, ...) \
   hipLaunchKernelGGL((conv_wgrad_dma_kernel<T_, BI_, BJ_, WI_, WJ_, NS_, ##__VA_ARGS__>), dim3(grid), dim3(WI_ * WJ_ * 64), 0, s, aa)
-#define WGS(BI_, BJ_, R_, NS_) \
-  hipLaunchKernelGGL((conv_wgrad_f32s_kernel<BI_, BJ_, R_, NS_>), dim3(grid), dim3(256), 0, s, aa)
     if (p.f32s >= 0) {
-      switch (p.f32s) {
-        case 0: WGS(64, 256, 16, 3); break;
-        case 1: WGS(64, 256, 32, 3); break;
-        case 2: WGS(128, 128, 16, 3); break;
-        case 3: WGS(128, 128, 32, 3); break;
-        case 4: WGS(128, 256, 16, 3); break;
-        default: WGS(64, 128, 16, 3); break;
-      }
+      dvx_launch_wgrad_f32s(p.f32s, &aa, grid, s);
     } else if (d->dtype == DV_BF16) {
       switch (p.cfg) {
         case 0: WGD(bf16_t, 128, 128, 2, 2, 3); break;
@@ -2898,7 +2171,6 @@ static int wgrad_impl(const dv_conv_desc* d, const void* x, const void* dy, floa
       }
     }
 #undef WGD
-#undef WGS
   } else {
 #define WG_LAUNCH(T_, G_)                                                                                   \
   do {                                                                                                      \

@@ -1,0 +1,425 @@
+// LDS-staged input tiles for the separable convolutions (fp32 split mode): the stride-1 "same" 1x3x3 and 3x1x1 convs of
+// backbone/s3dg.py:30-65 (STConv3d: 1xkxk -> BN -> ReLU -> kx1x1) and backbone/r21d.py:11-70 -- forward and data gradient.
+//
+// conv_gemm_kernel (conv.hip) is a per-tap implicit GEMM: every (tap, 16-channel) K tile costs one global -> LDS DMA round of the
+// activation tile and, in the fp32 mode, one split of its fragments into bf16 triples; the round-3 ablation priced those two at
+// 172 of the 523 us of Conv_2c's 1x3x3 forward, and nothing overlapped the matrix pipe.  Here a workgroup stages the 16-channel
+// slab of its 256 output positions ONCE per channel chunk -- with the halo its taps reach --, splits it ONCE into bf16 planes in
+// MFMA-fragment order, and every tap's A fragments are then plain ds_read_b128 at a row offset into those planes:
+//   * spatial (1 x kh x kw): the tile is 256 consecutive tensor rows; the planes hold rows [m0 - HALO, m0 + 256 + HALO), HALO =
+//     ph * W + pw.  A tap is the row offset dh' * W + dw'.  Rows of the image border (a tap that leaves the plane) read a shared
+//     48-byte ZERO slot instead: one v_cndmask on the LDS address per (row block, tap), no arithmetic on the data, no padded
+//     staging layout -- positions are tensor rows, tiles may straddle planes and clips.
+//   * temporal (kt x 1 x 1): the tile is P = 256 / T pixels x all T frames (T = 2, 4, 8), no halo; a tap is the planes of the
+//     neighbouring frame, and the (frame, tap) pairs that leave the clip are not multiplied at all (wave-uniform skip): 10 of
+//     12 for 3x1x1 on four frames.
+// Split instructions and activation loads per MFMA drop by the number of taps (x 256 / (256 + 2 HALO) for the halo); the
+// weights, pre-split in fragment order (dv_pack_w3), are streamed per (chunk, tap) by LDS DMA exactly as in conv_gemm_kernel.
+// LDS: NS x BN x 96 B of weight stages + (256 + 2 HALO) x 96 B of planes + the zero slot = 43 .. 54 KB: three workgroups per CU
+// (round 3 measured co-residency worth 1.36x on these kernels: the reason the 96 KB prototype of that round lost).
+//
+// Planes layout: [k half h][position][hi | mid | lo][8 bf16] = 48 B per (h, position): lane (l31, h) of a 32-row block reads
+// position base + l31 -- stride 48 B, conflict-free for ds_read_b128 at ANY base (3 is odd: the 16 lanes of a read group hit 16
+// different 16-byte slots), so a tap offset costs nothing.
+//
+// Activations go global -> VGPR -> split -> LDS (not LDS-DMA: the fp32 staging copy would cost 16 - 24 KB of LDS per stage and a
+// resident workgroup).  The loads of chunk c + 1 are issued at the start of chunk c and consumed at its end; they are inline
+// assembly with their own counted s_waitcnt so that the compiler's wait-count pass, which cannot see the LDS-DMA weight pieces,
+// does not drain the weight pipeline in front of them.
+#include "conv_common.hpp"
+
+namespace {
+
+constexpr int kTapMax = 9;
+
+struct TapArgs {
+  const void* src;        // x (forward) or dY (data gradient): [M][lds_] fp32
+  const void* w;          // pre-split weights (dv_pack_w3): forward layout for fwd, dgrad layout for dgrad
+  void* out;              // [M][ldo] fp32
+  float* stats;           // forward + DV_STATS: [2][N][ceil(M / 256)] BatchNorm partials
+  int M, N, NP;           // rows (stride 1, same: input rows == output rows), real columns, columns to write
+  int lds_, ldo, ldw;     // pitches in elements; ldw = padded row count of the pre-split weights
+  int ntn, flags;
+  int src_bytes, w_bytes, out_bytes;
+  int CP;                 // K per tap (channel pitch of src), multiple of 16
+  int npos, halo;         // staged positions per tile; positions in front of the tile's first row (spatial)
+  int tapoff[kTapMax];    // spatial: row offset of tap t; temporal: frame offset of tap t
+  int sdh[kTapMax], sdw[kTapMax];   // spatial: signed displacement of tap t along h / w
+  int H, W;
+  FastDiv fW, fH;
+  int T, S, P, lgP, NQ;   // temporal: frames, pixels per frame, pixels per tile (256 / T), log2 P, N * S
+  FastDiv fS;
+};
+
+// one 16-byte global load into registers, invisible to the compiler's wait-count pass (see the header comment)
+__device__ __forceinline__ void gload16(f32x4& dst, dma_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void gload16_hi(f32x4& dst, dma_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+// KIND 0: spatial (1 x kh x kw, NTAPS = kh * kw);  KIND 1: temporal (kt x 1 x 1, NTAPS = kt)
+// NU: staging units (8 channels of one position = 32 B) per thread: ceil(2 * npos / 256)
+template <int KIND, int NTAPS, int BN, int NS, int NU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_tap_kernel(TapArgs a) {
+  constexpr int BM = 256, NW = 4, TM = 2, TN = BN / 32;
+  constexpr int B_BYTES = BN * 96, BPC = B_BYTES / 1024;       // one weight stage: hi|mid|lo of both k halves, in 1 KiB DMA pieces
+  static_assert(B_BYTES % 1024 == 0, "weight stage in 1 KiB pieces");
+  constexpr int NPW = (BPC + NW - 1) / NW;                      // pieces per wave and stage (the last round may be partial)
+  constexpr int D = NS - 1;                                     // prefetch distance of the weight pipeline (steps)
+  static_assert(D >= 1 && NTAPS > D, "the staging loads of a chunk are complete once tap D of that chunk has been waited for");
+  constexpr int NSL = 2 * NU;                                   // staging loads per thread and chunk
+  static_assert((D - 1) * NPW + NSL <= 24, "counted wait");
+  constexpr unsigned kOOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char dsm[];
+  const int npos = a.npos;
+  const unsigned planes_off = NS * B_BYTES;                     // [2][npos][48]
+  const unsigned zero_off = planes_off + 2u * (unsigned)npos * 48u;       // 64 bytes of zeros
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int lbid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_n = lbid % a.ntn, tile_m = lbid / a.ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const dma_rsrc_t src_rs = dma_make_rsrc(a.src, (unsigned)a.src_bytes), w_rs = dma_make_rsrc(a.w, (unsigned)a.w_bytes);
+  const unsigned ldb = (unsigned)a.lds_ * 4u;
+  const unsigned dsm_base = lds_addr(dsm);
+
+  // ---- staging roles: unit u = tid + 256 k -> (position u >> 1, channel half u & 1)
+  unsigned soff[NU], pwr[NU];
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const int u = tid + 256 * k, pidx = u >> 1, half = u & 1;
+    bool ok = pidx < npos;
+    unsigned row = 0;
+    if constexpr (KIND == 0) {
+      const int r = m0 - a.halo + pidx;
+      ok = ok && r >= 0 && r < a.M;
+      row = (unsigned)r;
+    } else {
+      const int f = pidx >> a.lgP, p = pidx & (a.P - 1);
+      const unsigned q = (unsigned)(tile_m * a.P + p);
+      ok = ok && (int)q < a.NQ;
+      const unsigned n = fd_div(q, a.fS);
+      row = q + n * (unsigned)((a.T - 1) * a.S) + (unsigned)(f * a.S);
+    }
+    soff[k] = ok ? row * ldb + (unsigned)half * 32u : kOOB;
+    pwr[k] = pidx < npos ? planes_off + (unsigned)(half * npos + pidx) * 48u : 0xffffffffu;
+  }
+  f32x4 sreg[NU][2];
+  auto stage_issue = [&](int c0) {
+    const unsigned so = (unsigned)c0 * 4u;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      gload16(sreg[k][0], src_rs, soff[k], so);
+      gload16_hi(sreg[k][1], src_rs, soff[k], so);
+    }
+  };
+  // split the staged slab into the planes (the caller has made sure that nobody reads the planes any more)
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      if (pwr[k] != 0xffffffffu) {
+        const float v[8] = {sreg[k][0].x, sreg[k][0].y, sreg[k][0].z, sreg[k][0].w, sreg[k][1].x, sreg[k][1].y, sreg[k][1].z, sreg[k][1].w};
+        const Split3 s3 = split3(v);
+        bf16x8* dst = reinterpret_cast<bf16x8*>(dsm + pwr[k]);
+        dst[0] = s3.hi; dst[1] = s3.mid; dst[2] = s3.lo;
+      }
+    }
+  };
+  // the staging loads are older than every weight piece still in flight at the points this is called from: <= 2 * NPW pieces
+  auto stage_wait = [&]() {
+    static_assert(NU <= 3, "operand list");
+    if constexpr (NU == 1) asm volatile("s_waitcnt vmcnt(4)" : "+v"(sreg[0][0]), "+v"(sreg[0][1])::"memory");
+    else if constexpr (NU == 2)
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(sreg[0][0]), "+v"(sreg[0][1]), "+v"(sreg[1][0]), "+v"(sreg[1][1])::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(4)"
+                   : "+v"(sreg[0][0]), "+v"(sreg[0][1]), "+v"(sreg[1][0]), "+v"(sreg[1][1]), "+v"(sreg[2][0]), "+v"(sreg[2][1])::"memory");
+  };
+  static_assert(2 * NPW <= 4, "stage_wait's count");
+
+  // ---- weight pieces of this wave: LDS byte o of a stage <- W3 byte ((K tile * 2 + hh) * ldw + n0) * 48 + (o mod BN * 48)
+  unsigned woff[NPW];
+  int pieces = 0;
+#pragma unroll
+  for (int u = 0; u < NPW; ++u) {
+    const int p = wave + NW * u;
+    const unsigned o = (unsigned)p * 1024u + (unsigned)lane * 16u;
+    const unsigned hh = o / (BN * 48u), rem = o - hh * (BN * 48u);
+    woff[u] = (hh * (unsigned)a.ldw + (unsigned)n0) * 48u + rem;
+    pieces += p < BPC ? 1 : 0;
+  }
+  const int NC = a.CP >> 4, nsteps = NC * NTAPS;
+  auto w_issue = [&](int step, int stage) {
+    const int c = step / NTAPS, t = step - c * NTAPS;
+    const unsigned kt = (unsigned)(t * a.CP + c * 16) >> 4;
+#pragma unroll
+    for (int u = 0; u < NPW; ++u)
+      if (wave + NW * u < BPC)
+        dma_load16(w_rs, dsm_base + stage * B_BYTES + (wave + NW * u) * 1024, woff[u] + kt * (unsigned)a.ldw * 96u);
+  };
+
+  // ---- A-fragment addressing
+  unsigned abase[TM];          // LDS byte offset of (h, position of this lane's row in block i) -- spatial: at tap offset 0
+  unsigned amask[TM];          // spatial: bit t set = tap t leaves the image for this lane's row
+  int bfr[TM], bpb[TM];        // temporal: frame and 32-pixel block of row block i (wave-uniform)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    amask[i] = 0; bfr[i] = 0; bpb[i] = 0;
+    if constexpr (KIND == 0) {
+      const int rloc = 64 * wave + 32 * i + l31;
+      abase[i] = planes_off + (unsigned)(h * npos + a.halo + rloc) * 48u;
+      uint32_t q_, ww, hh_, q2;
+      fd_divmod((uint32_t)(m0 + rloc), a.fW, q_, ww);
+      fd_divmod(q_, a.fH, q2, hh_);
+      unsigned inv = 0;
+#pragma unroll
+      for (int t = 0; t < NTAPS; ++t)
+        inv |= (((unsigned)((int)hh_ + a.sdh[t]) >= (unsigned)a.H || (unsigned)((int)ww + a.sdw[t]) >= (unsigned)a.W) ? 1u : 0u) << t;
+      amask[i] = inv;
+    } else {
+      // balanced (frame, pixel block) pairs per wave: border frames have a tap less
+      if (a.T == 2) { bfr[i] = i; bpb[i] = wave; }
+      else if (a.T == 4) { bfr[i] = i == 0 ? wave : (wave ^ 1); bpb[i] = i; }
+      else { bfr[i] = i == 0 ? wave : 7 - wave; bpb[i] = 0; }
+      abase[i] = planes_off + (unsigned)(h * npos + bpb[i] * 32 + l31) * 48u;
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const unsigned bbase = (unsigned)(h * BN + l31) * 48u;
+  auto compute = [&](int t, int stage) {
+    Split3 bf[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const bf16x8* pb = reinterpret_cast<const bf16x8*>(dsm + stage * B_BYTES + bbase + j * (32 * 48));
+      bf[j].hi = pb[0]; bf[j].mid = pb[1]; bf[j].lo = pb[2];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      unsigned ad;
+      if constexpr (KIND == 0) {
+        const unsigned at = abase[i] + (unsigned)(a.tapoff[t] * 48);
+        ad = ((amask[i] >> t) & 1u) ? zero_off : at;
+      } else {
+        const int fs = bfr[i] + a.tapoff[t];
+        if (fs < 0 || fs >= a.T) continue;                      // (wave-uniform) this tap leaves the clip for the whole block
+        ad = abase[i] + (unsigned)(fs * a.P) * 48u;
+      }
+      const bf16x8* pa = reinterpret_cast<const bf16x8*>(dsm + ad);
+      Split3 af;
+      af.hi = pa[0]; af.mid = pa[1]; af.lo = pa[2];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) mma_split3(af, bf[j], acc[i][j]);
+    }
+  };
+
+  // ---- prologue: chunk 0 into the planes, the zero slot, the first D weight stages
+  stage_issue(0);
+  if (tid < 4) *reinterpret_cast<f32x4*>(dsm + zero_off + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stage_wait();
+  stage_write();
+  for (int s = 0; s < D && s < nsteps; ++s) w_issue(s, s);
+  int cur = 0, nxt = D % NS;
+  for (int c = 0; c < NC; ++c) {
+    const bool more = c + 1 < NC;
+    if (more) stage_issue((c + 1) * 16);
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+      const int step = c * NTAPS + t;
+      // stage `cur` (step) has landed: younger than it are the next D - 1 steps' pieces and, for the first D taps of a chunk,
+      // the staging loads of the next chunk (issued at the chunk's start, after the pieces of step c * NTAPS + D - 1)
+      dma_wait_upto(min(D - 1, nsteps - 1 - step) * pieces + ((more && t < D) ? NSL : 0));
+      __syncthreads();                         // ... everybody's; stage `nxt` (step - 1) is free; t == 0: the planes are published
+      if (step + D < nsteps) w_issue(step + D, nxt);
+      compute(t, cur);
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    }
+    if (more) {
+      stage_wait();
+      __syncthreads();                         // every wave has read its last fragments of this chunk's planes
+      stage_write();
+    }
+  }
+
+  // ---------------- epilogue: fp32 tiles straight from the accumulators (the row term sits in voffset: range-checked)
+  float* red = reinterpret_cast<float*>(dsm);                   // statistics scratch: [NW][BN] + [BN] floats in the weight stages
+  const int flags = a.flags;
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+  const unsigned ldo4 = (unsigned)a.ldo * 4u;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    unsigned ro[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+      if constexpr (KIND == 0) {
+        const int m = m0 + 64 * wave + 32 * i + rl;
+        ro[r] = m < a.M ? (unsigned)m * ldo4 : kOOB;
+      } else {
+        const unsigned q = (unsigned)(tile_m * a.P + bpb[i] * 32 + rl);
+        const unsigned n = fd_div(q, a.fS);
+        ro[r] = (int)q < a.NQ ? (q + n * (unsigned)((a.T - 1) * a.S) + (unsigned)(bfr[i] * a.S)) * ldo4 : kOOB;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + j * 32 + l31;
+      const bool col_ok = col < a.NP;                           // (columns [N, NP) are pad lanes: their weights are zero rows)
+      const unsigned cb = (unsigned)col * 4u;
+      unsigned old[16];
+      if ((flags & DV_ACCUM) && col_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = __builtin_amdgcn_raw_buffer_load_b32(orsrc, (int)(ro[r] + cb), 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = ro[r] == kOOB ? 0.f : acc[i][j][r];           // rows past the end feed neither the output nor the statistics
+        acc[i][j][r] = v;
+        if (col_ok) {
+          if (flags & DV_ACCUM) v += __builtin_bit_cast(float, old[r]);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, (int)(ro[r] + cb), 0, 0);
+        }
+      }
+    }
+  }
+  if (flags & DV_STATS) {
+    // per column: sum and M2 about the tile mean of the values as stored (two passes over the accumulators), [2][N][tiles]
+    const int n_mt = (a.M + BM - 1) / BM;
+    const int rows_here = min(BM, a.M - m0);
+    float* meanb = red + NW * BN;
+    __syncthreads();                                            // the weight stages are free
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+      s += __shfl_xor(s, 32);
+      if (h == 0) red[wave * BN + j * 32 + l31] = s;
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[w * BN + tid];
+      meanb[tid] = s / (float)rows_here;
+      if (n0 + tid < a.N) a.stats[(size_t)(n0 + tid) * n_mt + tile_m] = s;
+    }
+    __syncthreads();
+    // validity of this lane's rows again (ro[] is out of scope): bit r of vm[i]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float mu = meanb[j * 32 + l31];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+          bool ok;
+          if constexpr (KIND == 0) ok = m0 + 64 * wave + 32 * i + rl < a.M;
+          else ok = tile_m * a.P + bpb[i] * 32 + rl < a.NQ;
+          const float dlt = acc[i][j][r] - mu;
+          s += ok ? dlt * dlt : 0.f;
+        }
+      s += __shfl_xor(s, 32);
+      if (h == 0) red[wave * BN + j * 32 + l31] = s;
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.N) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[w * BN + tid];
+      a.stats[(size_t)(a.N + n0 + tid) * n_mt + tile_m] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+// 0: not applicable; 1: spatial; 2: temporal
+static int tap_kind(const ConvArgs& a, int mode) {
+  static const int on = getenv("DUALVAR_CONV_TAP") ? atoi(getenv("DUALVAR_CONV_TAP")) : 1;
+  static const int min_grid = getenv("DUALVAR_CONV_TAP_GRID") ? atoi(getenv("DUALVAR_CONV_TAP_GRID")) : 512;
+  if (!on) return 0;
+  const ConvGeom& g = a.g;
+  if (!(a.flags & DV_W3) || (a.flags & (DV_BIAS | DV_RELU | DV_SIGMOID)) || a.cls_on || a.bn_x != nullptr || a.out_bytes <= 0) return 0;
+  if (mode != MODE_FWD && (a.flags & DV_STATS)) return 0;
+  if (g.st != 1 || g.sh != 1 || g.sw != 1 || g.CP % 16 != 0) return 0;
+  if (g.rT != g.sT || g.rH != g.sH || g.rW != g.sW) return 0;
+  const int64_t grid = (int64_t)((a.M + 255) / 256) * ((a.NP + 63) / 64);
+  if (grid < min_grid) return 0;
+  if (g.kt == 1 && g.kh == 3 && g.kw == 3 && g.ph == 1 && g.pw == 1) {
+    if (g.sW + 1 > 57 || g.sH < 2 || g.sW < 2) return 0;         // planes of 256 + 2 (W + 1) positions: three workgroups per CU
+    return 1;
+  }
+  if (g.kt == 3 && g.kh == 1 && g.kw == 1 && g.pt == 1 && (g.sT == 2 || g.sT == 4 || g.sT == 8)) return 2;
+  return 0;
+}
+
+template <int KIND, int NTAPS, int NU>
+static void launch_tap(const TapArgs& t, int grid, size_t lds, hipStream_t s) {
+  hipLaunchKernelGGL((conv_tap_kernel<KIND, NTAPS, 64, 3, NU>), dim3(grid), dim3(256), lds, s, t);
+}
+
+}  // namespace
+
+// entry points for conv.hip (the argument block is conv_common.hpp's ConvArgs, passed by address)
+int dvt_conv_tap_kind(const void* conv_args, int mode) { return tap_kind(*static_cast<const ConvArgs*>(conv_args), mode); }
+
+// launches the LDS-staged kernel for this problem if it is one of its forms; returns 1 when it did
+int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream) {
+  const ConvArgs& a = *static_cast<const ConvArgs*>(conv_args);
+  const int kind = tap_kind(a, mode);
+  if (!kind) return 0;
+  const ConvGeom& g = a.g;
+  TapArgs t;
+  t.src = a.src; t.w = a.w; t.out = a.out; t.stats = a.stats;
+  t.M = a.M; t.N = a.N; t.NP = a.NP; t.lds_ = a.lds_; t.ldo = a.ldo; t.ldw = a.ldw;
+  t.ntn = (a.NP + 63) / 64;
+  t.flags = a.flags & (DV_STATS | DV_ACCUM);
+  t.src_bytes = a.src_bytes; t.w_bytes = a.w_bytes; t.out_bytes = a.out_bytes;
+  t.CP = g.CP;
+  t.H = g.sH; t.W = g.sW; t.T = g.sT; t.S = g.sH * g.sW;
+  t.fW = make_fastdiv((uint32_t)g.sW); t.fH = make_fastdiv((uint32_t)g.sH); t.fS = make_fastdiv((uint32_t)t.S);
+  t.P = 256 / g.sT; t.lgP = 0;
+  while ((1 << t.lgP) < t.P) ++t.lgP;
+  t.NQ = a.M / g.sT;
+  const int sgn = mode == MODE_FWD ? 1 : -1;       // data gradient: dX[m] = sum_d dY[m + p - d] W_d
+  for (int i = 0; i < kTapMax; ++i) t.tapoff[i] = t.sdh[i] = t.sdw[i] = 0;
+  const int grid = t.ntn * ((a.M + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == 1) {
+    t.halo = g.ph * g.sW + g.pw;
+    t.npos = 256 + 2 * t.halo;
+    for (int dh = 0; dh < 3; ++dh)
+      for (int dw = 0; dw < 3; ++dw) {
+        const int tp = dh * 3 + dw;
+        t.sdh[tp] = sgn * (dh - g.ph); t.sdw[tp] = sgn * (dw - g.pw);
+        t.tapoff[tp] = t.sdh[tp] * g.sW + t.sdw[tp];
+      }
+    const size_t lds = 3 * 64 * 96 + (size_t)t.npos * 96 + 64;
+    if (2 * t.npos <= 512) launch_tap<0, 9, 2>(t, grid, lds, s);
+    else launch_tap<0, 9, 3>(t, grid, lds, s);
+  } else {
+    t.halo = 0;
+    t.npos = 256;
+    for (int dt = 0; dt < 3; ++dt) t.tapoff[dt] = sgn * (dt - g.pt);
+    const size_t lds = 3 * 64 * 96 + (size_t)t.npos * 96 + 64;
+    launch_tap<1, 3, 2>(t, grid, lds, s);
+  }
+  return 1;
+}

@@ -449,8 +449,11 @@ class HostStep:
 
 def _conv_kname(lib, d, dgrad, dt, gv=16):
     """label of the kernel dv_conv3d_fwd / dv_conv3d_dgrad will launch for this descriptor (bench.py / profiles group by it)"""
-    ks = int(lib.dv_conv3d_ksplit_cols(C.byref(d), int(dgrad)))
     mode = 'DGRAD' if dgrad else 'FWD'
+    tap = int(lib.dv_conv3d_tap_kind(C.byref(d), int(dgrad)))
+    if tap:
+        return 'conv_tap<%s,%s,%s,256,64>' % (dt, mode, 'sp' if tap == 1 else 'tm')
+    ks = int(lib.dv_conv3d_ksplit_cols(C.byref(d), int(dgrad)))
     if ks:
         return 'conv_gemm_ks<%s,%s,64,%d>' % (dt, mode, ks)
     return 'conv_gemm<%s,%s,%d,%d,%d>' % ((dt, mode, gv) + _tile_shape(lib, d, dgrad))

@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""Development aid for csrc/conv_tap.hip: correctness of the LDS-staged input-tile kernel against torch's conv3d on the CPU
+(float64) for a list of shapes, forward / data gradient / `+=`, with the BatchNorm partials, plus which kernel the library
+picked.  Run with DUALVAR_CONV_TAP_GRID=1 to force small problems onto it.
+
+    DUALVAR_CONV_TAP_GRID=1 python tools/tap_check.py
+"""
+import ctypes as C
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dualvar_amd import _lib as L          # noqa: E402
+from dualvar_amd import ops                # noqa: E402
+
+CASES = [
+    # N, Cin, T, H, W, Cout, k, p
+    (2, 16, 2, 9, 7, 64, (1, 3, 3), (0, 1, 1)),
+    (3, 32, 3, 14, 14, 96, (1, 3, 3), (0, 1, 1)),
+    (2, 64, 4, 28, 28, 192, (1, 3, 3), (0, 1, 1)),
+    (1, 16, 2, 56, 56, 40, (1, 3, 3), (0, 1, 1)),
+    (5, 48, 1, 5, 3, 24, (1, 3, 3), (0, 1, 1)),
+    (3, 32, 4, 9, 7, 64, (3, 1, 1), (1, 0, 0)),
+    (2, 192, 4, 14, 14, 192, (3, 1, 1), (1, 0, 0)),
+    (5, 16, 2, 7, 7, 48, (3, 1, 1), (1, 0, 0)),
+    (3, 32, 8, 6, 5, 80, (3, 1, 1), (1, 0, 0)),
+]
+
+
+def main():
+    L.require_device()
+    dev = torch.device('cuda:0')
+    lib = L.load()
+    DT = L.DV_F32
+    worst = 0.0
+    for (N, Ci, T, H, W, Co, k, p) in CASES:
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(N, Ci, T, H, W, generator=g)
+        w = torch.randn(Co, Ci, *k, generator=g) * (Ci * k[0] * k[1] * k[2]) ** -0.5
+        gy = torch.randn(N, Co, T, H, W, generator=g)
+        xr, wr = x.double().requires_grad_(True), w.double()
+        yr = F.conv3d(xr, wr, None, 1, p)
+        yr.backward(gy.double())
+        xa = ops.act_from_ncdhw(x.to(dev), DT, cpitch=(Ci + 15) // 16 * 16)
+        ya = ops.new_act(N, T, H, W, Co, DT, dev, zero=True)
+        d = ops.conv_desc(DT, xa, ya, k, (1, 1, 1), p, flags=L.DV_STATS | L.DV_W3)
+        kind = lib.dv_conv3d_tap_kind(C.byref(d), 0)
+        wp = ops.pack_weight(w.to(dev), xa.cpitch)
+        tiles = ops.stat_tiles(d)
+        stats = torch.zeros(2, Co, tiles, device=dev)
+        ops.conv_fwd(d, xa, ops.pack_w3(wp.view(Co, -1)), None, ya, stats)
+        torch.cuda.synchronize()
+        e_f = float((ops.act_to_ncdhw(ya).double().cpu() - yr.detach()).abs().max() / yr.detach().abs().max())
+        M = N * T * H * W
+        local = torch.zeros(2 * Co + 1, device=dev)
+        ops.call('dv_bn_reduce_stats', stats, tiles, ops.tile_rows(d), Co, M, Co, local)
+        mean_ref = yr.detach().mean(dim=(0, 2, 3, 4))
+        var_ref = yr.detach().var(dim=(0, 2, 3, 4), unbiased=False)
+        e_m = float(((local[:Co].cpu().double() / M) - mean_ref).abs().max() / var_ref.sqrt().max())
+        e_v = float(((local[Co:2 * Co].cpu().double() / M) - var_ref).abs().max() / var_ref.max())
+        # data gradient (+ accumulate)
+        cop = (Co + 15) // 16 * 16
+        dya = ops.act_from_ncdhw(gy.to(dev), DT, cpitch=cop)
+        taps = k[0] * k[1] * k[2]
+        wd = torch.zeros(Ci, taps, cop, device=dev)
+        wd[:, :, :Co] = w.to(dev).reshape(Co, Ci, taps).permute(1, 2, 0)
+        dxa = ops.new_act(N, T, H, W, Ci, DT, dev, cpitch=xa.cpitch, zero=True)
+        wd3 = ops.pack_w3(wd.view(Ci, -1))
+        dd = ops.conv_desc(DT, dxa, dya, k, (1, 1, 1), p, flags=L.DV_W3)
+        kind_d = lib.dv_conv3d_tap_kind(C.byref(dd), 1)
+        ops.conv_dgrad(dd, dya, wd3, dxa)
+        dd2 = ops.conv_desc(DT, dxa, dya, k, (1, 1, 1), p, flags=L.DV_W3 | L.DV_ACCUM)
+        ops.conv_dgrad(dd2, dya, wd3, dxa)
+        torch.cuda.synchronize()
+        e_d = float((ops.act_to_ncdhw(dxa).double().cpu() - 2 * xr.grad).abs().max() / (2 * xr.grad).abs().max())
+        pad_ok = float(dxa.buf[:, Ci:].abs().max()) == 0.0 if xa.cpitch > Ci else True
+        print('N%d Cin%d T%d %dx%d Cout%d k%s: kind fwd %d dgrad %d | fwd %.2e mean %.2e var %.2e dgrad(+=) %.2e pad %s' % (
+            N, Ci, T, H, W, Co, 'x'.join(map(str, k)), kind, kind_d, e_f, e_m, e_v, e_d, pad_ok), flush=True)
+        worst = max(worst, e_f, e_m, e_v, e_d)
+        assert pad_ok
+    print('worst', worst)
+    assert worst < 5e-6, worst
+    print('ok')
+
+
+if __name__ == '__main__':
+    main()
