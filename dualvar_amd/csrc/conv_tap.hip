@@ -30,8 +30,6 @@
 
 namespace {
 
-constexpr int kTapMax = 9;
-
 struct TapArgs {
   const void* src;        // x (forward) or dY (data gradient): [M][lds_] fp32
   const void* w;          // pre-split weights (dv_pack_w3): forward layout for fwd, dgrad layout for dgrad
@@ -42,14 +40,22 @@ struct TapArgs {
   int ntn, flags;
   int src_bytes, w_bytes, out_bytes;
   int CP;                 // K per tap (channel pitch of src), multiple of 16
-  int npos, halo;         // staged positions per tile; positions in front of the tile's first row (spatial)
-  int tapoff[kTapMax];    // spatial: row offset of tap t; temporal: frame offset of tap t
-  int sdh[kTapMax], sdw[kTapMax];   // spatial: signed displacement of tap t along h / w
+  int npos, npp, halo;    // staged positions per tile, pitch of a k-half plane; positions in front of the tile's first row (spatial)
+  int sgn;                // +1 forward, -1 data gradient (dX[m] = sum_d dY[m + p - d] W_d): a tap's displacement is sgn * (d - p)
   int H, W;
   FastDiv fW, fH;
   int T, S, P, lgP, NQ;   // temporal: frames, pixels per frame, pixels per tile (256 / T), log2 P, N * S
   FastDiv fS;
 };
+
+// displacement of tap t (compile-time index, natural order (dh, dw) / dt; 3 x 3 and 3 x 1 x 1 windows, padding 1): a handful of
+// scalar instructions from two kernel arguments -- a table in the argument block was re-loaded (s_load + lgkmcnt(0), which also
+// waits for every LDS read in flight) inside the hot loop
+template <int KIND> __device__ __forceinline__ int tap_dh(int t) { return KIND == 0 ? t / 3 - 1 : 0; }
+template <int KIND> __device__ __forceinline__ int tap_dw(int t) { return KIND == 0 ? t % 3 - 1 : 0; }
+template <int KIND> __device__ __forceinline__ int tap_off(const int sgn, const int W, int t) {
+  return KIND == 0 ? sgn * (tap_dh<0>(t) * W + tap_dw<0>(t)) : sgn * (t - 1);
+}
 
 // one 16-byte global load into registers, invisible to the compiler's wait-count pass (see the header comment)
 __device__ __forceinline__ void gload16(f32x4& dst, dma_rsrc_t rsrc, unsigned voff, unsigned soff) {
@@ -74,8 +80,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   constexpr unsigned kOOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(1024))) unsigned char dsm[];
   const int npos = a.npos;
-  const unsigned planes_off = NS * B_BYTES;                     // [2][npos][48]
-  const unsigned zero_off = planes_off + 2u * (unsigned)npos * 48u;       // 64 bytes of zeros
+  // positions between the two k-half planes: npos rounded up to 4 mod 8 -- a staging store instruction (ds_write_b128: groups of 8
+  // lanes, 32 banks) covers four positions x both halves, 48 B apart within a half; with the halves 3 * npp = 4 mod 8 slots apart
+  // the eight 16-byte slots of a group are all different (PMC of the first version: 22 % of the LDS cycles were conflicts)
+  const int npp = a.npp;
+  const unsigned planes_off = NS * B_BYTES;                     // [2][npp][48]
+  const unsigned zero_off = planes_off + 2u * (unsigned)npp * 48u;        // 64 bytes of zeros
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,6 +96,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const dma_rsrc_t src_rs = dma_make_rsrc(a.src, (unsigned)a.src_bytes), w_rs = dma_make_rsrc(a.w, (unsigned)a.w_bytes);
   const unsigned ldb = (unsigned)a.lds_ * 4u;
   const unsigned dsm_base = lds_addr(dsm);
+  const int tsgn = a.sgn, tW = a.W, tT = a.T, tP48 = a.P * 48;
 
   // ---- staging roles: unit u = tid + 256 k -> (position u >> 1, channel half u & 1)
   unsigned soff[NU], pwr[NU];
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       row = q + n * (unsigned)((a.T - 1) * a.S) + (unsigned)(f * a.S);
     }
     soff[k] = ok ? row * ldb + (unsigned)half * 32u : kOOB;
-    pwr[k] = pidx < npos ? planes_off + (unsigned)(half * npos + pidx) * 48u : 0xffffffffu;
+    pwr[k] = pidx < npos ? planes_off + (unsigned)(half * npp + pidx) * 48u : 0xffffffffu;
   }
   f32x4 sreg[NU][2];
   auto stage_issue = [&](int c0) {
@@ -117,15 +128,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       gload16_hi(sreg[k][1], src_rs, soff[k], so);
     }
   };
-  // split the staged slab into the planes (the caller has made sure that nobody reads the planes any more)
+  // split the staged slab (registers -> bf16 triples), then store the triples into the planes (the caller has made sure that
+  // nobody reads the planes any more)
+  Split3 s3r[NU];
+  auto stage_split = [&]() {
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const float v[8] = {sreg[k][0].x, sreg[k][0].y, sreg[k][0].z, sreg[k][0].w, sreg[k][1].x, sreg[k][1].y, sreg[k][1].z, sreg[k][1].w};
+      s3r[k] = split3(v);
+    }
+  };
   auto stage_write = [&]() {
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
       if (pwr[k] != 0xffffffffu) {
-        const float v[8] = {sreg[k][0].x, sreg[k][0].y, sreg[k][0].z, sreg[k][0].w, sreg[k][1].x, sreg[k][1].y, sreg[k][1].z, sreg[k][1].w};
-        const Split3 s3 = split3(v);
         bf16x8* dst = reinterpret_cast<bf16x8*>(dsm + pwr[k]);
-        dst[0] = s3.hi; dst[1] = s3.mid; dst[2] = s3.lo;
+        dst[0] = s3r[k].hi; dst[1] = s3r[k].mid; dst[2] = s3r[k].lo;
       }
     }
   };
@@ -171,21 +189,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     amask[i] = 0; bfr[i] = 0; bpb[i] = 0;
     if constexpr (KIND == 0) {
       const int rloc = 64 * wave + 32 * i + l31;
-      abase[i] = planes_off + (unsigned)(h * npos + a.halo + rloc) * 48u;
+      abase[i] = planes_off + (unsigned)(h * npp + a.halo + rloc) * 48u;
       uint32_t q_, ww, hh_, q2;
       fd_divmod((uint32_t)(m0 + rloc), a.fW, q_, ww);
       fd_divmod(q_, a.fH, q2, hh_);
       unsigned inv = 0;
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t)
-        inv |= (((unsigned)((int)hh_ + a.sdh[t]) >= (unsigned)a.H || (unsigned)((int)ww + a.sdw[t]) >= (unsigned)a.W) ? 1u : 0u) << t;
+        inv |= (((unsigned)((int)hh_ + a.sgn * tap_dh<0>(t)) >= (unsigned)a.H || (unsigned)((int)ww + a.sgn * tap_dw<0>(t)) >= (unsigned)a.W) ? 1u : 0u) << t;
       amask[i] = inv;
     } else {
       // balanced (frame, pixel block) pairs per wave: border frames have a tap less
       if (a.T == 2) { bfr[i] = i; bpb[i] = wave; }
       else if (a.T == 4) { bfr[i] = i == 0 ? wave : (wave ^ 1); bpb[i] = i; }
       else { bfr[i] = i == 0 ? wave : 7 - wave; bpb[i] = 0; }
-      abase[i] = planes_off + (unsigned)(h * npos + bpb[i] * 32 + l31) * 48u;
+      abase[i] = planes_off + (unsigned)(h * npp + bpb[i] * 32 + l31) * 48u;
     }
   }
 
@@ -198,30 +216,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const unsigned bbase = (unsigned)(h * BN + l31) * 48u;
-  auto compute = [&](int t, int stage) {
+  // `issue`: the weight DMA of step + D, called once this step's first fragment reads are on their way (the DMA's address
+  // arithmetic and m0 traffic then sit under the LDS latency instead of in front of it)
+  auto compute = [&](int t, int stage, auto&& issue) {
     Split3 bf[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const bf16x8* pb = reinterpret_cast<const bf16x8*>(dsm + stage * B_BYTES + bbase + j * (32 * 48));
       bf[j].hi = pb[0]; bf[j].mid = pb[1]; bf[j].lo = pb[2];
     }
+    bool issued = false;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       unsigned ad;
       if constexpr (KIND == 0) {
-        const unsigned at = abase[i] + (unsigned)(a.tapoff[t] * 48);
+        const unsigned at = abase[i] + (unsigned)(tap_off<0>(tsgn, tW, t) * 48);
         ad = ((amask[i] >> t) & 1u) ? zero_off : at;
       } else {
-        const int fs = bfr[i] + a.tapoff[t];
-        if (fs < 0 || fs >= a.T) continue;                      // (wave-uniform) this tap leaves the clip for the whole block
-        ad = abase[i] + (unsigned)(fs * a.P) * 48u;
+        const int fs = bfr[i] + tap_off<1>(tsgn, tW, t);
+        if (fs < 0 || fs >= tT) continue;                      // (wave-uniform) this tap leaves the clip for the whole block
+        ad = abase[i] + (unsigned)(fs * tP48);
       }
       const bf16x8* pa = reinterpret_cast<const bf16x8*>(dsm + ad);
       Split3 af;
       af.hi = pa[0]; af.mid = pa[1]; af.lo = pa[2];
+      if (!issued) { issue(); issued = true; }
 #pragma unroll
       for (int j = 0; j < TN; ++j) mma_split3(af, bf[j], acc[i][j]);
     }
+    if (!issued) issue();
   };
 
   // ---- prologue: chunk 0 into the planes, the zero slot, the first D weight stages
@@ -229,6 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (tid < 4) *reinterpret_cast<f32x4*>(dsm + zero_off + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   stage_wait();
+  stage_split();
   stage_write();
   for (int s = 0; s < D && s < nsteps; ++s) w_issue(s, s);
   int cur = 0, nxt = D % NS;
@@ -242,14 +266,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       // the staging loads of the next chunk (issued at the chunk's start, after the pieces of step c * NTAPS + D - 1)
       dma_wait_upto(min(D - 1, nsteps - 1 - step) * pieces + ((more && t < D) ? NSL : 0));
       __syncthreads();                         // ... everybody's; stage `nxt` (step - 1) is free; t == 0: the planes are published
-      if (step + D < nsteps) w_issue(step + D, nxt);
-      compute(t, cur);
+      compute(t, cur, [&] { if (step + D < nsteps) w_issue(step + D, nxt); });
       cur = cur + 1 == NS ? 0 : cur + 1;
       nxt = nxt + 1 == NS ? 0 : nxt + 1;
     }
     if (more) {
       stage_wait();
       __syncthreads();                         // every wave has read its last fragments of this chunk's planes
+      stage_split();                           // (splitting in front of the barrier instead was measured equal)
       stage_write();
     }
   }
@@ -398,27 +422,21 @@ int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream) {
   t.P = 256 / g.sT; t.lgP = 0;
   while ((1 << t.lgP) < t.P) ++t.lgP;
   t.NQ = a.M / g.sT;
-  const int sgn = mode == MODE_FWD ? 1 : -1;       // data gradient: dX[m] = sum_d dY[m + p - d] W_d
-  for (int i = 0; i < kTapMax; ++i) t.tapoff[i] = t.sdh[i] = t.sdw[i] = 0;
+  t.sgn = mode == MODE_FWD ? 1 : -1;
   const int grid = t.ntn * ((a.M + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
   if (kind == 1) {
     t.halo = g.ph * g.sW + g.pw;
     t.npos = 256 + 2 * t.halo;
-    for (int dh = 0; dh < 3; ++dh)
-      for (int dw = 0; dw < 3; ++dw) {
-        const int tp = dh * 3 + dw;
-        t.sdh[tp] = sgn * (dh - g.ph); t.sdw[tp] = sgn * (dw - g.pw);
-        t.tapoff[tp] = t.sdh[tp] * g.sW + t.sdw[tp];
-      }
-    const size_t lds = 3 * 64 * 96 + (size_t)t.npos * 96 + 64;
+    t.npp = t.npos + ((4 - t.npos % 8) + 8) % 8;
+    const size_t lds = 3 * 64 * 96 + (size_t)t.npp * 96 + 64;
     if (2 * t.npos <= 512) launch_tap<0, 9, 2>(t, grid, lds, s);
     else launch_tap<0, 9, 3>(t, grid, lds, s);
   } else {
     t.halo = 0;
     t.npos = 256;
-    for (int dt = 0; dt < 3; ++dt) t.tapoff[dt] = sgn * (dt - g.pt);
-    const size_t lds = 3 * 64 * 96 + (size_t)t.npos * 96 + 64;
+    t.npp = t.npos + 4;
+    const size_t lds = 3 * 64 * 96 + (size_t)t.npp * 96 + 64;
     launch_tap<1, 3, 2>(t, grid, lds, s);
   }
   return 1;

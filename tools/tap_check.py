@@ -45,7 +45,10 @@ def main():
         yr = F.conv3d(xr, wr, None, 1, p)
         yr.backward(gy.double())
         xa = ops.act_from_ncdhw(x.to(dev), DT, cpitch=(Ci + 15) // 16 * 16)
-        ya = ops.new_act(N, T, H, W, Co, DT, dev, zero=True)
+        M_ = N * T * H * W
+        ybuf = torch.full((M_ + 300, ops.cp8(Co)), 12345.0, dtype=torch.float32, device=dev)      # sentinel rows behind the output
+        ybuf[:M_] = 0
+        ya = ops.Act(ybuf[:M_], N, T, H, W, Co, ops.cp8(Co), 0, DT, ops.cp8(Co))
         d = ops.conv_desc(DT, xa, ya, k, (1, 1, 1), p, flags=L.DV_STATS | L.DV_W3)
         kind = lib.dv_conv3d_tap_kind(C.byref(d), 0)
         wp = ops.pack_weight(w.to(dev), xa.cpitch)
@@ -67,7 +70,9 @@ def main():
         taps = k[0] * k[1] * k[2]
         wd = torch.zeros(Ci, taps, cop, device=dev)
         wd[:, :, :Co] = w.to(dev).reshape(Co, Ci, taps).permute(1, 2, 0)
-        dxa = ops.new_act(N, T, H, W, Ci, DT, dev, cpitch=xa.cpitch, zero=True)
+        xbuf = torch.full((M_ + 300, xa.cpitch), 12345.0, dtype=torch.float32, device=dev)
+        xbuf[:M_] = 0
+        dxa = ops.Act(xbuf[:M_], N, T, H, W, Ci, xa.cpitch, 0, DT, xa.cpitch)
         wd3 = ops.pack_w3(wd.view(Ci, -1))
         dd = ops.conv_desc(DT, dxa, dya, k, (1, 1, 1), p, flags=L.DV_W3)
         kind_d = lib.dv_conv3d_tap_kind(C.byref(dd), 1)
@@ -77,8 +82,10 @@ def main():
         torch.cuda.synchronize()
         e_d = float((ops.act_to_ncdhw(dxa).double().cpu() - 2 * xr.grad).abs().max() / (2 * xr.grad).abs().max())
         pad_ok = float(dxa.buf[:, Ci:].abs().max()) == 0.0 if xa.cpitch > Ci else True
+        assert bool((ybuf[M_:] == 12345.0).all()) and bool((xbuf[M_:] == 12345.0).all()), 'wrote behind the output'
         print('N%d Cin%d T%d %dx%d Cout%d k%s: kind fwd %d dgrad %d | fwd %.2e mean %.2e var %.2e dgrad(+=) %.2e pad %s' % (
             N, Ci, T, H, W, Co, 'x'.join(map(str, k)), kind, kind_d, e_f, e_m, e_v, e_d, pad_ok), flush=True)
+        assert all(e == e for e in (e_f, e_m, e_v, e_d)), 'NaN'
         worst = max(worst, e_f, e_m, e_v, e_d)
         assert pad_ok
     print('worst', worst)
