@@ -1678,6 +1678,33 @@ static void launch_ks(int bn, ConvArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL((conv_gemm_ks_kernel<MODE, 64, 3>), dim3(grid), dim3(256), 0, s, a);
 }
 
+// the parity classes of a strided data gradient (ConvArgs::cls_on == 1): `a` holds the launch-wide fields; -> number of classes
+static int dgrad_classes(const dv_conv_desc* d, const ConvArgs& a, ConvArgs (&out)[8]) {
+  const int taps_orig = d->kt * d->kh * d->kw;
+  int n = 0;
+  for (int rt = 0; rt < d->st; ++rt)
+    for (int rh = 0; rh < d->sh; ++rh)
+      for (int rw = 0; rw < d->sw; ++rw) {
+        auto first = [](int r, int p, int st_) { return ((r - p) % st_ + st_) % st_; };   // smallest pos with (pos+p)%s == r
+        const int ot = first(rt, d->pt, d->st), oh = first(rh, d->ph, d->sh), ow = first(rw, d->pw, d->sw);
+        if (ot >= d->Ti || oh >= d->Hi || ow >= d->Wi) continue;
+        ConvArgs& c = out[n++];
+        c = a;
+        ConvGeom& g = c.g;
+        g.rT = (d->Ti - ot + d->st - 1) / d->st; g.rH = (d->Hi - oh + d->sh - 1) / d->sh; g.rW = (d->Wi - ow + d->sw - 1) / d->sw;
+        g.kt = (d->kt - rt + d->st - 1) / d->st; g.kh = (d->kh - rh + d->sh - 1) / d->sh; g.kw = (d->kw - rw + d->sw - 1) / d->sw;
+        g.st = g.sh = g.sw = 1;
+        g.pt = (ot + d->pt - rt) / d->st; g.ph = (oh + d->ph - rh) / d->sh; g.pw = (ow + d->pw - rw) / d->sw;
+        g.Ktot = g.kt * g.kh * g.kw * g.CP;
+        g.dW = make_fastdiv((uint32_t)g.rW); g.dH = make_fastdiv((uint32_t)g.rH); g.dT = make_fastdiv((uint32_t)g.rT);
+        c.M = d->N * g.rT * g.rH * g.rW;
+        if (!(a.flags & DV_W3)) c.ldw = taps_orig * g.CP;       // (pre-split weights: ldw stays their padded row count)
+        c.cls_on = 1; c.cst = d->st; c.csh = d->sh; c.csw = d->sw; c.cot = ot; c.coh = oh; c.cow = ow;
+        c.crt = rt; c.crh = rh; c.crw = rw; c.oKH = d->kh; c.oKW = d->kw; c.oT = d->Ti; c.oH = d->Hi; c.oW = d->Wi;
+      }
+  return n;
+}
+
 // the ConvArgs fields the kernel-choice queries look at (no pointers: nothing is launched)
 static void query_args(const dv_conv_desc* d, int dgrad, ConvArgs& a) {
   fill_geom(d, dgrad ? MODE_DGRAD : MODE_FWD, a.g);
@@ -1695,9 +1722,18 @@ static void query_args(const dv_conv_desc* d, int dgrad, ConvArgs& a) {
 // 0: conv_gemm / conv_gemm_ks; 1 / 2: the LDS-staged input-tile kernel (conv_tap.hip), spatial / temporal form
 static int tap_choice(const dv_conv_desc* d, int dgrad) {
   if (d->dtype != DV_F32 || f32_exact() || !(d->flags & DV_W3)) return 0;
-  if (d->st > 1 || d->sh > 1 || d->sw > 1) return 0;
   ConvArgs a;
   query_args(d, dgrad, a);
+  if (d->st > 1 || d->sh > 1 || d->sw > 1) {
+    // a strided data gradient whose parity classes all run on the temporal form (the 7x1x1 / stride-2 stem conv); forward: never
+    if (!dgrad || d->st > 2 || d->sh > 2 || d->sw > 2 || !(d->kt >= d->st && d->kh >= d->sh && d->kw >= d->sw)) return 0;
+    a.ldw = w3_rows(d->Cin);
+    ConvArgs cls[8];
+    const int ncls = dgrad_classes(d, a, cls);
+    for (int i = 0; i < ncls; ++i)
+      if (!dvt_conv_tap_kind(&cls[i], MODE_DGRAD)) return 0;
+    return ncls > 0 ? 2 : 0;
+  }
   trim_dead_taps(a, dgrad ? MODE_DGRAD : MODE_FWD, d->dtype);
   return dvt_conv_tap_kind(&a, dgrad ? MODE_DGRAD : MODE_FWD);
 }
@@ -1905,7 +1941,8 @@ static int dgrad_impl(const dv_conv_desc* d, const void* dy, const void* wd, voi
     a.bn_shift = bnr->shift; a.bn_sums = bnr->sums; a.bn_rep = bnr->n_rep; a.bn_mask = (bnr->flags & DV_NO_RELU_MASK) ? 0 : 1;
   }
   const bool w3 = (d->flags & DV_W3) != 0;
-  if (w3 && (d->dtype != DV_F32 || f32_exact() || d->st > 1 || d->sh > 1 || d->sw > 1)) return DV_EUNSUPPORTED;
+  if (w3 && (d->dtype != DV_F32 || f32_exact())) return DV_EUNSUPPORTED;      // (strided: only where every parity class runs on the
+                                                                              //  LDS-staged kernel, checked at the class launches)
   if (w3) { a.flags |= DV_W3; a.ldw = w3_rows(d->Cin); }
   {
     const int64_t es = d->dtype == DV_F32 ? 4 : 2;
@@ -1925,32 +1962,24 @@ static int dgrad_impl(const dv_conv_desc* d, const void* dy, const void* wd, voi
   const bool strided = d->st > 1 || d->sh > 1 || d->sw > 1;
   if (strided && d->kt >= d->st && d->kh >= d->sh && d->kw >= d->sw) {
     // one dense stride-1 launch per parity class of the input positions (see ConvArgs): every class has >= 1 tap
-    const int taps_orig = d->kt * d->kh * d->kw;
-    for (int rt = 0; rt < d->st; ++rt)
-      for (int rh = 0; rh < d->sh; ++rh)
-        for (int rw = 0; rw < d->sw; ++rw) {
-          auto first = [](int r, int p, int st_) { return ((r - p) % st_ + st_) % st_; };   // smallest pos with (pos+p)%s == r
-          const int ot = first(rt, d->pt, d->st), oh = first(rh, d->ph, d->sh), ow = first(rw, d->pw, d->sw);
-          if (ot >= d->Ti || oh >= d->Hi || ow >= d->Wi) continue;
-          ConvArgs c = a;
-          ConvGeom& g = c.g;
-          g.rT = (d->Ti - ot + d->st - 1) / d->st; g.rH = (d->Hi - oh + d->sh - 1) / d->sh; g.rW = (d->Wi - ow + d->sw - 1) / d->sw;
-          g.kt = (d->kt - rt + d->st - 1) / d->st; g.kh = (d->kh - rh + d->sh - 1) / d->sh; g.kw = (d->kw - rw + d->sw - 1) / d->sw;
-          g.st = g.sh = g.sw = 1;
-          g.pt = (ot + d->pt - rt) / d->st; g.ph = (oh + d->ph - rh) / d->sh; g.pw = (ow + d->pw - rw) / d->sw;
-          g.Ktot = g.kt * g.kh * g.kw * g.CP;
-          g.dW = make_fastdiv((uint32_t)g.rW); g.dH = make_fastdiv((uint32_t)g.rH); g.dT = make_fastdiv((uint32_t)g.rT);
-          c.M = d->N * g.rT * g.rH * g.rW;
-          c.ldw = taps_orig * g.CP;
-          c.cls_on = 1; c.cst = d->st; c.csh = d->sh; c.csw = d->sw; c.cot = ot; c.coh = oh; c.cow = ow;
-          c.crt = rt; c.crh = rh; c.crw = rw; c.oKH = d->kh; c.oKW = d->kw; c.oT = d->Ti; c.oH = d->Hi; c.oW = d->Wi;
-          int bm, bn;
-          pick_tile(d->dtype, c.M, c.NP, bm, bn);
-          c.ntn = (c.NP + bn - 1) / bn;
-          const int grid = c.ntn * ((c.M + bm - 1) / bm);
-          if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, c, grid, s);
-          else launch_gemm<bf16_t, MODE_DGRAD, 16>(bm, bn, c, grid, s);
-        }
+    ConvArgs cls[8];
+    const int ncls = dgrad_classes(d, a, cls);
+    if (w3) {
+      // pre-split weights: every class on the LDS-staged input-tile kernel (conv_tap.hip, temporal form), or not at all
+      for (int i = 0; i < ncls; ++i)
+        if (!dvt_conv_tap_kind(&cls[i], MODE_DGRAD)) return DV_EUNSUPPORTED;
+      for (int i = 0; i < ncls; ++i) dvt_conv_tap_launch(&cls[i], MODE_DGRAD, stream);
+      return dv_launch_status();
+    }
+    for (int i = 0; i < ncls; ++i) {
+      ConvArgs& c = cls[i];
+      int bm, bn;
+      pick_tile(d->dtype, c.M, c.NP, bm, bn);
+      c.ntn = (c.NP + bn - 1) / bn;
+      const int grid = c.ntn * ((c.M + bm - 1) / bm);
+      if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, c, grid, s);
+      else launch_gemm<bf16_t, MODE_DGRAD, 16>(bm, bn, c, grid, s);
+    }
     return dv_launch_status();
   }
   trim_dead_taps(a, MODE_DGRAD, d->dtype);

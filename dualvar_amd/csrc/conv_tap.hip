@@ -46,6 +46,10 @@ struct TapArgs {
   FastDiv fW, fH;
   int T, S, P, lgP, NQ;   // temporal: frames, pixels per frame, pixels per tile (256 / T), log2 P, N * S
   FastDiv fS;
+  // temporal, general form (the parity classes of a t-strided data gradient, conv.hip ConvArgs::cls_on == 1: every class is a
+  // dense stride-1 problem over T frames of dY): tap j reads frame f + sgn * (j - pt); its weights sit at the ORIGINAL tap
+  // wt0 + wts * j; row frame f is frame f * ofs + ofo of an output tensor with oT frames
+  int pt, wt0, wts, oT, ofs, ofo;
 };
 
 // displacement of tap t (compile-time index, natural order (dh, dw) / dt; 3 x 3 and 3 x 1 x 1 windows, padding 1): a handful of
@@ -53,8 +57,8 @@ struct TapArgs {
 // waits for every LDS read in flight) inside the hot loop
 template <int KIND> __device__ __forceinline__ int tap_dh(int t) { return KIND == 0 ? t / 3 - 1 : 0; }
 template <int KIND> __device__ __forceinline__ int tap_dw(int t) { return KIND == 0 ? t % 3 - 1 : 0; }
-template <int KIND> __device__ __forceinline__ int tap_off(const int sgn, const int W, int t) {
-  return KIND == 0 ? sgn * (tap_dh<0>(t) * W + tap_dw<0>(t)) : sgn * (t - 1);
+template <int KIND> __device__ __forceinline__ int tap_off(const int sgn, const int W, int t, int pt = 1) {
+  return KIND == 0 ? sgn * (tap_dh<0>(t) * W + tap_dw<0>(t)) : sgn * (t - pt);
 }
 
 // one 16-byte global load into registers, invisible to the compiler's wait-count pass (see the header comment)
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const dma_rsrc_t src_rs = dma_make_rsrc(a.src, (unsigned)a.src_bytes), w_rs = dma_make_rsrc(a.w, (unsigned)a.w_bytes);
   const unsigned ldb = (unsigned)a.lds_ * 4u;
   const unsigned dsm_base = lds_addr(dsm);
-  const int tsgn = a.sgn, tW = a.W, tT = a.T, tP48 = a.P * 48;
+  const int tsgn = a.sgn, tW = a.W, tT = a.T, tP48 = a.P * 48, tpt = a.pt;
 
   // ---- staging roles: unit u = tid + 256 k -> (position u >> 1, channel half u & 1)
   unsigned soff[NU], pwr[NU];
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int NC = a.CP >> 4, nsteps = NC * NTAPS;
   auto w_issue = [&](int step, int stage) {
     const int c = step / NTAPS, t = step - c * NTAPS;
-    const unsigned kt = (unsigned)(t * a.CP + c * 16) >> 4;
+    const unsigned kt = (unsigned)((a.wt0 + a.wts * t) * a.CP + c * 16) >> 4;
 #pragma unroll
     for (int u = 0; u < NPW; ++u)
       if (wave + NW * u < BPC)
@@ -201,7 +205,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     } else {
       // balanced (frame, pixel block) pairs per wave: border frames have a tap less
       if (a.T == 2) { bfr[i] = i; bpb[i] = wave; }
-      else if (a.T == 4) { bfr[i] = i == 0 ? wave : (wave ^ 1); bpb[i] = i; }
+      else if (a.T == 4) {                 // frames {0, 2} and {1, 3} pair up: equal tap counts for 3 taps / padding 1 and 4 / 2
+        const int f0 = ((wave & 1) << 1) | (wave >> 1);
+        bfr[i] = i == 0 ? f0 : (f0 ^ 2); bpb[i] = i;
+      }
       else { bfr[i] = i == 0 ? wave : 7 - wave; bpb[i] = 0; }
       abase[i] = planes_off + (unsigned)(h * npp + bpb[i] * 32 + l31) * 48u;
     }
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const unsigned at = abase[i] + (unsigned)(tap_off<0>(tsgn, tW, t) * 48);
         ad = ((amask[i] >> t) & 1u) ? zero_off : at;
       } else {
-        const int fs = bfr[i] + tap_off<1>(tsgn, tW, t);
+        const int fs = bfr[i] + tap_off<1>(tsgn, tW, t, tpt);
         if (fs < 0 || fs >= tT) continue;                      // (wave-uniform) this tap leaves the clip for the whole block
         ad = abase[i] + (unsigned)(fs * tP48);
       }
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       } else {
         const unsigned q = (unsigned)(tile_m * a.P + bpb[i] * 32 + rl);
         const unsigned n = fd_div(q, a.fS);
-        ro[r] = (int)q < a.NQ ? (q + n * (unsigned)((a.T - 1) * a.S) + (unsigned)(bfr[i] * a.S)) * ldo4 : kOOB;
+        ro[r] = (int)q < a.NQ ? (q + n * (unsigned)((a.oT - 1) * a.S) + (unsigned)((bfr[i] * a.ofs + a.ofo) * a.S)) * ldo4 : kOOB;
       }
     }
 #pragma unroll
@@ -380,7 +387,17 @@ static int tap_kind(const ConvArgs& a, int mode) {
   static const int min_grid = getenv("DUALVAR_CONV_TAP_GRID") ? atoi(getenv("DUALVAR_CONV_TAP_GRID")) : 512;
   if (!on) return 0;
   const ConvGeom& g = a.g;
-  if (!(a.flags & DV_W3) || (a.flags & (DV_BIAS | DV_RELU | DV_SIGMOID)) || a.cls_on || a.bn_x != nullptr || a.out_bytes <= 0) return 0;
+  if (!(a.flags & DV_W3) || (a.flags & (DV_BIAS | DV_RELU | DV_SIGMOID)) || a.bn_x != nullptr || a.out_bytes <= 0) return 0;
+  if (a.cls_on == 1) {
+    // one parity class of a t-strided kt x 1 x 1 data gradient (S3D-G's 7x1x1 / stride 2 stem conv, backbone/s3dg.py:151): 3 or 4
+    // taps over the four frames of dY, rows = the class's four frames of dX
+    if (mode != MODE_DGRAD || g.kh != 1 || g.kw != 1 || a.csh != 1 || a.csw != 1 || a.coh || a.cow || a.crh || a.crw) return 0;
+    if (g.st != 1 || g.sh != 1 || g.sw != 1 || g.CP % 16 != 0 || g.rH != g.sH || g.rW != g.sW) return 0;
+    if (g.sT != 4 || g.rT != 4 || (g.kt != 3 && g.kt != 4) || g.pt < 0 || g.pt >= g.kt) return 0;
+    if ((int64_t)((a.M + 255) / 256) * ((a.NP + 63) / 64) < min_grid) return 0;
+    return 2;
+  }
+  if (a.cls_on) return 0;
   if (mode != MODE_FWD && (a.flags & DV_STATS)) return 0;
   if (g.st != 1 || g.sh != 1 || g.sw != 1 || g.CP % 16 != 0) return 0;
   if (g.rT != g.sT || g.rH != g.sH || g.rW != g.sW) return 0;
@@ -422,6 +439,8 @@ int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream) {
   t.P = 256 / g.sT; t.lgP = 0;
   while ((1 << t.lgP) < t.P) ++t.lgP;
   t.NQ = a.M / g.sT;
+  t.pt = g.pt; t.wt0 = 0; t.wts = 1; t.oT = g.sT; t.ofs = 1; t.ofo = 0;
+  if (a.cls_on == 1) { t.wt0 = a.crt; t.wts = a.cst; t.oT = a.oT; t.ofs = a.cst; t.ofo = a.cot; }
   t.sgn = mode == MODE_FWD ? 1 : -1;
   const int grid = t.ntn * ((a.M + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
@@ -437,7 +456,8 @@ int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream) {
     t.npos = 256;
     t.npp = t.npos + 4;
     const size_t lds = 3 * 64 * 96 + (size_t)t.npp * 96 + 64;
-    launch_tap<1, 3, 2>(t, grid, lds, s);
+    if (g.kt == 4) launch_tap<1, 4, 2>(t, grid, lds, s);
+    else launch_tap<1, 3, 2>(t, grid, lds, s);
   }
   return 1;
 }

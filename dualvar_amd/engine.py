@@ -880,6 +880,14 @@ class ConvOp(Op):
             elif self.need_dx:
                 acc = bool(self.acc.get('x'))
                 wdp, wdflag = st.w_dgrad(sl, strided=max(self.s) > 1)
+                if max(self.s) > 1 and self.bn_fuse is None:
+                    # a strided data gradient takes the pre-split weights only where every parity class of it runs on the
+                    # LDS-staged input-tile kernel (the 7x1x1 / stride-2 stem conv: dv_conv3d_tap_kind says so)
+                    wdp3, wdflag3 = st.w_dgrad(sl, strided=False)
+                    if wdflag3:
+                        d3 = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=(DV_ACCUM if acc else 0) | wdflag3)
+                        if int(lib.dv_conv3d_tap_kind(C.byref(d3), 1)):
+                            wdp, wdflag = wdp3, wdflag3
                 self.d_g = ops.conv_desc(self.dtype, x, y, self.k, self.s, self.p, flags=(DV_ACCUM if acc else 0) | wdflag)
                 kd = _conv_kname(lib, self.d_g, 1, _dt(self.dtype))
                 if self.bn_fuse is not None:

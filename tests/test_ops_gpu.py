@@ -1351,8 +1351,17 @@ def test_fp32_conv_at_headline_tile_sizes_against_cpu_conv3d(gpu, case):
         assert lib.dv_conv3d_tap_kind(C.byref(dg3), 1) == BIG_M_TAP[name], name
         ops.conv_dgrad(dg3, dya, ops.pack_w3(wd.view(Cin, -1)), dxa)
     else:
+        # t-strided (the 7x1x1 / stride-2 stem conv): with pre-split weights every parity class runs on the temporal form of the
+        # LDS-staged kernel; without them on conv_gemm -- both against float64
+        dg3 = ops.conv_desc(DV_F32, xa, dya, k, s, p, flags=DV_W3)
+        assert lib.dv_conv3d_tap_kind(C.byref(dg3), 1) == 2, name
+        ops.conv_dgrad(dg3, dya, ops.pack_w3(wd.view(Cin, -1)), dxa)
+        got['dgrad_gemm'] = rel(ops.act_to_ncdhw(dxa), xr.grad)
+        dxa.buf.zero_()
         ops.conv_dgrad(d2, dya, wd, dxa)
-    got['dgrad'] = rel(ops.act_to_ncdhw(dxa), xr.grad)
+        got['dgrad'], got['dgrad_gemm'] = got['dgrad_gemm'], rel(ops.act_to_ncdhw(dxa), xr.grad)
+        cpu['dgrad_gemm'] = cpu['dgrad']
+    got['dgrad'] = got.get('dgrad', rel(ops.act_to_ncdhw(dxa), xr.grad))
     print(name, 'relative-to-max error vs float64:', {k_: ('%.2e (cpu fp32 %.2e)' % (got[k_], cpu[k_])) for k_ in got},
           'wgrad splits', sp_.value)
     for k_ in got:

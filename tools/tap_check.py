@@ -88,6 +88,41 @@ def main():
         assert all(e == e for e in (e_f, e_m, e_v, e_d)), 'NaN'
         worst = max(worst, e_f, e_m, e_v, e_d)
         assert pad_ok
+    # t-strided kt x 1 x 1 data gradients (S3D-G's 7x1x1 / stride-2 stem conv and smaller kin): every parity class on the temporal
+    # form (3 / 4 taps over the four frames of dY, rows scattered to every second frame of dX), `+=` included
+    for (N, Ci, Ti, H, W, Co, kt, st, pt) in [(3, 32, 8, 9, 7, 64, 7, 2, 3), (2, 64, 8, 14, 14, 48, 7, 2, 3), (5, 16, 8, 6, 5, 32, 5, 2, 2)]:
+        g = torch.Generator().manual_seed(2)
+        k, sd, p = (kt, 1, 1), (st, 1, 1), (pt, 0, 0)
+        x = torch.randn(N, Ci, Ti, H, W, generator=g)
+        w = torch.randn(Co, Ci, *k, generator=g) * (Ci * kt) ** -0.5
+        xr = x.double().requires_grad_(True)
+        yr = F.conv3d(xr, w.double(), None, sd, p)
+        To = yr.shape[2]
+        gy = torch.randn(N, Co, To, H, W, generator=g)
+        yr.backward(gy.double())
+        cip, cop = (Ci + 15) // 16 * 16, (Co + 15) // 16 * 16
+        dya = ops.act_from_ncdhw(gy.to(dev), DT, cpitch=cop)
+        M_ = N * Ti * H * W
+        xbuf = torch.full((M_ + 300, cip), 12345.0, dtype=torch.float32, device=dev)
+        xbuf[:M_] = 0
+        dxa = ops.Act(xbuf[:M_], N, Ti, H, W, Ci, cip, 0, DT, cip)
+        wd = torch.zeros(Ci, kt, cop, device=dev)
+        wd[:, :, :Co] = w.to(dev).reshape(Co, Ci, kt).permute(1, 2, 0)
+        wd3 = ops.pack_w3(wd.view(Ci, -1))
+        dd = ops.conv_desc(DT, dxa, dya, k, sd, p, flags=L.DV_W3)
+        kind_d = lib.dv_conv3d_tap_kind(C.byref(dd), 1)
+        assert kind_d == (2 if kt == 7 else 0), (kt, kind_d)      # (5 taps / stride 2: a class of two taps -- stays on conv_gemm)
+        if kind_d == 2:
+            ops.conv_dgrad(dd, dya, wd3, dxa)
+            ops.conv_dgrad(ops.conv_desc(DT, dxa, dya, k, sd, p, flags=L.DV_W3 | L.DV_ACCUM), dya, wd3, dxa)
+            torch.cuda.synchronize()
+            e_d = float((ops.act_to_ncdhw(dxa).double().cpu() - 2 * xr.grad).abs().max() / (2 * xr.grad).abs().max())
+            assert bool((xbuf[M_:] == 12345.0).all()), 'wrote behind the output'
+            assert e_d == e_d
+            worst = max(worst, e_d)
+        else:
+            e_d = float('nan')
+        print('strided dgrad N%d Cin%d T%d->%d %dx%d Cout%d k%d s%d: kind %d | dgrad(+=) %.2e' % (N, Ci, Ti, To, H, W, Co, kt, st, kind_d, e_d), flush=True)
     print('worst', worst)
     assert worst < 5e-6, worst
     print('ok')
