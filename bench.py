@@ -354,6 +354,8 @@ def run_leg(args, dtype, rank, world, distributed, dev):
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
+    from dualvar_amd import rccl as _rccl
+    _rccl.STATS.reset()               # collectives issued inside the timed region (direct RCCL path; c10d calls are not counted)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -361,6 +363,7 @@ def run_leg(args, dtype, rank, world, distributed, dev):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    coll = _rccl.STATS.summary(args.steps) if distributed else None
     if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -417,6 +420,10 @@ def run_leg(args, dtype, rank, world, distributed, dev):
                           'frac_hbm': round(pb / step_s / 1e9 / HBM_PEAK_GBS, 4),
                           'frac_mfma': round(pf / step_s / 1e12 / MFMA_PEAK_TF[dtype], 4)},
            'kernel_time_ms_per_step': {k: round(v[1], 3) for k, v in sorted(csum.items(), key=lambda kv: -kv[1][1])[:12]}}
+    if coll is not None:
+        # per step and rank: how many collectives the step enqueues in-stream, their payload and the HOST time of the enqueue calls
+        # (the one-rank rehearsal under DUALVAR_FORCE_EXCHANGE=1 gives the code-path cost; a real N-GPU line adds wire latency)
+        res['collectives'] = {k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in coll.items()}
     del model, opt, block
     torch.cuda.empty_cache()
     return res
@@ -460,6 +467,10 @@ def main():
             'whole_step': first['whole_step'],
             'kernel_time_ms_per_step': first['kernel_time_ms_per_step'],
         }
+        if 'collectives' in first:
+            out['extra'] = {'collectives_per_step_and_rank': first['collectives'],
+                            'note': 'in-stream RCCL calls inside the timed region (rank 0): count, payload bytes and HOST time of the '
+                                    'enqueue calls per step; with one rank under DUALVAR_FORCE_EXCHANGE=1 this is the code-path cost only'}
         if second is not None:
             out['secondary'] = dict(second, note=(
                 'same step with bf16 STORAGE (fp32 accumulate and statistics): throughput mode.  Its outputs are bounded against '

@@ -34,6 +34,11 @@ BIG_LAYERS = [
     ('T16 Conv_1a.conv2 7x1x1 s2', 128, 16, 56, 56, 64, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0)),
     ('T16 Conv_2c.conv1 1x3x3', 128, 8, 28, 28, 64, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ('T16 Mixed_4b branch1 3x1x1', 128, 4, 7, 7, 208, 208, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    # R(2+1)D (BASELINE configs[2]; backbone/r21d.py:47-49,176-266) at its own per-GPU size, 32 samples x 3 views of 8 x 112 x 112:
+    # the conv2 block's 144 mid channels (52 % of the net's FLOPs), and conv3's strided 1x3x3 into 230 mid channels
+    ('r21d conv2 spatial 1x3x3 64->144', 96, 8, 56, 56, 64, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('r21d conv2 temporal 3x1x1 144->64', 96, 8, 56, 56, 144, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ('r21d conv3 spatial 1x3x3 s2 64->230', 96, 8, 56, 56, 64, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     ('r50@224 layer1 conv2 1x3x3', 8, 16, 56, 56, 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ('r50@224 layer1 conv3 1x1x1', 8, 16, 56, 56, 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ('r50@224 layer3 conv1 3x1x1', 8, 16, 14, 14, 1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
@@ -63,16 +68,19 @@ def test_conv_adjoint_identities_at_full_size(gpu, layer, dtype):
     To, Ho, Wo = ops.conv_out_dims(x, k, s, p)
     y, dy = ops.new_act(N_CLIPS, To, Ho, Wo, Co, dtype, gpu), ops.new_act(N_CLIPS, To, Ho, Wo, Co, dtype, gpu)
     dy.buf.copy_(torch.randn(dy.buf.shape, generator=g).to(tdt))
+    dy.buf[:, Co:] = 0                                                                     # pad lanes [Co, cout_pitch) hold zeros
     taps = k[0] * k[1] * k[2]
     wf = (torch.randn(Co, taps, Ci, generator=g) * (taps * Ci) ** -0.5).to(gpu)            # master layout [Co][tap][Ci]
     w16 = wf.to(tdt)
-    wd = w16.float().permute(2, 1, 0).contiguous().to(tdt)                                 # dgrad layout [Ci][tap][Co]
+    wd = torch.zeros(Ci, taps, ops.cp8(Co), dtype=tdt, device=gpu)                         # dgrad layout [Ci][tap][cout_pitch]
+    wd[:, :, :Co] = w16.float().permute(2, 1, 0).to(tdt)
     d = ops.conv_desc(dtype, x, y, k, s, p)
     dx = x.like()
     if f32:
         d3 = ops.conv_desc(dtype, x, y, k, s, p, flags=DV_W3)
         ops.conv_fwd(d3, x, ops.pack_w3(w16.view(Co, -1)), None, y, None)
-        if max(s) == 1:
+        import ctypes as C
+        if max(s) == 1 or _L.load().dv_conv3d_tap_kind(C.byref(d3), 1):       # (t-strided stem conv: its parity classes on conv_tap)
             ops.conv_dgrad(d3, dy, ops.pack_w3(wd.view(Ci, -1)), dx)
         else:
             ops.conv_dgrad(d, dy, wd, dx)
@@ -254,6 +262,52 @@ def test_full_size_fp32_training_step(gpu):
     assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(g1, g2)), 'the fp32 step must be bit-reproducible'
     assert all(torch.equal(a, b) for a, b in zip(g0, g1))
     print(f'|g|^2 {gn2:.4e}, lr {lr:.3e}: loss {l1[0]:.6f} -> {l1[1]:.6f}; predicted decrease 0.02, observed {l1[0] - l1[1]:.4e}')
+    assert 0.01 < l1[0] - l1[1] < 0.03
+
+
+def test_full_size_r21d_tsv4_step(gpu):
+    """BASELINE configs[2] at its per-GPU size: R(2+1)D SimCLR_TimeSeriesV4 (clip + shuffle-rank + tc heads; model/simclr.py:135-400,
+    backbone/r21d.py:176-266), 32 samples x 3 views of 8x112x112 in fp32 -- three encoder passes per step.  Finite gradients, the
+    step is bit-reproducible from the same state, and the summed loss goes down along the gradient by the first-order amount (a
+    wrong tile, tap or split in any of the large-M kernels this size alone reaches -- 144 / 230 / 460 mid channels at 2.4 M / 602 k
+    / 150 k rows -- breaks the last two)."""
+    from dualvar_amd import model as M
+    from dualvar_amd.optim import SGD
+    import types
+
+    def run(lr, steps):
+        torch.manual_seed(0)
+        np.random.seed(1234)
+        m = M.SimCLR_TimeSeriesV4('r21d', 128, 0.07, False, args=types.SimpleNamespace(shufflerank_theta=0.05))
+        m.set_compute_dtype('fp32').train().to(gpu)
+        block = torch.randn(32, 3, 3, 8, 112, 112, generator=torch.Generator().manual_seed(5)).to(gpu)
+        opt = SGD([p for p in m.parameters() if p.requires_grad], lr=lr, momentum=0.0, weight_decay=0.0, stores=m.stores())
+        losses, grads = [], None
+        for _ in range(steps):
+            np.random.seed(77)                          # the same segment shuffles in every step: the loss is one function of the weights
+            ret = m(block)
+            loss = ret['clip_contrast_loss']
+            for k_ in ret:
+                if 'loss' in k_ and 'clip' not in k_:
+                    loss = loss + ret[k_]
+            opt.zero_grad()
+            loss.backward()
+            if grads is None:
+                grads = [st.grad.detach().clone() for st in m.stores()]
+            opt.step()
+            losses.append(float(loss))
+        return losses, grads
+
+    _, g0 = run(0.0, 1)
+    assert all(bool(torch.isfinite(g).all()) for g in g0)
+    gn2 = float(sum(float(g.double().pow(2).sum()) for g in g0))
+    assert gn2 > 0
+    lr = 0.02 / gn2
+    l1, g1 = run(lr, 2)
+    l2, g2 = run(lr, 2)
+    assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(g1, g2)), 'the fp32 step must be bit-reproducible'
+    assert all(torch.equal(a, b) for a, b in zip(g0, g1))
+    print(f'r21d tsv4: |g|^2 {gn2:.4e}, lr {lr:.3e}: loss {l1[0]:.6f} -> {l1[1]:.6f}; predicted decrease 0.02, observed {l1[0] - l1[1]:.4e}')
     assert 0.01 < l1[0] - l1[1] < 0.03
 
 
