@@ -73,7 +73,7 @@ class GemmDesc(C.Structure):
 
 
 P, I32, I64, F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
-RETURNS_INT64 = ('dv_conv3d_wgrad_workspace', 'dv_w3_bytes', 'dv_bn_bwd_reduce_workspace', 'dv_infonce_workspace')       # everything else returns int
+RETURNS_INT64 = ('dv_conv3d_wgrad_workspace', 'dv_conv3d_dgrad_bn_workspace', 'dv_w3_bytes', 'dv_bn_bwd_reduce_workspace', 'dv_infonce_workspace')       # everything else returns int
 CD, PD = C.POINTER(ConvDesc), C.POINTER(PoolDesc)
 
 # name -> argtypes, exactly as declared in include/dualvar_hip.h
@@ -88,6 +88,8 @@ SIGNATURES = {
     'dv_conv3d_fwd': [CD, P, P, P, P, P, P],
     'dv_conv3d_dgrad': [CD, P, P, P, P],
     'dv_conv3d_dgrad_bn': [CD, P, P, P, P, P],
+    'dv_conv3d_dgrad_bn_workspace': [CD],
+    'dv_conv3d_dgrad_bn_ws': [CD, P, P, P, P, P, I64, P],
     'dv_conv3d_wgrad_workspace': [CD],
     'dv_conv3d_wgrad_tile': [CD, P, P, P],
     'dv_conv3d_wgrad': [CD, P, P, P, P, I64, P],

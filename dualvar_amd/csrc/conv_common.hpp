@@ -93,6 +93,10 @@ struct ConvArgs {
   const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
   float* bn_sums;
   int bn_ldx, bn_rep, bn_mask;
+  // dv_conv3d_dgrad_bn_ws (conv_tap.hip): per-tile partial sums + tickets of the ORDERED form of that reduce (no float atomics);
+  // bn_bytes = extent of bn_x for its buffer descriptor
+  float* bn_ws;
+  int bn_bytes;
 };
 
 template <int BYTES> struct VecB;

@@ -50,7 +50,31 @@ struct TapArgs {
   // dense stride-1 problem over T frames of dY): tap j reads frame f + sgn * (j - pt); its weights sit at the ORIGINAL tap
   // wt0 + wts * j; row frame f is frame f * ofs + ofo of an output tensor with oT frames
   int pt, wt0, wts, oT, ofs, ofo;
+  // data gradient that is dL/dy of y = relu(BatchNorm(bn_x)) and its only contribution (dv_conv3d_dgrad_bn_ws): the epilogue
+  // also forms the BatchNorm backward's sum(g), sum(g * xhat) over the rows it stores -- from the accumulators and ONE read of
+  // bn_x, instead of dv_bn_bwd_reduce's second read of dL/dy -- as per-tile rows in bn_ws, folded in tile order by the
+  // workgroups that take the last tickets (no float atomics; += into bn_sums [2][bn_cpb], which the caller zeroed)
+  const void* bn_x;
+  const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
+  float *bn_sums, *bn_ws;
+  int bn_ldx, bn_mask, bn_bytes, bn_cpb;
 };
+
+// rows / tickets of the ordered fold (the protocol of elementwise.hip's ordered_fold: sc1 stores -> s_waitcnt vmcnt(0) -> barrier ->
+// one agent-scope ticket -> the last arriver reads with sc1 loads; validated on gfx950, see the comment there)
+constexpr int kBnFoldGroup = 32, kBnRow = 128;                  // tiles per group; floats per row: [sum g | sum g xhat] x 64 columns
+static inline int64_t bn_ws_floats_per_coltile(int n_mt) {
+  const int ngrp = (n_mt + kBnFoldGroup - 1) / kBnFoldGroup;
+  return (int64_t)(n_mt + ngrp) * kBnRow + ((ngrp + 1 + 7) & ~7);
+}
+__device__ __forceinline__ size_t bn_ws_floats_per_coltile_dev(int n_mt) {
+  const int ngrp = (n_mt + kBnFoldGroup - 1) / kBnFoldGroup;
+  return (size_t)(n_mt + ngrp) * kBnRow + (size_t)((ngrp + 1 + 7) & ~7);
+}
+__device__ __forceinline__ void tap_coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float tap_coherent_load(const float* p) {
+  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // displacement of tap t (compile-time index, natural order (dh, dw) / dt; 3 x 3 and 3 x 1 x 1 windows, padding 1): a handful of
 // scalar instructions from two kernel arguments -- a table in the argument block was re-loaded (s_load + lgkmcnt(0), which also
@@ -290,20 +314,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int flags = a.flags;
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
   const unsigned ldo4 = (unsigned)a.ldo * 4u;
+  const bool bn_on = a.bn_x != nullptr;
+  const __amdgpu_buffer_rsrc_t bn_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(bn_on ? a.bn_x : a.out), 0,
+                                                                           bn_on ? a.bn_bytes : a.out_bytes, 0x00020000);
+  const unsigned bn_ldx4 = (unsigned)a.bn_ldx * 4u;
+  float bn_mu[TN], bn_is[TN], bn_sc[TN], bn_sh[TN], bn_s1[TN], bn_s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + j * 32 + l31;
+    const bool ok = bn_on && col < a.N;
+    bn_mu[j] = ok ? a.bn_mean[col] : 0.f;
+    bn_is[j] = ok ? a.bn_invstd[col] : 0.f;
+    bn_sc[j] = (ok && a.bn_mask) ? a.bn_scale[col] : 0.f;
+    bn_sh[j] = (ok && a.bn_mask) ? a.bn_shift[col] : 0.f;
+    bn_s1[j] = bn_s2[j] = 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    unsigned ro[16];
+    unsigned ro[16], rox[16];                                   // byte offsets of this lane's rows in the output / in bn_x
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+      unsigned row;
+      bool ok;
       if constexpr (KIND == 0) {
         const int m = m0 + 64 * wave + 32 * i + rl;
-        ro[r] = m < a.M ? (unsigned)m * ldo4 : kOOB;
+        ok = m < a.M; row = (unsigned)m;
       } else {
         const unsigned q = (unsigned)(tile_m * a.P + bpb[i] * 32 + rl);
         const unsigned n = fd_div(q, a.fS);
-        ro[r] = (int)q < a.NQ ? (q + n * (unsigned)((a.oT - 1) * a.S) + (unsigned)((bfr[i] * a.ofs + a.ofo) * a.S)) * ldo4 : kOOB;
+        ok = (int)q < a.NQ;
+        row = q + n * (unsigned)((a.oT - 1) * a.S) + (unsigned)((bfr[i] * a.ofs + a.ofo) * a.S);
       }
+      ro[r] = ok ? row * ldo4 : kOOB;
+      rox[r] = ok ? row * bn_ldx4 : kOOB;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -315,6 +359,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) old[r] = __builtin_amdgcn_raw_buffer_load_b32(orsrc, (int)(ro[r] + cb), 0, 0);
       }
+      if (bn_on) {                                              // the BatchNorm's input at this lane's 16 rows of column `col`
+        const unsigned xb = (unsigned)col * 4u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          old[r] = col_ok ? __builtin_amdgcn_raw_buffer_load_b32(bn_rsrc, (int)(rox[r] + xb), 0, 0) : 0u;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = ro[r] == kOOB ? 0.f : acc[i][j][r];           // rows past the end feed neither the output nor the statistics
@@ -323,8 +374,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
           if (flags & DV_ACCUM) v += __builtin_bit_cast(float, old[r]);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, (int)(ro[r] + cb), 0, 0);
         }
+        if (bn_on) {
+          const float xv = __builtin_bit_cast(float, old[r]);
+          const float act = xv * bn_sc[j] + bn_sh[j];          // the forward's expression (dv_bn_apply), same rounding
+          const float gg = (a.bn_mask && !(act > 0.f)) ? 0.f : v;
+          bn_s1[j] += gg;
+          bn_s2[j] += gg * (xv - bn_mu[j]) * bn_is[j];
+        }
       }
     }
+  }
+  if (bn_on) {
+    // ---- this tile's row of partial sums (fixed order: registers, wave halves, waves), then the ordered fold over tiles
+    constexpr int G = kBnFoldGroup;
+    static_assert(BN == 64, "a row of partial sums is [sum g | sum g xhat] x 64 columns");
+    float* redf = reinterpret_cast<float*>(dsm);                // [NW][2][BN] + the row [2][BN]; one flag word behind it
+    __syncthreads();                                            // the weight stages are free
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s1 = bn_s1[j], s2 = bn_s2[j];
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (h == 0) { redf[(wave * 2 + 0) * BN + j * 32 + l31] = s1; redf[(wave * 2 + 1) * BN + j * 32 + l31] = s2; }
+    }
+    __syncthreads();
+    const int n_mt = (a.M + BM - 1) / BM, ngrp = (n_mt + G - 1) / G, grp = tile_m / G;
+    const int gsize = min(G, n_mt - grp * G);
+    float* wsn = a.bn_ws + (size_t)tile_n * bn_ws_floats_per_coltile_dev(n_mt);
+    float* rows = wsn;
+    float* grows = rows + (size_t)n_mt * kBnRow;
+    unsigned* tick = reinterpret_cast<unsigned*>(grows + (size_t)ngrp * kBnRow);
+    unsigned* lastf = reinterpret_cast<unsigned*>(redf + (NW * 2 + 2) * BN);
+    const int which = tid >> 6, cc = tid & 63;                  // tid < 128: (sum index, column)
+    const bool mine = tid < kBnRow;
+    if (mine) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += redf[(w * 2 + which) * BN + cc];
+      tap_coherent_store(rows + (size_t)tile_m * kBnRow + tid, t);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this tile's row has reached the coherence point ...
+    __syncthreads();
+    if (tid == 0) *lastf = (atomicAdd(tick + grp, 1u) == (unsigned)gsize - 1u) ? 1u : 0u;       // ... before its ticket is taken
+    __syncthreads();
+    if (!*lastf) return;
+    auto fold = [&](const float* src, int n) -> float {         // rows src[0 .. n) of this thread's word, in row order
+      float t = 0.f;
+      for (int b = 0; b < n; b += G) {
+        float v[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) v[u] = tap_coherent_load(src + (size_t)min(b + u, n - 1) * kBnRow + tid);
+#pragma unroll
+        for (int u = 0; u < G; ++u) t += (b + u < n) ? v[u] : 0.f;
+      }
+      return t;
+    };
+    auto finish = [&](float t) {                                // += into the caller's sums: [2][bn_cpb], real columns only
+      const int c = n0 + cc;
+      if (c < a.N) a.bn_sums[(size_t)which * a.bn_cpb + c] += t;
+    };
+    float t = mine ? fold(rows + (size_t)grp * G * kBnRow, gsize) : 0.f;
+    if (ngrp == 1) {
+      if (mine) finish(t);
+      if (tid == 0) __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (mine) tap_coherent_store(grows + (size_t)grp * kBnRow + tid, t);
+    if (tid == 0) __hip_atomic_store(tick + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) *lastf = (atomicAdd(tick + ngrp, 1u) == (unsigned)ngrp - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (!*lastf) return;
+    if (mine) finish(fold(grows, ngrp));
+    if (tid == 0) __hip_atomic_store(tick + ngrp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
   }
   if (flags & DV_STATS) {
     // per column: sum and M2 about the tile mean of the values as stored (two passes over the accumulators), [2][N][tiles]
@@ -384,10 +508,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // 0: not applicable; 1: spatial; 2: temporal
 static int tap_kind(const ConvArgs& a, int mode) {
   static const int on = getenv("DUALVAR_CONV_TAP") ? atoi(getenv("DUALVAR_CONV_TAP")) : 1;
-  static const int min_grid = getenv("DUALVAR_CONV_TAP_GRID") ? atoi(getenv("DUALVAR_CONV_TAP_GRID")) : 512;
+  // smallest grid (256-row x 64-column tiles) the kernel takes: half a chip's worth of workgroups.  The 12 544-row levels
+  // (Mixed_4b - 4f: 196 .. 245 tiles) are 10 - 20 % faster on it in isolation (1x3x3 forward 76.6 -> 63.4, 85.5 -> 69.5 us; 3x1x1
+  // data gradient 59.2 -> 47.6 us) and the step is equal within noise (18.13 / 18.11 / 18.09 ms at 512 / 256 / 128 on one box);
+  // below that conv_gemm's 64-row tiles / conv_gemm_ks fill the chip better.  DUALVAR_CONV_TAP_GRID overrides (tests: 1).
+  static const int min_grid = getenv("DUALVAR_CONV_TAP_GRID") ? atoi(getenv("DUALVAR_CONV_TAP_GRID")) : 128;
   if (!on) return 0;
   const ConvGeom& g = a.g;
-  if (!(a.flags & DV_W3) || (a.flags & (DV_BIAS | DV_RELU | DV_SIGMOID)) || a.bn_x != nullptr || a.out_bytes <= 0) return 0;
+  if (!(a.flags & DV_W3) || (a.flags & (DV_BIAS | DV_RELU | DV_SIGMOID)) || a.out_bytes <= 0) return 0;
+  // the fused BatchNorm-backward reduce: only in its ordered form (workspace given), on a data gradient that is not accumulated
+  if (a.bn_x != nullptr && (a.bn_ws == nullptr || a.bn_bytes <= 0 || mode != MODE_DGRAD || (a.flags & DV_ACCUM))) return 0;
   if (a.cls_on == 1) {
     // one parity class of a t-strided kt x 1 x 1 data gradient (S3D-G's 7x1x1 / stride 2 stem conv, backbone/s3dg.py:151): 3 or 4
     // taps over the four frames of dY, rows = the class's four frames of dX
@@ -418,6 +548,11 @@ static void launch_tap(const TapArgs& t, int grid, size_t lds, hipStream_t s) {
 
 }  // namespace
 
+// floats of dv_conv3d_dgrad_bn_ws's workspace for a launch of `rows` rows and `np` (padded) columns
+int64_t dvt_bn_ws_floats(int64_t rows, int np) {
+  return (int64_t)((np + 63) / 64) * bn_ws_floats_per_coltile((int)((rows + 255) / 256));
+}
+
 // entry points for conv.hip (the argument block is conv_common.hpp's ConvArgs, passed by address)
 int dvt_conv_tap_kind(const void* conv_args, int mode) { return tap_kind(*static_cast<const ConvArgs*>(conv_args), mode); }
 
@@ -442,6 +577,10 @@ int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream) {
   t.pt = g.pt; t.wt0 = 0; t.wts = 1; t.oT = g.sT; t.ofs = 1; t.ofo = 0;
   if (a.cls_on == 1) { t.wt0 = a.crt; t.wts = a.cst; t.oT = a.oT; t.ofs = a.cst; t.ofo = a.cot; }
   t.sgn = mode == MODE_FWD ? 1 : -1;
+  t.bn_x = a.bn_x; t.bn_mean = a.bn_mean; t.bn_invstd = a.bn_invstd; t.bn_scale = a.bn_scale; t.bn_shift = a.bn_shift;
+  t.bn_sums = a.bn_sums; t.bn_ws = a.bn_ws; t.bn_ldx = a.bn_ldx; t.bn_mask = a.bn_mask; t.bn_bytes = a.bn_bytes;
+  t.bn_cpb = (a.N + 7) & ~7;
+  if (a.bn_x == nullptr) { t.bn_ws = nullptr; t.bn_sums = nullptr; t.bn_bytes = 0; }
   const int grid = t.ntn * ((a.M + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
   if (kind == 1) {

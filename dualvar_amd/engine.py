@@ -45,6 +45,16 @@ FUSE_BN_POOL = True
 # 1.36 -> 0.66 / 1.07 -> 0.55 ms per step, but the data gradients that carry them grow by 0.62 / 0.52 ms (a serial tail per
 # workgroup that re-reads its tile and the BatchNorm input), and they sit on the critical path: 20.47 -> 20.77 / 9.79 -> 9.98 ms.
 FUSE_BN_REDUCE = False        # (module switch, no environment variable: tests/test_models_gpu.py monkeypatches it)
+# The same fusion in its ORDERED form on the LDS-staged input-tile kernel (dv_conv3d_dgrad_bn_ws: the sums come from the
+# accumulators and one read of the BatchNorm's input, tile rows are folded in tile order -- no float atomics): taken wherever the
+# consuming conv's data gradient runs on that kernel (fp32 mode: the separable pairs and the strided stem conv of S3D-G / R(2+1)D).
+FUSE_BN_REDUCE_TAP = True      # (module switch; tests monkeypatch it for the A/B of the two plans)
+# ... only behind a long K loop (>= 512 = taps x channel pitch of dY) and never for the strided stem conv: the epilogue's read of
+# the BatchNorm input is exposed at the end of a workgroup's life, and for a short loop it costs more than the standalone reduce
+# saves -- all eight candidates of the S3D-G step fused: data gradients +740 us, reduce launches -565 us (the stem conv alone 422 ->
+# 854 us for a 312 us reduce); with this rule the step is 0.03 - 0.05 ms faster, i.e. the fusion VERDICT round 3 priced at -0.26 ms
+# is worth a tenth of that.
+FUSE_BN_REDUCE_TAP_MIN_K = 512
 # BatchNorm-backward APPLY inside the weight gradient of a conv whose input needs no gradient (the first conv of a network:
 # dL/d(conv output) has that weight gradient as its only reader): dv_conv3d_wgrad_bn forms it on the fly from dL/dy and the
 # conv output -- one read of each instead of read + read + write (apply) + read (wgrad).  fp32 split mode only.
@@ -629,6 +639,40 @@ class Plan:
                             or a.rows != y.rows or cop.bn_fuse is not None):
                         continue
                     cop.bn_fuse, m.reduce_fused = m, True
+        self.bn_fuse_ws = None
+        if self.with_grad and self.training and FUSE_BN_REDUCE_TAP and self.dtype == DV_F32 and not FUSE_BN_REDUCE:
+            writers, need_ws = {}, 0
+            for op in self.ops:
+                for name, a in op.grad_targets():
+                    g = a.grad if a.grad is not None else a
+                    writers.setdefault((g.buf.data_ptr(), g.off), []).append((op, a))
+            for op in self.ops:
+                if not isinstance(op, BNGroupOp):
+                    continue
+                for m in op.members:
+                    y = m.y
+                    if y.grad is None or m.res is not None or m.fused_pool is not None or (m.relu and not m.mask_from_x):
+                        continue
+                    w = writers.get((y.grad.buf.data_ptr(), y.grad.off), [])
+                    if len(w) != 1 or not isinstance(w[0][0], ConvOp):
+                        continue
+                    cop, a = w[0]
+                    if (cop.fp8 or not cop.need_dx or cop.acc.get('x') or a.buf is not y.buf or a.off != y.off or a.C != y.C
+                            or a.rows != y.rows or cop.bn_fuse is not None or m.x.ld * 4 * (m.x.rows - 1) >= (1 << 31)):
+                        continue
+                    _, wdflag = self.store.w_dgrad(cop.slot, strided=False)
+                    if not wdflag or max(cop.s) > 1 or cop.slot.cout_pitch * cop.k[0] * cop.k[1] * cop.k[2] < FUSE_BN_REDUCE_TAP_MIN_K:
+                        continue                 # (short K loops: the epilogue's read of the BatchNorm input is not hidden)
+                    d3 = ops.conv_desc(cop.dtype, cop.x, cop.y, cop.k, cop.s, cop.p, flags=wdflag)
+                    nb = int(self.lib.dv_conv3d_dgrad_bn_workspace(C.byref(d3)))
+                    if nb <= 0:
+                        continue
+                    cop.bn_fuse, cop.bn_fuse_tap, m.reduce_fused = m, True, True
+                    need_ws = max(need_ws, nb)
+            if need_ws:
+                # one workspace for all of them (they run one after the other on the main stream; the ticket words are zero
+                # between launches, and after a failed launch: _lib.register_ticket_workspace)
+                self.bn_fuse_ws = L.register_ticket_workspace(self.f32(need_ws // 4))
         if self.with_grad and self.training and FUSE_BN_WGRAD and self.dtype == DV_F32:
             for op in self.ops:
                 if not isinstance(op, BNGroupOp) or len(op.members) != 1:
@@ -820,6 +864,7 @@ class ConvOp(Op):
         self.alg_k = None
         self.zero_pad_taps = None
         self.bn_fuse = None          # BNMember whose backward reduce this conv's data gradient carries (Plan.finalize)
+        self.bn_fuse_tap = False     # ... in the ordered form of the LDS-staged kernel (dv_conv3d_dgrad_bn_ws)
         self.bn_apply = None         # BNMember (of this conv's output) whose backward apply this conv's weight gradient carries
 
     def grad_targets(self):
@@ -880,7 +925,7 @@ class ConvOp(Op):
             elif self.need_dx:
                 acc = bool(self.acc.get('x'))
                 wdp, wdflag = st.w_dgrad(sl, strided=max(self.s) > 1)
-                if max(self.s) > 1 and self.bn_fuse is None:
+                if max(self.s) > 1 and (self.bn_fuse is None or self.bn_fuse_tap):
                     # a strided data gradient takes the pre-split weights only where every parity class of it runs on the
                     # LDS-staged input-tile kernel (the 7x1x1 / stride-2 stem conv: dv_conv3d_tap_kind says so)
                     wdp3, wdflag3 = st.w_dgrad(sl, strided=False)
@@ -896,8 +941,14 @@ class ConvOp(Op):
                     r.x, r.ldx = m.x.ptr, m.x.ld
                     r.mean, r.invstd, r.scale, r.shift = (t.data_ptr() for t in (m.mean, m.invstd, m.scale, m.shift))
                     r.sums, r.n_rep, r.flags = p.zero_ptr(m.sums_off), BN_REPLICAS, (0 if m.relu else DV_NO_RELU_MASK)
-                    b.append(Launch('conv_dgrad', kd, lib.dv_conv3d_dgrad_bn, (C.byref(self.d_g), y.grad.ptr, wdp, x.grad.ptr, C.byref(r)),
-                                    _abytes(y) + wbytes + _abytes(x) * 2, flops, shp + ' +bn_reduce'))
+                    if self.bn_fuse_tap:
+                        ws = p.bn_fuse_ws
+                        b.append(Launch('conv_dgrad', kd + '+bn_reduce', lib.dv_conv3d_dgrad_bn_ws,
+                                        (C.byref(self.d_g), y.grad.ptr, wdp, x.grad.ptr, C.byref(r), ws.data_ptr(), ws.numel() * 4),
+                                        _abytes(y) + wbytes + _abytes(x) * 2, flops, shp + ' +bn_reduce'))
+                    else:
+                        b.append(Launch('conv_dgrad', kd, lib.dv_conv3d_dgrad_bn, (C.byref(self.d_g), y.grad.ptr, wdp, x.grad.ptr, C.byref(r)),
+                                        _abytes(y) + wbytes + _abytes(x) * 2, flops, shp + ' +bn_reduce'))
                 else:
                     b.append(Launch('conv_dgrad', kd, lib.dv_conv3d_dgrad, (C.byref(self.d_g), y.grad.ptr, wdp, x.grad.ptr),
                                     _abytes(y) + wbytes + _abytes(x) * (2 if acc else 1), flops, shp))

@@ -129,6 +129,16 @@ typedef struct dv_bn_reduce {
 } dv_bn_reduce;
 int dv_conv3d_dgrad_bn(const dv_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const dv_bn_reduce* bn,
                        void* stream);
+/* The ORDERED form of the same fusion, on the LDS-staged input-tile kernel (dv_conv3d_tap_kind != 0: DV_F32 + DV_W3 stride-1
+ * "same" 1x3x3 / 3x1x1 convs and the t-strided 7x1x1 stem conv): the two sums are formed from the accumulators and ONE read of
+ * x_bn -- dv_bn_bwd_reduce's read of dL/dy disappears --, every 256-row tile stores its row of partial sums into `workspace` and
+ * the workgroups that take the last tickets add the rows in tile order: no float atomics, two runs give the same bits.  The
+ * result is ADDED to sums[0][2][cp8(Cin)] (n_rep is ignored; the caller zeroes `sums`).  dv_conv3d_dgrad_bn_workspace returns
+ * the bytes `workspace` must hold (0: this problem does not run on that kernel -- use dv_bn_bwd_reduce); its ticket words must be
+ * ZERO before the first call and are left zero (memset the buffer once; it may be shared by consecutive calls on one stream). */
+int64_t dv_conv3d_dgrad_bn_workspace(const dv_conv_desc* d);
+int dv_conv3d_dgrad_bn_ws(const dv_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const dv_bn_reduce* bn,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 /* dw += x^T * dy into the fp32 gradient arena (caller zeroes at zero_grad).  Deterministic: the rows are split over
  * workgroups whose partial tiles go to `workspace` ([splits][Cout][taps*CinP] fp32, plain stores) and are then added to dw
  * in a fixed order -- no float atomics, so two runs on the same inputs give the same bits.  dv_conv3d_wgrad_workspace

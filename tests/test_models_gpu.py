@@ -696,6 +696,38 @@ def test_fused_bn_reduce_plan_gives_the_same_gradients(gpu, monkeypatch, net, dt
     assert err <= tol, (err, tol)
 
 
+def test_ordered_fused_bn_reduce_on_the_lds_staged_kernel_at_headline_size(gpu, monkeypatch):
+    """engine.FUSE_BN_REDUCE_TAP (default on): where a conv -> BatchNorm -> conv chain's second conv runs its data gradient on the
+    LDS-staged input-tile kernel, the BatchNorm backward's sums come out of that launch (dv_conv3d_dgrad_bn_ws: accumulators + one
+    read of the BatchNorm input, per-tile rows folded in tile order).  The headline step (S3D-G, 64 x 2 clips of 8x112x112, fp32)
+    with and without it: the same gradients up to the grouping of the fp32 row sums, and the fused plan is bit-reproducible."""
+    from dualvar_amd import engine, model as M
+    from dualvar_amd import _lib
+    if _lib.f32_exact():
+        pytest.skip('the LDS-staged kernel belongs to the split mode')
+    block = torch.randn(64, 2, 3, 8, 112, 112, generator=torch.Generator().manual_seed(3)).to(gpu)
+    grads, fused = [], []
+    for on in (False, True, True):
+        monkeypatch.setattr(engine, 'FUSE_BN_REDUCE_TAP', on)
+        torch.manual_seed(0)
+        m = M.SimCLR_Naked('s3dg', 128, 0.07, False)
+        m.set_compute_dtype('fp32').train().to(gpu)
+        ret = m(block)
+        for st in m.stores():
+            st.zero_grad()
+        ret['clip_contrast_loss'].backward()
+        torch.cuda.synchronize()
+        grads.append(torch.cat([st.grad.detach().float().flatten().clone() for st in m.stores()]))
+        plans = [pl for lst in m.encoder_q[0]._plans.values() for pl in lst]
+        fused.append(sum(1 for pl in plans for op in pl.ops if getattr(op, 'bn_fuse_tap', False)))
+        del m, ret
+    print('data gradients carrying the ordered BatchNorm-backward reduce:', fused)
+    assert fused[0] == 0 and fused[1] == fused[2] >= 4, fused
+    assert torch.equal(grads[1], grads[2]), float((grads[1] - grads[2]).abs().max())
+    err = float((grads[0] - grads[1]).abs().max())
+    assert bool(torch.isfinite(grads[1]).all()) and err <= 2e-4 * float(grads[0].abs().max()), (err, float(grads[0].abs().max()))
+
+
 @pytest.mark.parametrize('net', ['s3dg', 'r21d', 'r3d'])
 def test_first_conv_weight_gradient_carrying_the_batchnorm_backward_gives_the_same_bits(gpu, monkeypatch, net):
     """engine.FUSE_BN_WGRAD: the first conv's input needs no gradient, so dL/d(conv output) -- the BatchNorm backward's dx --

@@ -30,6 +30,53 @@ CASES = [
 ]
 
 
+def check_fused_bn_reduce(lib, dev, dd_plain, dya, wd3, like, Ci, tag):
+    """dv_conv3d_dgrad_bn_ws against the plain data gradient + the sums computed from it in float64: same dx bits, sums within
+    fp32 rounding of a sum over all rows, identical bits from run to run, `+=` into the caller's sums, tickets left zero"""
+    DT = L.DV_F32
+    N, T, H, W, cip = like.N, like.T, like.H, like.W, like.cpitch
+    dxp = ops.new_act(N, T, H, W, Ci, DT, dev, cpitch=cip, zero=True)
+    ops.conv_dgrad(dd_plain, dya, wd3, dxp)
+    g = torch.Generator().manual_seed(5)
+    xb = ops.new_act(N, T, H, W, Ci, DT, dev, cpitch=cip, zero=True)
+    xb.buf[:, :Ci] = (torch.randn(xb.rows, Ci, generator=g) + 0.2).to(dev)
+    CPi = ops.cp8(Ci)
+
+    def padded(t):
+        o = torch.zeros(CPi, device=dev)
+        o[:Ci] = t.to(dev)
+        return o
+    mean, invstd = padded(0.1 * torch.randn(Ci, generator=g)), padded(1 + 0.1 * torch.randn(Ci, generator=g).abs())
+    scale, shift = padded(1 + 0.2 * torch.randn(Ci, generator=g)), padded(0.1 * torch.randn(Ci, generator=g))
+    need = int(lib.dv_conv3d_dgrad_bn_workspace(C.byref(dd_plain)))
+    assert need > 0, tag
+    ws = torch.zeros(need // 4, device=dev)
+    worst = 0.0
+    for bflag in (0, L.DV_NO_RELU_MASK):
+        gx, xx = dxp.buf[:, :CPi].double(), xb.buf[:, :CPi].double()
+        act = (xb.buf[:, :CPi] * scale) + shift                    # two roundings, as the kernels compute it (no fma)
+        gg = gx if bflag else torch.where(act > 0, gx, torch.zeros_like(gx))
+        want = torch.stack([gg.sum(0), (gg * (xx - mean.double()) * invstd.double()).sum(0)])
+        runs = []
+        for rep in range(2):
+            dxf = ops.new_act(N, T, H, W, Ci, DT, dev, cpitch=cip, zero=True)
+            sums = torch.full((1, 2, CPi), 1.0, device=dev)            # += : starts at 1
+            r = ops.bn_reduce_desc(xb, mean, invstd, scale, shift, sums, 1, bflag)
+            L.check(lib.dv_conv3d_dgrad_bn_ws(C.byref(dd_plain), dya.ptr, wd3.data_ptr(), dxf.ptr, C.byref(r), ws.data_ptr(), need,
+                                              ops.stream_ptr()), 'dv_conv3d_dgrad_bn_ws')
+            torch.cuda.synchronize()
+            assert torch.equal(dxf.buf, dxp.buf), tag + ': dx differs from the plain data gradient'
+            runs.append(sums.clone())
+        assert torch.equal(runs[0], runs[1]), tag + ': the fused sums are not reproducible'
+        got = runs[0][0].double().cpu() - 1.0
+        den = float(want.abs().max()) + float(gg.abs().sum(0).max()) * 1e-3
+        e = float((got[:, :Ci] - want.cpu()[:, :Ci]).abs().max()) / float(gg.abs().sum(0).max())
+        assert e == e
+        worst = max(worst, e)
+        assert float(got[:, Ci:].abs().max()) == 0.0 if CPi > Ci else True
+    return worst
+
+
 def main():
     L.require_device()
     dev = torch.device('cuda:0')
@@ -80,11 +127,13 @@ def main():
         dd2 = ops.conv_desc(DT, dxa, dya, k, (1, 1, 1), p, flags=L.DV_W3 | L.DV_ACCUM)
         ops.conv_dgrad(dd2, dya, wd3, dxa)
         torch.cuda.synchronize()
+        e_bn = check_fused_bn_reduce(lib, dev, dd, dya, wd3, dxa, Ci, 'N%d Cin%d k%s' % (N, Ci, k))
         e_d = float((ops.act_to_ncdhw(dxa).double().cpu() - 2 * xr.grad).abs().max() / (2 * xr.grad).abs().max())
         pad_ok = float(dxa.buf[:, Ci:].abs().max()) == 0.0 if xa.cpitch > Ci else True
         assert bool((ybuf[M_:] == 12345.0).all()) and bool((xbuf[M_:] == 12345.0).all()), 'wrote behind the output'
-        print('N%d Cin%d T%d %dx%d Cout%d k%s: kind fwd %d dgrad %d | fwd %.2e mean %.2e var %.2e dgrad(+=) %.2e pad %s' % (
-            N, Ci, T, H, W, Co, 'x'.join(map(str, k)), kind, kind_d, e_f, e_m, e_v, e_d, pad_ok), flush=True)
+        print('N%d Cin%d T%d %dx%d Cout%d k%s: kind fwd %d dgrad %d | fwd %.2e mean %.2e var %.2e dgrad(+=) %.2e pad %s | fused bn sums %.2e' % (
+            N, Ci, T, H, W, Co, 'x'.join(map(str, k)), kind, kind_d, e_f, e_m, e_v, e_d, pad_ok, e_bn), flush=True)
+        assert e_bn < 2e-6, e_bn
         assert all(e == e for e in (e_f, e_m, e_v, e_d)), 'NaN'
         worst = max(worst, e_f, e_m, e_v, e_d)
         assert pad_ok
@@ -120,6 +169,8 @@ def main():
             assert bool((xbuf[M_:] == 12345.0).all()), 'wrote behind the output'
             assert e_d == e_d
             worst = max(worst, e_d)
+            e_bn = check_fused_bn_reduce(lib, dev, dd, dya, wd3, dxa, Ci, 'strided k%d' % kt)
+            assert e_bn < 2e-6, e_bn
         else:
             e_d = float('nan')
         print('strided dgrad N%d Cin%d T%d->%d %dx%d Cout%d k%d s%d: kind %d | dgrad(+=) %.2e' % (N, Ci, Ti, To, H, W, Co, kt, st, kind_d, e_d), flush=True)
