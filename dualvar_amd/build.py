@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdualvar_hip.so')
-SOURCES = ['conv.hip', 'conv_tap.hip', 'conv_experiments.hip', 'elementwise.hip', 'loss.hip', 'augment.hip']
+SOURCES = ['conv.hip', 'conv_tap.hip', 'conv_tap_wgrad.hip', 'conv_experiments.hip', 'elementwise.hip', 'loss.hip', 'augment.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-comment', '-Wno-inline-asm', '-ffp-contract=off']
 # every compile also reports registers / LDS / scratch per kernel; the report is kept next to the object (csrc/<name>.res) and
 # tests/test_abi_and_host.py fails on any kernel with scratch > 0 (a spill arrived silently in round 3)

@@ -1054,24 +1054,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 //    workgroup tiles 128 x 128 or 64 x 256 (f32: 64 x 128 with 32 x 64 wave tiles): half the dY / im2col re-reads of
 //    the 128 x 64 tiles this replaces.
 
-// rows of RB bytes: four consecutive rows must fall on four different 64-byte bank groups of the 256-byte LDS line
-// (RB a multiple of 256: XOR the 64-byte chunk index with row&3; RB = 128 mod 256, i.e. 128 or 384: rows 0/1 already
-// differ by 128 bytes, XOR chunk bit 0 with (row>>1)&1)
-template <int RB> __device__ __forceinline__ int wg_swz(int row) { return (RB % 256) ? ((row >> 1) & 1) : (row & 3); }
-
-template <int RB>
-__device__ __forceinline__ bf16x8 wg_frag(const unsigned char* tile, int col0, int lane, int ks) {
-  const int g16 = lane >> 4, li = lane & 15;
-  const int q = li >> 2, p = li & 3;
-  const int row = ks * 16 + 8 * (g16 >> 1) + q;              // wg_swz(row) == wg_swz(q) == wg_swz(row + 4)
-  const int colb = ((col0 + 16 * (g16 & 1) + 4 * p) * 2) ^ (wg_swz<RB>(q) << 6);
-  const unsigned char* ad = tile + row * RB + colb;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad + 4 * RB));
-  s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  return __builtin_bit_cast(bf16x8, v);
-}
-
 // NS: LDS stages -- tiles s+1 .. s+NS-1 are in flight while tile s is multiplied (counted vmcnt; every wave issues the
 // same NPW + NQW pieces per tile).  WVI x WVJ waves, each a 64 x 64 tile of dW.
 // workgroups per CU the LDS footprint admits (<= 3), and the waves per SIMD that makes (the register allocator is
@@ -2047,8 +2029,40 @@ struct WgradPlan {
   int BI, BJ, nti, ntj, splits, rows_per_split, gvb, cfg;
   int f32s;                   // >= 0: conv_wgrad_f32s_kernel configuration (conv_experiments.hip)
   bool dma;
+  bool tm;                    // conv_wgrad_tm_kernel (conv_tap_wgrad.hip): stride-1 3x1x1, fp32 split mode, T = 2 / 4
+  int nchunks, chunks_per_split;
   long long slab_stride;      // elements
 };
+
+// the LDS-staged weight gradient of the stride-1 3x1x1 convs (conv_tap_wgrad.hip); the argument is a TmWgradArgs*
+void dvw_wgrad_tm_launch(const void* args, int grid, void* stream);
+
+// 0: no; 1: stride 1, 3x1x1, T = 2 / 4; 2: the 7x1x1 / stride-2 stem conv (8 -> 4 frames); 3: stride 1, 1x3x3, padding 1
+static int wgrad_tm_kind(const dv_conv_desc* d) {
+  static const int on = env_int("DUALVAR_WGRAD_TM", 1);           // (A/B switch; 2: temporal forms only)
+  if (!on || d->dtype != DV_F32 || f32_exact()) return 0;
+  if (d->sh != 1 || d->sw != 1 || d->cin_pitch % 8 || d->cout_pitch % 8) return 0;
+  int kind = 0;
+  if (d->kh == 1 && d->kw == 1 && !d->ph && !d->pw) {
+    if (d->kt == 3 && d->st == 1 && d->pt == 1 && d->To == d->Ti && (d->Ti == 2 || d->Ti == 4)) kind = 1;
+    else if (d->kt == 7 && d->st == 2 && d->pt == 3 && d->Ti == 8 && d->To == 4) kind = 2;
+  } else if (on != 2 && d->kt == 1 && d->st == 1 && !d->pt && d->kh == 3 && d->kw == 3 && d->ph == 1 && d->pw == 1 &&
+             d->Hi >= 2 && d->Wi >= 2) {
+    // the spatial form pays on the large maps whose channel count fills its 64-channel x tiles: Conv_2c 710 -> 542 us, Mixed_3c
+    // (128 channels) 310 -> 240; Mixed_3b (96 channels: a half-empty second tile) 148 -> 156 and the 12 544-row levels 89 -> 87
+    // stay on conv_wgrad_dma_kernel (isolated, one box)
+    const int64_t rows = (int64_t)d->N * d->Ti * d->Hi * d->Wi;
+    static const int any_size = env_int("DUALVAR_CONV_TAP_GRID", 128) <= 1;
+    if (any_size || (rows >= 50000 && (d->cin_pitch + 63) / 64 * 64 * 10 <= d->cin_pitch * 11)) kind = 3;
+  }
+  if (!kind) return 0;
+  const int64_t Mx = (int64_t)d->N * d->Ti * d->Hi * d->Wi, M = (int64_t)d->N * d->To * d->Ho * d->Wo;
+  const int64_t xb = (Mx - 1) * d->ldx * 4 + (int64_t)d->cin_pitch * 4, yb = (M - 1) * d->ldy * 4 + (int64_t)d->cout_pitch * 4;
+  if (xb >= (1ll << 31) || yb >= (1ll << 31)) return 0;
+  // (DUALVAR_CONV_TAP_GRID <= 1, the test knob of the LDS-staged kernels, also lets tiny problems through: tools/tap_check.py)
+  static const int min_rows = env_int("DUALVAR_CONV_TAP_GRID", 128) <= 1 ? 1 : 8192;
+  return M >= min_rows ? kind : 0;
+}
 
 
 static WgradPlan plan_wgrad(const dv_conv_desc* d) {
@@ -2066,6 +2080,32 @@ static WgradPlan plan_wgrad(const dv_conv_desc* d) {
   int per_cu = 3;
   p.cfg = -1;
   p.f32s = -1;
+  p.tm = false; p.nchunks = p.chunks_per_split = 0;
+  if (const int tmk = wgrad_tm_kind(d)) {
+    // 64 x 64 (n, c) tiles carrying all three taps; the row splits are ranges of 64 / T-pixel steps: one round of three
+    // co-resident workgroups per CU, at least 8 steps each, and not more than the slab traffic pays for (as below)
+    p.tm = true; p.dma = false;
+    const int bc = tmk == 2 ? 32 : 64;                            // channel tile of x (conv_tap_wgrad.hip)
+    p.BI = 64; p.BJ = (tmk == 3 ? 3 : d->kt) * bc;
+    p.nti = (d->Cout + 63) / 64; p.ntj = (d->cin_pitch + bc - 1) / bc;
+    const int krows = tmk == 3 ? 3 : 1;                           // spatial: one workgroup per kernel row dh
+    if (tmk == 3) {
+      p.nchunks = (M + 63) / 64;                                  // 64-row steps
+    } else {
+      const int pxs = 64 / d->To;
+      p.nchunks = (int)(((int64_t)d->N * d->Hi * d->Wi + pxs - 1) / pxs);
+    }
+    int splits = std::max(1, (tmk == 2 ? 512 : 768) / (p.nti * p.ntj * krows));      // (the stem form: two workgroups per CU)
+    splits = std::min(splits, std::max(1, p.nchunks / 8));
+    const double slab_us = 8.0 * d->Cout * (double)J / 4e6;
+    const int s_opt = (int)(std::sqrt(p.nchunks * 1.2 / slab_us) + 0.5);          // ~1.2 us per step of one workgroup
+    splits = std::max(1, std::min(splits, s_opt));
+    p.chunks_per_split = (p.nchunks + splits - 1) / splits;
+    p.splits = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
+    p.rows_per_split = p.chunks_per_split * 64;
+    p.slab_stride = ((long long)d->Cout * J + 63) / 64 * 64;
+    return p;
+  }
   // DUALVAR_WGRAD_F32S = 0 | 2: conv_wgrad_f32s_kernel (conv_experiments.hip) in its 64 x 256 / 128 x 128 form for every fp32
   // weight gradient (sweeps: tools/wgrad_sweep.sh).  Not selected by default: isolated it gains 8 - 10 % on the layers whose
   // shape its tiles fit (128-channel layers on 128 x 128, the 7x1x1 stem conv on 64 x 256) and nothing elsewhere, and a
@@ -2188,7 +2228,20 @@ static int wgrad_impl(const dv_conv_desc* d, const void* x, const void* dy, floa
   const int grid = p.nti * p.ntj * p.splits;
   const bool narrow = p.BI == 64;
   hipStream_t s = (hipStream_t)stream;
-  if (p.dma) {
+  if (p.tm) {
+    TmWgradArgs t;
+    t.x = x; t.dy = dy; t.dw = dw; t.slab = a.slab; t.slab_stride = p.slab_stride;
+    t.S = d->Hi * d->Wi; t.NQ = d->N * t.S; t.T = d->To; t.kind = wgrad_tm_kind(d);
+    t.Cout = d->Cout; t.CoutP = d->cout_pitch; t.CP = d->cin_pitch;
+    t.ldx = d->ldx; t.ldy = d->ldy; t.ldw = a.ldw;
+    t.nti = p.nti; t.ntc = p.ntj; t.nchunks = p.nchunks; t.chunks_per_split = p.chunks_per_split;
+    t.x_bytes = (int)(((int64_t)d->N * d->Ti * d->Hi * d->Wi - 1) * d->ldx * 4 + (int64_t)d->cin_pitch * 4);
+    t.dy_bytes = (int)(((int64_t)a.M - 1) * d->ldy * 4 + (int64_t)d->cout_pitch * 4);
+    t.fS = make_fastdiv((uint32_t)t.S);
+    t.M = a.M; t.H = d->Hi; t.W = d->Wi;
+    t.fW = make_fastdiv((uint32_t)d->Wi); t.fH = make_fastdiv((uint32_t)d->Hi);
+    dvw_wgrad_tm_launch(&t, t.kind == 3 ? grid * 3 : grid, stream);
+  } else if (p.dma) {
     const int64_t es = d->dtype == DV_F32 ? 4 : 2;
     WgradDmaArgs aa;
     aa.w = a;

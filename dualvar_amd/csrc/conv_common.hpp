@@ -398,4 +398,42 @@ struct WgradDmaArgs {
   int bn_rep, bn_mask;
 };
 
+// rows of RB bytes: four consecutive rows must fall on four different 64-byte bank groups of the 256-byte LDS line
+// (RB a multiple of 256: XOR the 64-byte chunk index with row&3; RB = 128 mod 256, i.e. 128 or 384: rows 0/1 already
+// differ by 128 bytes, XOR chunk bit 0 with (row>>1)&1)
+template <int RB> __device__ __forceinline__ int wg_swz(int row) { return (RB % 256) ? ((row >> 1) & 1) : (row & 3); }
+
+template <int RB>
+__device__ __forceinline__ bf16x8 wg_frag(const unsigned char* tile, int col0, int lane, int ks) {
+  const int g16 = lane >> 4, li = lane & 15;
+  const int q = li >> 2, p = li & 3;
+  const int row = ks * 16 + 8 * (g16 >> 1) + q;              // wg_swz(row) == wg_swz(q) == wg_swz(row + 4)
+  const int colb = ((col0 + 16 * (g16 & 1) + 4 * p) * 2) ^ (wg_swz<RB>(q) << 6);
+  const unsigned char* ad = tile + row * RB + colb;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ad + 4 * RB));
+  s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// ---- weight gradient of the stride-1 3x1x1 convs with LDS-staged, once-split operand tiles (conv_tap_wgrad.hip) -------------
+struct TmWgradArgs {
+  const void* x;          // [N][T][S][ldx] fp32
+  const void* dy;         // [N][T][S][ldy] fp32
+  float* dw;              // [Cout][taps * CP] fp32 (+=) when splits == 1
+  float* slab;            // [splits][slab_stride] partial tiles, or nullptr
+  long long slab_stride;
+  int NQ, S, T;           // N * S pixels, pixels per frame, frames of dY (2 or 4)
+  int Cout, CoutP, CP;    // output channels (and pitch of dY's channels), channel pitch of x
+  int ldx, ldy, ldw;      // pitches in elements; ldw = taps * CP
+  int nti, ntc;           // 64-channel tiles of Cout; 64- (kind 1) / 32-channel (kind 2) tiles of CP
+  int nchunks, chunks_per_split;      // steps (64 / T pixels each) in all / per row split
+  int x_bytes, dy_bytes;
+  int kind;               // 1: stride 1, 3 taps, T = 2 / 4 frames; 2: 7 taps, stride 2, 8 -> 4 frames (the stem conv);
+                          // 3: spatial 1x3x3, stride 1, padding 1 (M, H, W, fW, fH below; nchunks = 64-row steps)
+  FastDiv fS;
+  int M, H, W;
+  FastDiv fW, fH;
+};
+
 }  // namespace

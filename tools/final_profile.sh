@@ -5,7 +5,7 @@
 # Afterwards copy <outdir>/<dtype>/{bench_prof.log,launches.tsv,pmc_traffic.json,stats/**/*kernel_stats.csv} and
 # <outdir>/bench_full.log into profiles/<tag>_*.
 set -e -o pipefail
-OUT=${1:-gpurun_out/fin}; TAG=${2:-r03}
+OUT=${1:-gpurun_out/fin}; TAG=${2:-r04}
 mkdir -p $OUT
 export TMPDIR=/tmp
 echo "[0] bench (default flags: fp32 headline + bf16 secondary + cpu baseline)"

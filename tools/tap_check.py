@@ -27,6 +27,8 @@ CASES = [
     (2, 192, 4, 14, 14, 192, (3, 1, 1), (1, 0, 0)),
     (5, 16, 2, 7, 7, 48, (3, 1, 1), (1, 0, 0)),
     (3, 32, 8, 6, 5, 80, (3, 1, 1), (1, 0, 0)),
+    (7, 80, 4, 7, 5, 136, (3, 1, 1), (1, 0, 0)),
+    (9, 208, 2, 7, 7, 208, (3, 1, 1), (1, 0, 0)),
 ]
 
 
@@ -131,6 +133,32 @@ def main():
         e_d = float((ops.act_to_ncdhw(dxa).double().cpu() - 2 * xr.grad).abs().max() / (2 * xr.grad).abs().max())
         pad_ok = float(dxa.buf[:, Ci:].abs().max()) == 0.0 if xa.cpitch > Ci else True
         assert bool((ybuf[M_:] == 12345.0).all()) and bool((xbuf[M_:] == 12345.0).all()), 'wrote behind the output'
+        if (k == (3, 1, 1) and T in (2, 4)) or k == (1, 3, 3):
+            # the LDS-staged weight gradient (conv_tap_wgrad.hip): against float64, bit-reproducible, += , workspace content irrelevant
+            wr = w.double().requires_grad_(True)
+            F.conv3d(x.double(), wr, None, 1, p).backward(gy.double())
+            dwd = ops.conv_desc(DT, xa, dya, k, (1, 1, 1), p)
+            rr, cc_, ss = C.c_int32(), C.c_int32(), C.c_int32()
+            assert lib.dv_conv3d_wgrad_tile(C.byref(dwd), C.byref(rr), C.byref(cc_), C.byref(ss)) == 0
+            assert (rr.value, cc_.value) == (64, 192), (rr.value, cc_.value)
+            need = ops.wgrad_workspace_bytes(dwd)
+            runs = []
+            for fill in (0, 0xFF):
+                ws = torch.full((max(need, 16),), fill, dtype=torch.uint8, device=dev)
+                dw = torch.zeros(Co, taps * xa.cpitch, device=dev)
+                ops.conv_wgrad(dwd, xa, dya, dw, workspace=ws)
+                runs.append(dw)
+            torch.cuda.synchronize()
+            assert torch.equal(runs[0], runs[1]), 'weight gradient depends on the workspace content'
+            got = ops.unpack_weight(runs[0].view(Co, taps, xa.cpitch), w.shape).double().cpu()
+            e_w = float((got - wr.grad).abs().max() / wr.grad.abs().max())
+            if xa.cpitch > Ci:
+                assert float(runs[0].view(Co, taps, xa.cpitch)[:, :, Ci:].abs().max()) == 0.0
+            ops.conv_wgrad(dwd, xa, dya, runs[1], workspace=ws)
+            assert torch.allclose(runs[1], 2 * runs[0], rtol=1e-6, atol=0)
+            print('   weight gradient (LDS-staged, %d row splits): %.2e' % (ss.value, e_w), flush=True)
+            assert e_w == e_w and e_w < 3e-6, e_w
+            worst = max(worst, e_w)
         print('N%d Cin%d T%d %dx%d Cout%d k%s: kind fwd %d dgrad %d | fwd %.2e mean %.2e var %.2e dgrad(+=) %.2e pad %s | fused bn sums %.2e' % (
             N, Ci, T, H, W, Co, 'x'.join(map(str, k)), kind, kind_d, e_f, e_m, e_v, e_d, pad_ok, e_bn), flush=True)
         assert e_bn < 2e-6, e_bn
@@ -171,6 +199,28 @@ def main():
             worst = max(worst, e_d)
             e_bn = check_fused_bn_reduce(lib, dev, dd, dya, wd3, dxa, Ci, 'strided k%d' % kt)
             assert e_bn < 2e-6, e_bn
+            # the stem form of the LDS-staged weight gradient (7 taps, stride 2, 8 -> 4 frames)
+            wr = w.double().requires_grad_(True)
+            F.conv3d(x.double(), wr, None, sd, p).backward(gy.double())
+            xa = ops.act_from_ncdhw(x.to(dev), DT, cpitch=cip)
+            dwd = ops.conv_desc(DT, xa, dya, k, sd, p)
+            rr, cc_, ss = C.c_int32(), C.c_int32(), C.c_int32()
+            assert lib.dv_conv3d_wgrad_tile(C.byref(dwd), C.byref(rr), C.byref(cc_), C.byref(ss)) == 0
+            assert (rr.value, cc_.value) == (64, 7 * 32), (rr.value, cc_.value)
+            need = ops.wgrad_workspace_bytes(dwd)
+            runs = []
+            for fill in (0, 0xFF):
+                ws = torch.full((max(need, 16),), fill, dtype=torch.uint8, device=dev)
+                dw = torch.zeros(Co, kt * cip, device=dev)
+                ops.conv_wgrad(dwd, xa, dya, dw, workspace=ws)
+                runs.append(dw)
+            torch.cuda.synchronize()
+            assert torch.equal(runs[0], runs[1])
+            got = ops.unpack_weight(runs[0].view(Co, kt, cip), w.shape).double().cpu()
+            e_w = float((got - wr.grad).abs().max() / wr.grad.abs().max())
+            print('   weight gradient (LDS-staged stem form, %d row splits): %.2e' % (ss.value, e_w), flush=True)
+            assert e_w == e_w and e_w < 3e-6, e_w
+            worst = max(worst, e_w)
         else:
             e_d = float('nan')
         print('strided dgrad N%d Cin%d T%d->%d %dx%d Cout%d k%d s%d: kind %d | dgrad(+=) %.2e' % (N, Ci, Ti, To, H, W, Co, kt, st, kind_d, e_d), flush=True)
