@@ -388,8 +388,10 @@ def run_leg(args, dtype, rank, world, distributed, dev):
     try:        # HBM bytes per launch of this kernel family from the committed PMC passes (tools/pmc_traffic.py)
         for pj in sorted((f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_traffic.json')), reverse=True):
             fam = json.load(open(os.path.join(ROOT, 'profiles', pj)))['families']
-            if dominant in fam:
-                traffic, roof_src = round(fam[dominant]['hbm_bytes_per_launch']), pj
+            # (conv_tap's forward and data gradient are one kernel: the PMC tables have one family for both)
+            key = dominant if dominant in fam else dominant.replace('FWD,', '').replace('DGRAD,', '').replace('+bn_reduce', '')
+            if key in fam:
+                traffic, roof_src = round(fam[key]['hbm_bytes_per_launch']), pj
                 break
     except Exception:
         traffic = None

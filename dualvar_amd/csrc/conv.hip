@@ -2041,7 +2041,16 @@ void dvw_wgrad_tm_launch(const void* args, int grid, void* stream);
 static int wgrad_tm_kind(const dv_conv_desc* d) {
   static const int on = env_int("DUALVAR_WGRAD_TM", 1);           // (A/B switch; 2: temporal forms only)
   if (!on || d->dtype != DV_F32 || f32_exact()) return 0;
-  if (d->sh != 1 || d->sw != 1 || d->cin_pitch % 8 || d->cout_pitch % 8) return 0;
+  if (d->cin_pitch % 8 || d->cout_pitch % 8) return 0;
+  // 4: the pixel-pair RGB stem conv: window 1 x 7 x 4 over 8-channel pixel pairs, stride (1, 2, 1), no padding
+  if (on != 2 && d->kt == 1 && d->kh == 7 && d->kw == 4 && d->st == 1 && d->sh == 2 && d->sw == 1 && !d->pt && !d->ph && !d->pw &&
+      d->cin_pitch == 8 && d->ldx == 8 && d->Wo <= 64 && d->Wi <= 68) {
+    const int64_t Mx = (int64_t)d->N * d->Ti * d->Hi * d->Wi, M = (int64_t)d->N * d->To * d->Ho * d->Wo;
+    static const int min_rows4 = env_int("DUALVAR_CONV_TAP_GRID", 128) <= 1 ? 1 : 8192;
+    if (Mx * 32 < (1ll << 31) && (M - 1) * d->ldy * 4 + (int64_t)d->cout_pitch * 4 < (1ll << 31) && M >= min_rows4) return 4;
+    return 0;
+  }
+  if (d->sh != 1 || d->sw != 1) return 0;
   int kind = 0;
   if (d->kh == 1 && d->kw == 1 && !d->ph && !d->pw) {
     if (d->kt == 3 && d->st == 1 && d->pt == 1 && d->To == d->Ti && (d->Ti == 2 || d->Ti == 4)) kind = 1;
@@ -2053,7 +2062,7 @@ static int wgrad_tm_kind(const dv_conv_desc* d) {
     // stay on conv_wgrad_dma_kernel (isolated, one box)
     const int64_t rows = (int64_t)d->N * d->Ti * d->Hi * d->Wi;
     static const int any_size = env_int("DUALVAR_CONV_TAP_GRID", 128) <= 1;
-    if (any_size || (rows >= 50000 && (d->cin_pitch + 63) / 64 * 64 * 10 <= d->cin_pitch * 11)) kind = 3;
+    if ((any_size && d->cin_pitch >= 16) || (rows >= 50000 && (d->cin_pitch + 63) / 64 * 64 * 10 <= d->cin_pitch * 11)) kind = 3;
   }
   if (!kind) return 0;
   const int64_t Mx = (int64_t)d->N * d->Ti * d->Hi * d->Wi, M = (int64_t)d->N * d->To * d->Ho * d->Wo;
@@ -2089,13 +2098,16 @@ static WgradPlan plan_wgrad(const dv_conv_desc* d) {
     p.BI = 64; p.BJ = (tmk == 3 ? 3 : d->kt) * bc;
     p.nti = (d->Cout + 63) / 64; p.ntj = (d->cin_pitch + bc - 1) / bc;
     const int krows = tmk == 3 ? 3 : 1;                           // spatial: one workgroup per kernel row dh
-    if (tmk == 3) {
+    if (tmk == 4) {
+      p.BJ = 224; p.ntj = 1;
+      p.nchunks = d->N * d->To * d->Ho;                           // output lines
+    } else if (tmk == 3) {
       p.nchunks = (M + 63) / 64;                                  // 64-row steps
     } else {
       const int pxs = 64 / d->To;
       p.nchunks = (int)(((int64_t)d->N * d->Hi * d->Wi + pxs - 1) / pxs);
     }
-    int splits = std::max(1, (tmk == 2 ? 512 : 768) / (p.nti * p.ntj * krows));      // (the stem form: two workgroups per CU)
+    int splits = std::max(1, ((tmk == 2 || tmk == 4) ? 512 : 768) / (p.nti * p.ntj * krows));      // (the stem forms: two workgroups per CU)
     splits = std::min(splits, std::max(1, p.nchunks / 8));
     const double slab_us = 8.0 * d->Cout * (double)J / 4e6;
     const int s_opt = (int)(std::sqrt(p.nchunks * 1.2 / slab_us) + 0.5);          // ~1.2 us per step of one workgroup
@@ -2188,6 +2200,7 @@ extern "C" int64_t dv_conv3d_wgrad_workspace(const dv_conv_desc* d) {
 
 // the plan runs on conv_wgrad_dma_kernel<float, 64, 128, 1, 4, 2, true, true>, the form that can carry dv_conv3d_wgrad_bn
 static bool wgrad_plan_is_share(const dv_conv_desc* d, const WgradPlan& p) {
+  if (p.tm) return wgrad_tm_kind(d) == 4;        // conv_wgrad_pp_kernel<BNA> (conv_tap_wgrad.hip)
   return p.dma && d->dtype == DV_F32 && !f32_exact() && p.f32s < 0 && p.cfg == 1;
 }
 extern "C" int dv_conv3d_wgrad_bn_ok(const dv_conv_desc* d) {
@@ -2240,6 +2253,17 @@ static int wgrad_impl(const dv_conv_desc* d, const void* x, const void* dy, floa
     t.fS = make_fastdiv((uint32_t)t.S);
     t.M = a.M; t.H = d->Hi; t.W = d->Wi;
     t.fW = make_fastdiv((uint32_t)d->Wi); t.fH = make_fastdiv((uint32_t)d->Hi);
+    t.Wo = d->Wo; t.Ho = d->Ho; t.Wp = d->Wi; t.Hp = d->Hi;
+    t.bn_x = nullptr;
+    if (t.kind == 4) {
+      t.fH = make_fastdiv((uint32_t)d->Ho);                      // line -> (image, output line)
+      if (bn) {
+        t.bn_x = bn->x; t.bn_mean = bn->mean; t.bn_invstd = bn->invstd; t.bn_gamma = bn->gamma; t.bn_scale = bn->scale;
+        t.bn_shift = bn->shift; t.bn_sums = bn->sums; t.bn_dgamma = bn->dgamma; t.bn_dbeta = bn->dbeta;
+        t.bn_inv_count = bn->inv_count; t.bn_dscale = bn->dparam_scale; t.bn_rep = bn->n_rep;
+        t.bn_mask = (bn->flags & DV_NO_RELU_MASK) ? 0 : 1;
+      }
+    }
     dvw_wgrad_tm_launch(&t, t.kind == 3 ? grid * 3 : grid, stream);
   } else if (p.dma) {
     const int64_t es = d->dtype == DV_F32 ? 4 : 2;

@@ -434,6 +434,15 @@ struct TmWgradArgs {
   FastDiv fS;
   int M, H, W;
   FastDiv fW, fH;
+  // kind 4: the pixel-pair RGB stem conv (window 1 x 7 x 4 over 8-channel pixel pairs, stride (1, 2, 1), no padding): one output
+  // line per step.  Wo / Ho output pixels per line / lines per frame, Wp / Hp pairs per input line / input lines per frame,
+  // nchunks = N * T * Ho lines.  bn_x != nullptr: the dY operand is dv_bn_bwd_apply's output formed on the fly (dv_conv3d_wgrad_bn)
+  int Wo, Ho, Wp, Hp;
+  const void* bn_x;
+  const float *bn_mean, *bn_invstd, *bn_gamma, *bn_scale, *bn_shift, *bn_sums;
+  float *bn_dgamma, *bn_dbeta;
+  float bn_inv_count, bn_dscale;
+  int bn_rep, bn_mask;
 };
 
 }  // namespace

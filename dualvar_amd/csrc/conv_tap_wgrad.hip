@@ -393,13 +393,204 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Pixel-pair stem form: the weight gradient of the network's first conv (backbone/s3dg.py:151 Conv_1a.conv1, 1x7x7 / stride 2 on
+// RGB -- here a 1 x 7 x 4 window over 8-channel pixel pairs of the bordered frames, stride (1, 2, 1)), with
+// or without the following BatchNorm's backward apply formed on the fly (BNA: dv_conv3d_wgrad_bn -- the conv's input needs no
+// gradient, so this kernel is dL/d(conv output)'s only reader).  It is the largest kernel of the step and the last of the
+// weight-gradient tail.  One OUTPUT LINE (Wo <= 64 pixels = the K of the MFMAs, padded with zero rows) per step:
+//   * dY planes [64 rows][64 channels] as in the other forms (BNA: k1 * g' + k2 * y + k3 per element in front of the split, with
+//     dv_bn_bwd_apply's expression; the per-channel coefficients sit in LDS);
+//   * the seven input lines the window reaches as planes [dh][pair][8 channels] (16-byte rows): the 32 columns of kernel row dh
+//     are its four pair taps x 8 channels, and a lane's transposed read takes its 4-column group from pair (pixel + tap) --
+//     the im2col matrix is never formed.  224 columns = 7 blocks; wave (bi, parity) carries the kernel rows of its parity.
+template <bool BNA>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_pp_kernel(TmWgradArgs a) {
+  constexpr int KH = 7, KS = 4, RBY = 128, XROWS = 68, XRB = 16;
+  constexpr int YPLANE = 64 * RBY, YOP = 3 * YPLANE;
+  constexpr int XLINE = XROWS * XRB, XPLANE = KH * XLINE, XOP = 3 * XPLANE;
+  constexpr int COFF = YOP + XOP;                                // BNA: k1 | k2 | k3 | scale | shift, 64 floats each
+  constexpr unsigned kOOB = 0x80000000u;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[COFF + 5 * 64 * 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  int bid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_i = bid % a.nti;
+  const int split = bid / a.nti;
+  const int i0 = tile_i * 64;
+  const int bi = wave >> 1, par = wave & 1;
+  const int ln_begin = split * a.chunks_per_split, ln_end = min(a.nchunks, ln_begin + a.chunks_per_split);
+  const dma_rsrc_t x_rs = dma_make_rsrc(a.x, (unsigned)a.x_bytes), dy_rs = dma_make_rsrc(a.dy, (unsigned)a.dy_bytes);
+  const dma_rsrc_t bx_rs = dma_make_rsrc(BNA ? a.bn_x : a.dy, (unsigned)a.dy_bytes);
+  const unsigned ldyb = (unsigned)a.ldy * 4u;
+  const int Wo = a.Wo, Wp = a.Wp;
+
+  // zero everything once: the K padding rows of the dY planes and the pairs past the end of a line are never written again
+  for (int o = tid * 16; o < COFF; o += 256 * 16) *reinterpret_cast<f32x4*>(smem + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (BNA) {
+    if (tid < 64) {
+      const int c = i0 + tid, cpb = (a.Cout + 7) & ~7;
+      float k1 = 0.f, k2 = 0.f, k3 = 0.f, sc = 0.f, sh = 0.f;
+      if (c < a.Cout) {
+        float sg = 0.f, sgx = 0.f;
+        for (int r = 0; r < a.bn_rep; ++r) { sg += a.bn_sums[(size_t)r * 2 * cpb + c]; sgx += a.bn_sums[(size_t)r * 2 * cpb + cpb + c]; }
+        k1 = a.bn_gamma[c] * a.bn_invstd[c];
+        k2 = -k1 * a.bn_invstd[c] * sgx * a.bn_inv_count;
+        k3 = -k1 * sg * a.bn_inv_count - k2 * a.bn_mean[c];
+        if (a.bn_mask) { sc = a.bn_scale[c]; sh = a.bn_shift[c]; }
+        if (split == 0 && a.bn_dgamma) {                         // one workgroup per channel tile: dgamma, dbeta
+          a.bn_dbeta[c] += a.bn_dscale * sg;
+          a.bn_dgamma[c] += a.bn_dscale * sgx;
+        }
+      }
+      float* cf = reinterpret_cast<float*>(smem + COFF);
+      cf[tid] = k1; cf[64 + tid] = k2; cf[128 + tid] = k3; cf[192 + tid] = sc; cf[256 + tid] = sh;
+    }
+  }
+
+  // staging roles: dY units u = tid, tid + 256 (row u >> 3 < Wo, channel group u & 7 = tid & 7); x units u = tid, tid + 256 < 7 * Wp
+  const int ch8 = tid & 7;
+  const unsigned ycol = i0 + ch8 * 8 + 8 <= a.CoutP ? (unsigned)(i0 + ch8 * 8) * 4u : kOOB;
+  unsigned ywr[2], xwr[2], xsrc[2];
+  bool yok[2], xok[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int u = tid + 256 * k, row = u >> 3;
+    yok[k] = row < Wo && ycol != kOOB;
+    ywr[k] = (unsigned)(row * RBY + ((ch8 ^ (wg_swz<RBY>(row) << 2)) << 4));
+    const int dh = u / Wp, wp = u - dh * Wp;
+    xok[k] = u < KH * Wp;
+    xwr[k] = (unsigned)(YOP + dh * XLINE + wp * XRB);
+    xsrc[k] = (unsigned)((dh * Wp + wp) * 32);                   // bytes from the first pair of input line (2 ho + 0)
+  }
+  f32x4 greg[2][2], breg[2][2], xreg[2][2];
+  auto issue = [&](int line) {
+    const unsigned m0 = (unsigned)line * (unsigned)Wo;           // first output row of the line
+    const unsigned img = fd_div((uint32_t)line, a.fH);           // (n * T + t); ho = line - img * Ho
+    const unsigned ho = (unsigned)line - img * (unsigned)a.Ho;
+    const unsigned xline0 = ((img * (unsigned)a.Hp + 2u * ho) * (unsigned)Wp) * 32u;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const unsigned yo = yok[k] ? (m0 + (unsigned)((tid + 256 * k) >> 3)) * ldyb + ycol : kOOB;
+      tw_gload16(greg[k][0], dy_rs, yo);
+      tw_gload16_hi(greg[k][1], dy_rs, yo);
+      if constexpr (BNA) {
+        tw_gload16(breg[k][0], bx_rs, yo);
+        tw_gload16_hi(breg[k][1], bx_rs, yo);
+      }
+      const unsigned xo = xok[k] ? xline0 + xsrc[k] : kOOB;
+      tw_gload16(xreg[k][0], x_rs, xo);
+      tw_gload16_hi(xreg[k][1], x_rs, xo);
+    }
+  };
+  auto write3 = [&](unsigned off, int plane, const Split3& q3) {
+    *reinterpret_cast<bf16x8*>(smem + off) = q3.hi;
+    *reinterpret_cast<bf16x8*>(smem + off + plane) = q3.mid;
+    *reinterpret_cast<bf16x8*>(smem + off + 2 * plane) = q3.lo;
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+  // this lane's part of an x fragment address: rows (pixel + pair tap), 8-byte column half
+  const int g16 = lane >> 4, li = lane & 15, fq = li >> 2, fp = li & 3;
+  const int cg = (g16 & 1) * 4 + fp;
+  const unsigned xlane = (unsigned)(YOP + (8 * (g16 >> 1) + fq + (cg >> 1)) * XRB + (cg & 1) * 8);
+
+  __syncthreads();                             // zeros and coefficients are in place
+  if (ln_begin < ln_end) issue(ln_begin);
+  for (int ln = ln_begin; ln < ln_end; ++ln) {
+    if constexpr (BNA)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(greg[0][0]), "+v"(greg[0][1]), "+v"(greg[1][0]), "+v"(greg[1][1]), "+v"(breg[0][0]), "+v"(breg[0][1]),
+                     "+v"(breg[1][0]), "+v"(breg[1][1]), "+v"(xreg[0][0]), "+v"(xreg[0][1]), "+v"(xreg[1][0]), "+v"(xreg[1][1])::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(greg[0][0]), "+v"(greg[0][1]), "+v"(greg[1][0]), "+v"(greg[1][1]), "+v"(xreg[0][0]), "+v"(xreg[0][1]),
+                     "+v"(xreg[1][0]), "+v"(xreg[1][1])::"memory");
+    Split3 sy[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float v[8] = {greg[k][0].x, greg[k][0].y, greg[k][0].z, greg[k][0].w, greg[k][1].x, greg[k][1].y, greg[k][1].z, greg[k][1].w};
+      if constexpr (BNA) {
+        const float xv[8] = {breg[k][0].x, breg[k][0].y, breg[k][0].z, breg[k][0].w, breg[k][1].x, breg[k][1].y, breg[k][1].z, breg[k][1].w};
+        const float* cf = reinterpret_cast<const float*>(smem + COFF) + ch8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float act = xv[e] * cf[192 + e] + cf[256 + e];   // the forward's expression (dv_bn_apply), same rounding
+          const float gg = (a.bn_mask && !(act > 0.f)) ? 0.f : v[e];
+          v[e] = cf[e] * gg + cf[64 + e] * xv[e] + cf[128 + e];  // dv_bn_bwd_apply's expression
+        }
+      }
+      sy[k] = split3w(v);
+    }
+    __syncthreads();                           // every wave has read its last fragments of the previous line's planes
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (yok[k]) write3(ywr[k], YPLANE, sy[k]);
+      if (xok[k]) {
+        const float v[8] = {xreg[k][0].x, xreg[k][0].y, xreg[k][0].z, xreg[k][0].w, xreg[k][1].x, xreg[k][1].y, xreg[k][1].z, xreg[k][1].w};
+        write3(xwr[k], XPLANE, split3w(v));
+      }
+    }
+    __syncthreads();
+    if (ln + 1 < ln_end) issue(ln + 1);        // in flight underneath this line's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      Split3 av;
+      av.hi = wg_frag<RBY>(smem, bi * 32, lane, ks);
+      av.mid = wg_frag<RBY>(smem + YPLANE, bi * 32, lane, ks);
+      av.lo = wg_frag<RBY>(smem + 2 * YPLANE, bi * 32, lane, ks);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int dh = 2 * d + par;
+        if (dh >= KH) continue;                                  // (wave-uniform: the odd-parity waves carry three kernel rows)
+        const unsigned ad = xlane + (unsigned)(dh * XLINE + ks * 16 * XRB);
+        auto rd = [&](unsigned o) -> bf16x8 {
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + o));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + o + 4 * XRB));
+          s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          return __builtin_bit_cast(bf16x8, v);
+        };
+        Split3 b;
+        b.hi = rd(ad); b.mid = rd(ad + XPLANE); b.lo = rd(ad + 2 * XPLANE);
+        mma_split3(av, b, acc[d]);
+      }
+    }
+  }
+
+  // ---- epilogue: block (bi, dh) is columns dh * 32 .. + 31 of dW (its four pair taps x 8 channels)
+  const int nrow0 = i0 + bi * 32;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int dh = 2 * d + par;
+    if (dh >= KH) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = nrow0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (n < a.Cout) {
+        const size_t e = (size_t)n * a.ldw + (size_t)dh * 32 + l31;
+        if (a.slab) a.slab[(size_t)split * a.slab_stride + e] = acc[d][r];
+        else a.dw[e] += acc[d][r];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // entry point for conv.hip (the argument block is conv_common.hpp's TmWgradArgs, passed by address)
 void dvw_wgrad_tm_launch(const void* args, int grid, void* stream) {
   const TmWgradArgs& a = *static_cast<const TmWgradArgs*>(args);
   hipStream_t s = (hipStream_t)stream;
-  if (a.kind == 3) hipLaunchKernelGGL((conv_wgrad_sp_kernel<0>), dim3(grid), dim3(256), 0, s, a);
+  if (a.kind == 4) {
+    if (a.bn_x) hipLaunchKernelGGL((conv_wgrad_pp_kernel<true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_pp_kernel<false>), dim3(grid), dim3(256), 0, s, a);
+  } else if (a.kind == 3) hipLaunchKernelGGL((conv_wgrad_sp_kernel<0>), dim3(grid), dim3(256), 0, s, a);
   else if (a.kind == 2) hipLaunchKernelGGL((conv_wgrad_tm_kernel<4, 8, 7, 2, 3, 32>), dim3(grid), dim3(256), 0, s, a);
   else if (a.T == 4) hipLaunchKernelGGL((conv_wgrad_tm_kernel<4, 4, 3, 1, 1, 64>), dim3(grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv_wgrad_tm_kernel<2, 2, 3, 1, 1, 64>), dim3(grid), dim3(256), 0, s, a);

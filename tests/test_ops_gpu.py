@@ -1377,10 +1377,17 @@ def test_lds_staged_input_tile_kernel_on_small_and_ragged_shapes(gpu):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'tap_check.py')], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, DUALVAR_CONV_TAP_GRID='1'))
+    env = dict(os.environ, DUALVAR_CONV_TAP_GRID='1')
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'tap_check.py')], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout[-3000:] + r.stderr[-2000:]
     assert 'kind fwd 0' not in r.stdout and 'dgrad 0' not in r.stdout, r.stdout[-3000:]
+    # the pixel-pair stem form of the LDS-staged weight gradient (conv_wgrad_pp_kernel, with and without the BatchNorm apply
+    # inside) on the small stem shapes of this file: the same tests, with the size thresholds lifted
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k',
+                        '(batchnorm_backward_apply_inside and shape0) or rgb_stem_as_pixel_pair or (conv_fwd_dgrad_wgrad and pair_stem)'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=root)
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0 and ' passed' in tail, tail
 
 
 SENTINEL_CASES = [

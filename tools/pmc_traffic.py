@@ -50,6 +50,18 @@ def short(name):
     m = re.search(r'conv_gemm_ks_kernelILi(\d)ELi(\d+)E', n) or re.search(r'conv_gemm_ks_kernel<(\d), (\d+)', n)
     if m:
         return 'conv_gemm_ks<f32,%s,64,%s>' % ('DGRAD' if m.group(1) == '1' else 'FWD', m.group(2))
+    # the LDS-staged kernels of round 4 (csrc/conv_tap.hip, conv_tap_wgrad.hip)
+    m = re.search(r'conv_tap_kernelILi(\d)E', n) or re.search(r'conv_tap_kernel<(\d)', n)
+    if m:
+        return 'conv_tap<f32,%s,256,64>' % ('sp' if m.group(1) == '0' else 'tm')          # (fwd and dgrad are one kernel)
+    m = re.search(r'conv_wgrad_tm_kernelILi\d+ELi\d+ELi(\d+)ELi\d+ELi\d+ELi(\d+)E', n) or \
+        re.search(r'conv_wgrad_tm_kernel<\d+, \d+, (\d+), \d+, \d+, (\d+)>', n)
+    if m:
+        return 'conv_wgrad<f32,16,64,%d>' % (int(m.group(1)) * int(m.group(2)))
+    if re.search(r'conv_wgrad_sp_kernel', n):
+        return 'conv_wgrad<f32,16,64,192>'
+    if re.search(r'conv_wgrad_pp_kernel', n):
+        return 'conv_wgrad<f32,16,64,224>' + ('+bn_bwd_apply' if re.search(r'pp_kernelILb1E|pp_kernel<true>', n) else '')
     m = re.search(r'conv_wgrad_f32s_kernelILi(\d+)ELi(\d+)E', n) or re.search(r'conv_wgrad_f32s_kernel<(\d+), (\d+)', n)
     if m:
         return 'conv_wgrad<f32,16,%s,%s>' % (m.group(1), m.group(2))
