@@ -389,7 +389,8 @@ def run_leg(args, dtype, rank, world, distributed, dev):
         for pj in sorted((f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc_traffic.json')), reverse=True):
             fam = json.load(open(os.path.join(ROOT, 'profiles', pj)))['families']
             # (conv_tap's forward and data gradient are one kernel: the PMC tables have one family for both)
-            key = dominant if dominant in fam else dominant.replace('FWD,', '').replace('DGRAD,', '').replace('+bn_reduce', '')
+            key = dominant.replace('+bn_in', '')         # (the BatchNorm-on-load instantiations are counted with their family)
+            key = key if key in fam else key.replace('FWD,', '').replace('DGRAD,', '').replace('+bn_reduce', '')
             if key in fam:
                 traffic, roof_src = round(fam[key]['hbm_bytes_per_launch']), pj
                 break

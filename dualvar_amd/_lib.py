@@ -54,6 +54,11 @@ class BnReduce(C.Structure):
                 [(n, C.c_int32) for n in ('ldx', 'n_rep', 'flags', '_pad')])
 
 
+class BnIn(C.Structure):
+    """dv_bn_in: the BatchNorm (+ReLU) a conv applies to its input on load, for dv_conv3d_fwd_bn_in / dv_conv3d_wgrad_bn_in"""
+    _fields_ = [('scale', C.c_void_p), ('shift', C.c_void_p), ('flags', C.c_int32), ('_pad', C.c_int32)]
+
+
 class BnBwd(C.Structure):
     """dv_bn_bwd: the BatchNorm behind a conv whose input needs no gradient, for dv_conv3d_wgrad_bn"""
     _fields_ = ([(n, C.c_void_p) for n in ('x', 'mean', 'invstd', 'gamma', 'scale', 'shift', 'sums', 'dgamma', 'dbeta')] +
@@ -94,6 +99,9 @@ SIGNATURES = {
     'dv_conv3d_wgrad_tile': [CD, P, P, P],
     'dv_conv3d_wgrad': [CD, P, P, P, P, I64, P],
     'dv_conv3d_wgrad_bn_ok': [CD],
+    'dv_conv3d_bn_in_ok': [CD],
+    'dv_conv3d_fwd_bn_in': [CD, P, P, P, P, P, P],
+    'dv_conv3d_wgrad_bn_in': [CD, P, P, P, P, P, I64, P],
     'dv_conv3d_wgrad_bn': [CD, P, P, P, P, I64, P, P],
     'dv_quantize_fp8_workspace': [],
     'dv_quantize_fp8': [I32, P, I64, I32, I32, I32, P, I32, P, P, P],

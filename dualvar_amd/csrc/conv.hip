@@ -42,12 +42,16 @@ constexpr int conv_waves_per_simd(int es, int gvb, int bm, int bn) {
 // bf16, 48 bytes per (row, h)), so a B tile is two contiguous chunks that the DMA copies as they are and a lane's three
 // operand fragments are three conflict-free ds_read_b128 -- no vector instruction is spent on the weight operand; only
 // the activation fragments are split in the kernel (the kernel was bound by exactly those instructions).
+// BNL (dv_conv3d_fwd_bn_in): the gathered tensor is the INPUT of the BatchNorm (+ReLU) in front of this conv; the A fragments are
+// y = [relu](x * scale + shift) formed between the LDS read and the split (coefficients in a small LDS table, one inverted tap
+// mask per fragment row: a tap that leaves the tensor is a ZERO of y, not [relu](shift)).
 template <typename T, int MODE, int GVB, int BM, int BN, int WAVES_M, int WAVES_N, int GM, int NS = 2, bool SPLIT = false,
-          bool WF = false>
+          bool WF = false, bool BNL = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64)
 __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))) void conv_gemm_kernel(ConvArgs a) {
   static_assert(!SPLIT || sizeof(T) == 4, "the bf16 split is the fp32 mode's product");
   static_assert(!WF || (SPLIT && GVB == 16), "pre-split weights belong to the fp32 split kernels");
+  static_assert(!BNL || (WF && GM == 1 && MODE == MODE_FWD), "BatchNorm on load: forward, uniform-tap gathers, pre-split weights");
   // DMA: 16-byte gathers go global -> LDS directly (buffer_load ... lds), no VGPR staging and no ds_write.  One wave
   // instruction fills 16 rows x 64 B = 1 KiB of a row-linear, UNPADDED tile; bank conflicts of the ds_read_b128 fragment
   // reads are avoided by XOR-swizzling the 16-byte slot with (row>>2)&3, applied on the source side (which k-slot a
@@ -178,7 +182,34 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
     for (int p = 0; p < B_G; ++p)
       if (!WF && woff[p] != kOOB) woff[p] += (unsigned)vslot * GVB;
   }
-  __syncthreads();                             // taptab
+  // BNL: scale | shift of the gathered channels (pad lanes: 0, 0) and the inverted tap masks of this lane's FRAGMENT rows
+  constexpr int kBnlC = 256;
+  float* bncoef = nullptr;
+  unsigned cmask[TM];
+  int c_c0 = 0, c_tap = 0;                     // wave-uniform K cursor of the tile being multiplied
+  if constexpr (BNL) {
+    __shared__ __attribute__((aligned(16))) float bntab[2 * kBnlC];
+    bncoef = bntab;
+    for (int c = tid; c < g.CP; c += NT) {
+      bntab[c] = c < a.in_C ? a.in_scale[c] : 0.f;
+      bntab[kBnlC + c] = c < a.in_C ? a.in_shift[c] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const RowPos r = decode_row<MODE>((uint32_t)(m0 + wm0 + i * 32 + l31), a.M, g);
+      unsigned inv = 0;
+      int tp = 0;
+      for (int dt = 0; dt < g.kt; ++dt)
+        for (int dh = 0; dh < g.kh; ++dh)
+          for (int dw = 0; dw < g.kw; ++dw, ++tp) {
+            const bool ok = r.valid && (unsigned)(r.t0 + dt) < (unsigned)g.sT && (unsigned)(r.h0 + dh) < (unsigned)g.sH &&
+                            (unsigned)(r.w0 + dw) < (unsigned)g.sW;
+            inv |= (ok ? 0u : 1u) << tp;
+          }
+      cmask[i] = inv;
+    }
+  }
+  __syncthreads();                             // taptab (and the coefficient table)
 
   const int nk = (g.Ktot + BKE - 1) / BKE;
   vec_t ra[A_G], rb[B_G];
@@ -279,8 +310,31 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
     if constexpr (SPLIT) {
       // each fragment is split ONCE per K tile and used by TN (TM) blocks
       Split3 af[TM], bf[TN];
+      if constexpr (BNL) {
+        const f32x4* cs = reinterpret_cast<const f32x4*>(bncoef + c_c0 + 8 * h);
+        const f32x4* ch = reinterpret_cast<const f32x4*>(bncoef + kBnlC + c_c0 + 8 * h);
+        const f32x4 s0 = cs[0], s1 = cs[1], h0 = ch[0], h1 = ch[1];
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const unsigned char* row = smem + buf * BUFB + (wm0 + i * 32 + l31) * PITCH;
+          const f32x4 lo4 = *reinterpret_cast<const f32x4*>(row + ((2 * h) ^ swz) * 16);
+          const f32x4 hi4 = *reinterpret_cast<const f32x4*>(row + ((2 * h + 1) ^ swz) * 16);
+          float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+          // [relu] and "a tap outside the tensor is a zero of y" as ONE clamp per element: live rows [0 | -inf, +inf], dead rows [0, 0]
+          const bool dead = (cmask[i] >> c_tap) & 1u;
+          const float lo = (dead || a.in_relu) ? 0.f : -__builtin_inff(), hi = dead ? 0.f : __builtin_inff();
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * sc[e] + sh[e], lo, hi);      // dv_bn_apply's expression
+          af[i] = split3(v);
+        }
+        c_c0 += BKE;
+        if (c_c0 >= g.CP) { c_c0 = 0; ++c_tap; }
+      } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = split3_row(smem + buf * BUFB + (wm0 + i * 32 + l31) * PITCH, h, swz);
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if constexpr (WF) {
@@ -1526,6 +1580,12 @@ static void pick_tile(int dtype, int M, int NP, int& bm, int& bn) {
 template <typename T, int MODE, int GVB, int GM, int NS, bool SPLIT = false, bool WF = false>
 static void launch_gemm_ns(int bm, int bn, const ConvArgs& a, int grid, hipStream_t s) {
   if constexpr (WF) {       // pre-split weights: the instantiations the fp32 split mode uses
+    if constexpr (MODE == MODE_FWD && GM == 1 && NS == 2 && sizeof(T) == 4) {
+      if (a.in_scale != nullptr) {             // BatchNorm on load (fwd_impl has checked: 256 x 64 tile, channel pitch <= 256)
+        hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 256, 64, 4, 1, GM, NS, true, true, true>), dim3(grid), dim3(256), 0, s, a);
+        return;
+      }
+    }
     if (bm == 256) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 256, 64, 4, 1, GM, NS, true, true>), dim3(grid), dim3(256), 0, s, a);
     else if (bm == 64 && bn == 32) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 32, 2, 1, GM, NS, true, true>), dim3(grid), dim3(128), 0, s, a);
     else if (bm == 64 && bn == 64) hipLaunchKernelGGL((conv_gemm_kernel<T, MODE, GVB, 64, 64, 2, 2, GM, NS, true, true>), dim3(grid), dim3(256), 0, s, a);
@@ -1773,8 +1833,30 @@ extern "C" int dv_conv3d_stat_tiles(const dv_conv_desc* d) {
   return (int)((m + bm - 1) / bm);
 }
 
-extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
-                             float* stats, void* stream) {
+// which forward kernel can apply a BatchNorm to its INPUT (dv_conv3d_fwd_bn_in): 1 the LDS-staged temporal form, 2 conv_gemm's
+// 256 x 64 uniform-tap form; 0 none
+static int fwd_bn_in_path(const dv_conv_desc* d) {
+  if (d->dtype != DV_F32 || f32_exact() || !(d->flags & DV_W3) || (d->flags & (DV_BIAS | DV_RELU | DV_SIGMOID))) return 0;
+  if (d->cin_pitch % 16 != 0) return 0;
+  static const float dummy = 0.f;
+  ConvArgs a;
+  query_args(d, 0, a);
+  a.in_scale = &dummy;
+  if (d->st == 1 && d->sh == 1 && d->sw == 1) {
+    trim_dead_taps(a, MODE_FWD, d->dtype);
+    if (a.cls_on) return 0;
+    if (dvt_conv_tap_kind(&a, MODE_FWD)) return 1;
+    if (tap_choice(d, 0)) return 0;          // (the plain launch would take the spatial LDS-staged form: keep it)
+  }
+  if (d->cin_pitch > 256 || d->kt * d->kh * d->kw > 32) return 0;
+  int bm, bn;
+  pick_tile(d->dtype, a.M, a.NP, bm, bn);
+  if (bm != 256 || bn != 64 || ks_tile(d->dtype, a, bm)) return 0;
+  return 2;
+}
+
+static int fwd_impl(const dv_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats,
+                    const dv_bn_in* bn_in, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!x || !w || !y) return DV_EINVAL;
@@ -1792,6 +1874,13 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   if (w3 && (d->dtype != DV_F32 || f32_exact())) return DV_EUNSUPPORTED;
   if (w3) { a.flags |= DV_W3; a.ldw = w3_rows(d->Cout); }
   a.cls_on = 0;
+  int bn_path = 0;
+  if (bn_in) {
+    if (!bn_in->scale || !bn_in->shift) return DV_EINVAL;
+    bn_path = fwd_bn_in_path(d);
+    if (!bn_path) return DV_EUNSUPPORTED;
+    a.in_scale = bn_in->scale; a.in_shift = bn_in->shift; a.in_C = d->Cin; a.in_relu = (bn_in->flags & DV_RELU) ? 1 : 0;
+  }
   {
     const int64_t es = d->dtype == DV_F32 ? 4 : 2;
     const int64_t sb = ((int64_t)d->N * d->Ti * d->Hi * d->Wi - 1) * d->ldx * es + (int64_t)d->cin_pitch * es;
@@ -1809,14 +1898,15 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   if (gvb == 16 && !aligned16(x)) return DV_EALIGN;
   const int esz = d->dtype == DV_F32 ? 4 : 2;
   if ((d->ldx * esz) % gvb || (a.ldw * esz) % gvb) return DV_EALIGN;
-  trim_dead_taps(a, MODE_FWD, d->dtype);
-  if (d->dtype == DV_F32 && w3 && dvt_conv_tap_launch(&a, MODE_FWD, stream)) return dv_launch_status();
+  if (bn_path != 2) trim_dead_taps(a, MODE_FWD, d->dtype);
+  if (d->dtype == DV_F32 && w3 && bn_path != 2 && dvt_conv_tap_launch(&a, MODE_FWD, stream)) return dv_launch_status();
+  if (bn_path == 1) return DV_EUNSUPPORTED;          // (cannot happen: fwd_bn_in_path asked the same question)
   int bm, bn;
   pick_tile(d->dtype, a.M, a.NP, bm, bn);
   a.ntn = (a.NP + bn - 1) / bn;
   const int grid = a.ntn * ((a.M + bm - 1) / bm);
   hipStream_t s = (hipStream_t)stream;
-  if (const int kbn = ks_tile(d->dtype, a, bm)) {
+  if (const int kbn = bn_path ? 0 : ks_tile(d->dtype, a, bm)) {
     launch_ks<MODE_FWD>(kbn, a, s);
     return dv_launch_status();
   }
@@ -1824,6 +1914,17 @@ extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w
   else if (gvb == 16) launch_gemm<bf16_t, MODE_FWD, 16>(bm, bn, a, grid, s);
   else launch_gemm<bf16_t, MODE_FWD, 8>(bm, bn, a, grid, s);
   return dv_launch_status();
+}
+
+extern "C" int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
+                             float* stats, void* stream) {
+  return fwd_impl(d, x, w, bias, y, stats, nullptr, stream);
+}
+
+extern "C" int dv_conv3d_fwd_bn_in(const dv_conv_desc* d, const void* x_bn, const dv_bn_in* bn, const void* w, void* y,
+                                   float* stats, void* stream) {
+  if (!bn) return DV_EINVAL;
+  return fwd_impl(d, x_bn, w, nullptr, y, stats, bn, stream);
 }
 
 // ---- fp8 pointwise GEMMs (BASELINE configs[4]: the 1x1x1 convs of resnet_2d3d.py's bottleneck blocks) --------------------
@@ -2209,12 +2310,17 @@ extern "C" int dv_conv3d_wgrad_bn_ok(const dv_conv_desc* d) {
 }
 
 static int wgrad_impl(const dv_conv_desc* d, const void* x, const void* dy, float* dw, void* workspace,
-                      int64_t workspace_bytes, const dv_bn_bwd* bn, void* stream) {
+                      int64_t workspace_bytes, const dv_bn_bwd* bn, void* stream, const dv_bn_in* bn_in = nullptr) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!x || !dy || !dw) return DV_EINVAL;
   if (!aligned16(dy) || !aligned16(dw) || (reinterpret_cast<uintptr_t>(x) & 7)) return DV_EALIGN;
   const WgradPlan p = plan_wgrad(d);
+  if (bn_in) {
+    if (bn || !bn_in->scale || !bn_in->shift) return DV_EINVAL;
+    const int k = p.tm ? wgrad_tm_kind(d) : 0;
+    if (k != 1 && k != 2) return DV_EUNSUPPORTED;
+  }
   if (bn) {
     if (!bn->x || !bn->mean || !bn->invstd || !bn->gamma || !bn->sums || bn->n_rep <= 0) return DV_EINVAL;
     if ((bn->dgamma == nullptr) != (bn->dbeta == nullptr)) return DV_EINVAL;
@@ -2255,6 +2361,7 @@ static int wgrad_impl(const dv_conv_desc* d, const void* x, const void* dy, floa
     t.fW = make_fastdiv((uint32_t)d->Wi); t.fH = make_fastdiv((uint32_t)d->Hi);
     t.Wo = d->Wo; t.Ho = d->Ho; t.Wp = d->Wi; t.Hp = d->Hi;
     t.bn_x = nullptr;
+    if (bn_in) { t.in_scale = bn_in->scale; t.in_shift = bn_in->shift; t.in_C = d->Cin; t.in_relu = (bn_in->flags & DV_RELU) ? 1 : 0; }
     if (t.kind == 4) {
       t.fH = make_fastdiv((uint32_t)d->Ho);                      // line -> (image, output line)
       if (bn) {
@@ -2330,4 +2437,17 @@ extern "C" int dv_conv3d_wgrad_bn(const dv_conv_desc* d, const void* x, const vo
                                   int64_t workspace_bytes, const dv_bn_bwd* bn, void* stream) {
   if (!bn) return DV_EINVAL;
   return wgrad_impl(d, x, g, dw, workspace, workspace_bytes, bn, stream);
+}
+
+extern "C" int dv_conv3d_wgrad_bn_in(const dv_conv_desc* d, const void* x_bn, const dv_bn_in* bn, const void* dy, float* dw,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!bn) return DV_EINVAL;
+  return wgrad_impl(d, x_bn, dy, dw, workspace, workspace_bytes, nullptr, stream, bn);
+}
+
+extern "C" int dv_conv3d_bn_in_ok(const dv_conv_desc* d) {
+  if (!d || check_desc(d)) return 0;
+  const int k = wgrad_tm_kind(d);
+  if (k != 1 && k != 2) return 0;
+  return fwd_bn_in_path(d);
 }

@@ -97,6 +97,12 @@ struct ConvArgs {
   // bn_bytes = extent of bn_x for its buffer descriptor
   float* bn_ws;
   int bn_bytes;
+  // forward whose input is y = [relu](src * in_scale + in_shift) -- the BatchNorm (+ReLU) in front of this conv, whose output is
+  // never materialised (dv_conv3d_fwd_bn_in): src is that BatchNorm's INPUT and the affine map is applied where the operand
+  // fragments are formed, with dv_bn_apply's expression (same bits as the two-launch plan).  Channels >= in_C are pad lanes (zero).
+  const float* in_scale = nullptr;
+  const float* in_shift = nullptr;
+  int in_C = 0, in_relu = 0;
 };
 
 template <int BYTES> struct VecB;
@@ -443,6 +449,10 @@ struct TmWgradArgs {
   float *bn_dgamma, *bn_dbeta;
   float bn_inv_count, bn_dscale;
   int bn_rep, bn_mask;
+  // kinds 1, 2: the x operand is y = [relu](x * in_scale + in_shift) formed on the fly (dv_conv3d_wgrad_bn_in; see ConvArgs)
+  const float* in_scale = nullptr;
+  const float* in_shift = nullptr;
+  int in_C = 0, in_relu = 0;
 };
 
 }  // namespace

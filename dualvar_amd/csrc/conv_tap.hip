@@ -58,6 +58,10 @@ struct TapArgs {
   const float *bn_mean, *bn_invstd, *bn_scale, *bn_shift;
   float *bn_sums, *bn_ws;
   int bn_ldx, bn_mask, bn_bytes, bn_cpb;
+  // forward whose input is y = [relu](src * in_scale + in_shift), the BatchNorm in front of this conv (dv_conv3d_fwd_bn_in; BNL
+  // instantiation, temporal form): applied to the staged slab in front of the split
+  const float *in_scale, *in_shift;
+  int in_C, in_relu;
 };
 
 // rows / tickets of the ordered fold (the protocol of elementwise.hip's ordered_fold: sc1 stores -> s_waitcnt vmcnt(0) -> barrier ->
@@ -95,8 +99,10 @@ __device__ __forceinline__ void gload16_hi(f32x4& dst, dma_rsrc_t rsrc, unsigned
 
 // KIND 0: spatial (1 x kh x kw, NTAPS = kh * kw);  KIND 1: temporal (kt x 1 x 1, NTAPS = kt)
 // NU: staging units (8 channels of one position = 32 B) per thread: ceil(2 * npos / 256)
-template <int KIND, int NTAPS, int BN, int NS, int NU>
+// BNL: BatchNorm (+ReLU) of the layer in front applied to the staged slab (coefficients in an LDS table behind the zero slot)
+template <int KIND, int NTAPS, int BN, int NS, int NU, bool BNL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_tap_kernel(TapArgs a) {
+  static_assert(!BNL || KIND == 1, "BatchNorm on load: temporal form (rows past the end never share a tile row with valid ones)");
   constexpr int BM = 256, NW = 4, TM = 2, TN = BN / 32;
   constexpr int B_BYTES = BN * 96, BPC = B_BYTES / 1024;       // one weight stage: hi|mid|lo of both k halves, in 1 KiB DMA pieces
   static_assert(B_BYTES % 1024 == 0, "weight stage in 1 KiB pieces");
@@ -114,6 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int npp = a.npp;
   const unsigned planes_off = NS * B_BYTES;                     // [2][npp][48]
   const unsigned zero_off = planes_off + 2u * (unsigned)npp * 48u;        // 64 bytes of zeros
+  const unsigned coef_off = zero_off + 64u;                               // BNL: [scale | shift][CP] floats
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -159,10 +166,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // split the staged slab (registers -> bf16 triples), then store the triples into the planes (the caller has made sure that
   // nobody reads the planes any more)
   Split3 s3r[NU];
-  auto stage_split = [&]() {
+  const float bn_lo = (BNL && !a.in_relu) ? -__builtin_inff() : 0.f;
+  auto stage_split = [&](int c0) {
+    float sc[8], sh[8];
+    if constexpr (BNL) {                                        // every unit of this thread is channel half tid & 1 of the chunk
+      const f32x4* cs = reinterpret_cast<const f32x4*>(dsm + coef_off + (unsigned)(c0 + 8 * (tid & 1)) * 4u);
+      const f32x4* ch = reinterpret_cast<const f32x4*>(dsm + coef_off + (unsigned)(a.CP + c0 + 8 * (tid & 1)) * 4u);
+      const f32x4 s0 = cs[0], s1 = cs[1], h0 = ch[0], h1 = ch[1];
+      sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+      sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+    }
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-      const float v[8] = {sreg[k][0].x, sreg[k][0].y, sreg[k][0].z, sreg[k][0].w, sreg[k][1].x, sreg[k][1].y, sreg[k][1].z, sreg[k][1].w};
+      float v[8] = {sreg[k][0].x, sreg[k][0].y, sreg[k][0].z, sreg[k][0].w, sreg[k][1].x, sreg[k][1].y, sreg[k][1].z, sreg[k][1].w};
+      if constexpr (BNL) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], bn_lo);      // dv_bn_apply's expression; bn_lo = 0 | -inf
+      }
       s3r[k] = split3(v);
     }
   };
@@ -281,9 +301,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // ---- prologue: chunk 0 into the planes, the zero slot, the first D weight stages
   stage_issue(0);
   if (tid < 4) *reinterpret_cast<f32x4*>(dsm + zero_off + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (BNL) {
+    float* tab = reinterpret_cast<float*>(dsm + coef_off);
+    for (int c = tid; c < a.CP; c += 256) {
+      tab[c] = c < a.in_C ? a.in_scale[c] : 0.f;
+      tab[a.CP + c] = c < a.in_C ? a.in_shift[c] : 0.f;
+    }
+    __syncthreads();
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   stage_wait();
-  stage_split();
+  stage_split(0);
   stage_write();
   for (int s = 0; s < D && s < nsteps; ++s) w_issue(s, s);
   int cur = 0, nxt = D % NS;
@@ -304,7 +332,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (more) {
       stage_wait();
       __syncthreads();                         // every wave has read its last fragments of this chunk's planes
-      stage_split();                           // (splitting in front of the barrier instead was measured equal)
+      stage_split((c + 1) * 16);               // (splitting in front of the barrier instead was measured equal)
       stage_write();
     }
   }
@@ -518,6 +546,7 @@ static int tap_kind(const ConvArgs& a, int mode) {
   if (!(a.flags & DV_W3) || (a.flags & (DV_BIAS | DV_RELU | DV_SIGMOID)) || a.out_bytes <= 0) return 0;
   // the fused BatchNorm-backward reduce: only in its ordered form (workspace given), on a data gradient that is not accumulated
   if (a.bn_x != nullptr && (a.bn_ws == nullptr || a.bn_bytes <= 0 || mode != MODE_DGRAD || (a.flags & DV_ACCUM))) return 0;
+  if (a.cls_on == 1 && a.in_scale != nullptr) return 0;
   if (a.cls_on == 1) {
     // one parity class of a t-strided kt x 1 x 1 data gradient (S3D-G's 7x1x1 / stride 2 stem conv, backbone/s3dg.py:151): 3 or 4
     // taps over the four frames of dY, rows = the class's four frames of dX
@@ -529,6 +558,8 @@ static int tap_kind(const ConvArgs& a, int mode) {
   }
   if (a.cls_on) return 0;
   if (mode != MODE_FWD && (a.flags & DV_STATS)) return 0;
+  // BatchNorm on load: forward of the stride-1 temporal form only
+  if (a.in_scale != nullptr && !(mode == MODE_FWD && g.kt == 3 && g.kh == 1 && g.kw == 1 && g.CP <= 512)) return 0;
   if (g.st != 1 || g.sh != 1 || g.sw != 1 || g.CP % 16 != 0) return 0;
   if (g.rT != g.sT || g.rH != g.sH || g.rW != g.sW) return 0;
   const int64_t grid = (int64_t)((a.M + 255) / 256) * ((a.NP + 63) / 64);
@@ -541,9 +572,9 @@ static int tap_kind(const ConvArgs& a, int mode) {
   return 0;
 }
 
-template <int KIND, int NTAPS, int NU>
+template <int KIND, int NTAPS, int NU, bool BNL = false>
 static void launch_tap(const TapArgs& t, int grid, size_t lds, hipStream_t s) {
-  hipLaunchKernelGGL((conv_tap_kernel<KIND, NTAPS, 64, 3, NU>), dim3(grid), dim3(256), lds, s, t);
+  hipLaunchKernelGGL((conv_tap_kernel<KIND, NTAPS, 64, 3, NU, BNL>), dim3(grid), dim3(256), lds, s, t);
 }
 
 }  // namespace
@@ -581,6 +612,7 @@ int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream) {
   t.bn_sums = a.bn_sums; t.bn_ws = a.bn_ws; t.bn_ldx = a.bn_ldx; t.bn_mask = a.bn_mask; t.bn_bytes = a.bn_bytes;
   t.bn_cpb = (a.N + 7) & ~7;
   if (a.bn_x == nullptr) { t.bn_ws = nullptr; t.bn_sums = nullptr; t.bn_bytes = 0; }
+  t.in_scale = a.in_scale; t.in_shift = a.in_shift; t.in_C = a.in_C; t.in_relu = a.in_relu;
   const int grid = t.ntn * ((a.M + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
   if (kind == 1) {
@@ -595,7 +627,8 @@ int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream) {
     t.npos = 256;
     t.npp = t.npos + 4;
     const size_t lds = 3 * 64 * 96 + (size_t)t.npp * 96 + 64;
-    if (g.kt == 4) launch_tap<1, 4, 2>(t, grid, lds, s);
+    if (a.in_scale != nullptr) launch_tap<1, 3, 2, true>(t, grid, lds + (size_t)g.CP * 8, s);
+    else if (g.kt == 4) launch_tap<1, 4, 2>(t, grid, lds, s);
     else launch_tap<1, 3, 2>(t, grid, lds, s);
   }
   return 1;

@@ -44,7 +44,10 @@ __device__ __forceinline__ bf16x8 wg_frag64(const unsigned char* tile, int lane,
 //   BC = 32 (the 7x1x1 / stride-2 stem conv, backbone/s3dg.py:151: XT = 8, YT = 4): x planes 128 rows x 32 channels (the same
 //            24 KB); wave (bi, parity) carries the 32 x 32 blocks of the taps of its parity -- even taps only ever read odd
 //            x frames and vice versa, so a wave touches half of the x planes.
-template <int YT, int XT, int KT, int ST, int PT, int BC>
+// BNL (dv_conv3d_wgrad_bn_in): x is the INPUT of the BatchNorm (+ReLU) in front of this conv; the x operand is
+// y = [relu](x * scale + shift) formed in front of the split with dv_bn_apply's expression (coefficients of the workgroup's BC
+// channels in LDS).  Rows past the end carry [relu](shift) instead of zero: their dY rows are zero, the products vanish.
+template <int YT, int XT, int KT, int ST, int PT, int BC, bool BNL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BC == 64 ? 3 : 2, BC == 64 ? 3 : 2))) void conv_wgrad_tm_kernel(TmWgradArgs a) {
   constexpr int PXS = 64 / YT, KS = PXS / 16, YROWS = 64, XROWS = XT * PXS;
   constexpr int RBY = 128, RBX = BC * 2;                         // plane row bytes
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BC == 64 ? 
   static_assert(BC == 64 || (BC == 32 && ST == 2), "tap-parity waves belong to the stride-2 form");
   constexpr int NACC = BC == 64 ? KT : (KT + 1) / 2;
   constexpr unsigned kOOB = 0x80000000u;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[YOP + XOP];      // dY planes, then x planes
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[YOP + XOP + (BNL ? 2 * BC * 4 : 0)];      // dY planes, then x planes
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
@@ -63,6 +66,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BC == 64 ? 
   const int tile_i = bid % a.nti;
   const int split = bid / a.nti;
   const int i0 = tile_i * 64, c0 = tile_c * BC;
+  if constexpr (BNL) {
+    float* tab = reinterpret_cast<float*>(smem + YOP + XOP);      // [scale | shift][BC]; published by the first step's barrier
+    if (tid < BC) {
+      const int c = c0 + tid;
+      tab[tid] = c < a.in_C ? a.in_scale[c] : 0.f;
+      tab[BC + tid] = c < a.in_C ? a.in_shift[c] : 0.f;
+    }
+    __syncthreads();
+  }
   const int bi = wave >> 1, wlo = wave & 1;                      // wlo: column block (BC = 64) / tap parity (BC = 32)
   const int ch_begin = split * a.chunks_per_split, ch_end = min(a.nchunks, ch_begin + a.chunks_per_split);
   const dma_rsrc_t x_rs = dma_make_rsrc(a.x, (unsigned)a.x_bytes), dy_rs = dma_make_rsrc(a.dy, (unsigned)a.dy_bytes);
@@ -164,8 +176,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BC == 64 ? 
     // stem form) leave no room for the 48 registers of that: unit by unit behind it
     constexpr bool PRESPLIT = NACC <= 3;
     Split3 sp[PRESPLIT ? 4 : 1];
+    const float bn_lo = (BNL && !a.in_relu) ? -__builtin_inff() : 0.f;
     auto split_unit = [&](int k) -> Split3 {
-      const float v[8] = {sreg[k][0].x, sreg[k][0].y, sreg[k][0].z, sreg[k][0].w, sreg[k][1].x, sreg[k][1].y, sreg[k][1].z, sreg[k][1].w};
+      float v[8] = {sreg[k][0].x, sreg[k][0].y, sreg[k][0].z, sreg[k][0].w, sreg[k][1].x, sreg[k][1].y, sreg[k][1].z, sreg[k][1].w};
+      if constexpr (BNL) {
+        if (k >= 2) {
+          const int ch8 = ((tid + 256 * k) & 511) % XU;
+          const f32x4* cs = reinterpret_cast<const f32x4*>(smem + YOP + XOP + ch8 * 32);
+          const f32x4* ch = reinterpret_cast<const f32x4*>(smem + YOP + XOP + BC * 4 + ch8 * 32);
+          const f32x4 s0 = cs[0], s1 = cs[1], h0 = ch[0], h1 = ch[1];
+          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+          const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], bn_lo);      // dv_bn_apply's expression; bn_lo = 0 | -inf
+        }
+      }
       return split3w(v);
     };
     if constexpr (PRESPLIT) {
@@ -591,6 +616,11 @@ void dvw_wgrad_tm_launch(const void* args, int grid, void* stream) {
     if (a.bn_x) hipLaunchKernelGGL((conv_wgrad_pp_kernel<true>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_pp_kernel<false>), dim3(grid), dim3(256), 0, s, a);
   } else if (a.kind == 3) hipLaunchKernelGGL((conv_wgrad_sp_kernel<0>), dim3(grid), dim3(256), 0, s, a);
+  else if (a.in_scale != nullptr) {
+    if (a.kind == 2) hipLaunchKernelGGL((conv_wgrad_tm_kernel<4, 8, 7, 2, 3, 32, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.T == 4) hipLaunchKernelGGL((conv_wgrad_tm_kernel<4, 4, 3, 1, 1, 64, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_tm_kernel<2, 2, 3, 1, 1, 64, true>), dim3(grid), dim3(256), 0, s, a);
+  }
   else if (a.kind == 2) hipLaunchKernelGGL((conv_wgrad_tm_kernel<4, 8, 7, 2, 3, 32>), dim3(grid), dim3(256), 0, s, a);
   else if (a.T == 4) hipLaunchKernelGGL((conv_wgrad_tm_kernel<4, 4, 3, 1, 1, 64>), dim3(grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv_wgrad_tm_kernel<2, 2, 3, 1, 1, 64>), dim3(grid), dim3(256), 0, s, a);

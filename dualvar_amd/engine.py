@@ -48,17 +48,22 @@ FUSE_BN_REDUCE = False        # (module switch, no environment variable: tests/t
 # The same fusion in its ORDERED form on the LDS-staged input-tile kernel (dv_conv3d_dgrad_bn_ws: the sums come from the
 # accumulators and one read of the BatchNorm's input, tile rows are folded in tile order -- no float atomics): taken wherever the
 # consuming conv's data gradient runs on that kernel (fp32 mode: the separable pairs and the strided stem conv of S3D-G / R(2+1)D).
-FUSE_BN_REDUCE_TAP = True      # (module switch; tests monkeypatch it for the A/B of the two plans)
+FUSE_BN_REDUCE_TAP = os.environ.get('DUALVAR_FUSE_BN_REDUCE_TAP', '1') != '0'      # (A/B switch; tests monkeypatch the module attribute)
 # ... only behind a long K loop (>= 512 = taps x channel pitch of dY) and never for the strided stem conv: the epilogue's read of
 # the BatchNorm input is exposed at the end of a workgroup's life, and for a short loop it costs more than the standalone reduce
 # saves -- all eight candidates of the S3D-G step fused: data gradients +740 us, reduce launches -565 us (the stem conv alone 422 ->
 # 854 us for a 312 us reduce); with this rule the step is 0.03 - 0.05 ms faster, i.e. the fusion VERDICT round 3 priced at -0.26 ms
 # is worth a tenth of that.
-FUSE_BN_REDUCE_TAP_MIN_K = 512
+FUSE_BN_REDUCE_TAP_MIN_K = int(os.environ.get('DUALVAR_FUSE_BN_REDUCE_TAP_MIN_K', '512'))
 # BatchNorm-backward APPLY inside the weight gradient of a conv whose input needs no gradient (the first conv of a network:
 # dL/d(conv output) has that weight gradient as its only reader): dv_conv3d_wgrad_bn forms it on the fly from dL/dy and the
 # conv output -- one read of each instead of read + read + write (apply) + read (wgrad).  fp32 split mode only.
 FUSE_BN_WGRAD = os.environ.get('DUALVAR_FUSE_BN_WGRAD', '1') != '0'      # (A/B switch; tests monkeypatch the module attribute)
+# BatchNorm ON LOAD (include/dualvar_hip.h: dv_conv3d_fwd_bn_in / dv_conv3d_wgrad_bn_in): conv -> BN -> ReLU -> conv chains whose
+# second conv is the only reader of the BatchNorm's output (the 1xkxk -> kx1x1 pairs of backbone/s3dg.py:30-65 and the stem): the
+# output is never written; the second conv's forward and weight gradient read the BatchNorm's INPUT and apply the affine map +
+# ReLU while they stage it.  Priced before it was built (apply launches skipped, stale data in the buffers): 17.09 -> 16.59 ms.
+FUSE_BN_IN = os.environ.get('DUALVAR_FUSE_BN_IN', '1') != '0'         # (A/B switch; tests monkeypatch the module attribute)
 
 
 class Slot:
@@ -639,6 +644,28 @@ class Plan:
                             or a.rows != y.rows or cop.bn_fuse is not None):
                         continue
                     cop.bn_fuse, m.reduce_fused = m, True
+        if self.training and FUSE_BN_IN and self.dtype == DV_F32:
+            for op in self.ops:
+                if not isinstance(op, BNGroupOp):
+                    continue
+                for m in op.members:
+                    if (m.res is not None or m.fused_pool is not None or m.conv_bias is not None
+                            or (self.with_grad and m.relu and not m.mask_from_x)):
+                        continue
+                    y = m.y
+                    readers = [o for o in self.ops if o is not op and any(
+                        r is not None and r.buf is y.buf for r in [getattr(o, 'x', None), getattr(o, 'cat', None)] +
+                        [t for mm in getattr(o, 'members', ()) for t in (mm.x, mm.res)])]
+                    if len(readers) != 1 or not isinstance(readers[0], ConvOp):
+                        continue
+                    cop = readers[0]
+                    if (cop.fp8 or cop.bn_in is not None or cop.x.buf is not y.buf or cop.x.off != y.off or cop.x.C != y.C
+                            or m.x.cpitch != cop.slot.cin_pitch or m.x.rows != y.rows or m.x.C != y.C):
+                        continue
+                    d = ops.conv_desc(cop.dtype, m.x, cop.y, cop.k, cop.s, cop.p, flags=cop.d.flags)
+                    if not int(self.lib.dv_conv3d_bn_in_ok(C.byref(d))) or ops.tile_rows(d) != cop.tile_rows:
+                        continue
+                    cop.bn_in, m.fused_conv = m, cop
         self.bn_fuse_ws = None
         if self.with_grad and self.training and FUSE_BN_REDUCE_TAP and self.dtype == DV_F32 and not FUSE_BN_REDUCE:
             writers, need_ws = {}, 0
@@ -866,6 +893,7 @@ class ConvOp(Op):
         self.bn_fuse = None          # BNMember whose backward reduce this conv's data gradient carries (Plan.finalize)
         self.bn_fuse_tap = False     # ... in the ordered form of the LDS-staged kernel (dv_conv3d_dgrad_bn_ws)
         self.bn_apply = None         # BNMember (of this conv's output) whose backward apply this conv's weight gradient carries
+        self.bn_in = None            # BNMember (of this conv's INPUT) applied on load: x is never materialised (FUSE_BN_IN)
 
     def grad_targets(self):
         return [('x', self.x)] if self.need_dx else []
@@ -887,6 +915,14 @@ class ConvOp(Op):
         f = [Launch('conv_fwd', kf, lib.dv_conv3d_fwd,
                     (C.byref(self.d), x.ptr, self._wf, 0, y.ptr, self.stats.data_ptr() if self.stats is not None else 0),
                     _abytes(x) + wbytes + _abytes(y), flops, shp)]
+        if self.bn_in is not None:
+            m = self.bn_in
+            r = self._bn_in = L.BnIn()
+            r.scale, r.shift, r.flags = m.scale.data_ptr(), m.shift.data_ptr(), (DV_RELU if m.relu else 0)
+            self.d_in = ops.conv_desc(self.dtype, m.x, y, self.k, self.s, self.p, flags=self.d.flags)
+            f = [Launch('conv_fwd', _conv_kname(lib, self.d_in, 0, _dt(self.dtype), gv) + '+bn_in', lib.dv_conv3d_fwd_bn_in,
+                        (C.byref(self.d_in), m.x.ptr, C.byref(r), self._wf, y.ptr, self.stats.data_ptr() if self.stats is not None else 0),
+                        _abytes(x) + wbytes + _abytes(y), flops, shp + ' +bn_in')]
         if self.fp8:
             f = self._fp8_forward(shp, flops, wbytes)
         b = []
@@ -910,6 +946,14 @@ class ConvOp(Op):
                                  ws.numel() if ws is not None else 0, C.byref(r)),
                                 _abytes(x) + 2 * _abytes(y) + sl.Cout * kdim * 4, flops, shp + ' +bn_bwd_apply'))
                 b[-1].gend = max(sl.off + sl.size, _gend(gs, bs))
+            elif self.bn_in is not None:
+                m = self.bn_in
+                self.d_w_in = ops.conv_desc(self.dtype, m.x, y, self.k, self.s, self.p, flags=0)
+                b.append(Launch('conv_wgrad', 'conv_wgrad<%s,%d,%s>+bn_in' % (_dt(self.dtype), gv, tile), lib.dv_conv3d_wgrad_bn_in,
+                                (C.byref(self.d_w_in), m.x.ptr, C.byref(self._bn_in), y.grad.ptr, st.w_grad(sl),
+                                 ws.data_ptr() if ws is not None else 0, ws.numel() if ws is not None else 0),
+                                _abytes(x) + _abytes(y) + sl.Cout * kdim * 4, flops, shp + ' +bn_in'))
+                b[-1].gend = sl.off + sl.size
             else:
                 b.append(Launch('conv_wgrad', 'conv_wgrad<%s,%d,%s>' % (_dt(self.dtype), gv, tile), lib.dv_conv3d_wgrad,
                                 (C.byref(self.d_w), x.ptr, y.grad.ptr, st.w_grad(sl), ws.data_ptr() if ws is not None else 0,
@@ -1019,6 +1063,7 @@ class BNMember:
         # xhat anyway) with the forward's expression and never touches y -- 5 tensor passes per BatchNorm instead of 7
         self.conv_bias = None        # Plan.bn(conv_bias=...)
         self.fused_pool = None       # the PoolOp that consumes y on the fly (Plan.maxpool(sole_consumer=True))
+        self.fused_conv = None       # the ConvOp that applies this BatchNorm while it stages x (Plan.finalize, FUSE_BN_IN)
         self.reduce_fused = False    # the backward reduce runs in the epilogue of the consuming conv's data gradient
         self.apply_fused = False     # the backward apply runs inside the producing conv's weight gradient (dv_conv3d_wgrad_bn)
         self.mask_from_x = bool(relu) and residual is None
@@ -1074,7 +1119,7 @@ class BNGroupOp(Op):
             it.fwd_flags = DV_RELU if m.relu else 0
             total = m.M * (m.CP // V)
             ends[0] += m.C
-            ends[1] += max(1, min(4096, (total + 255) // 256))
+            ends[1] += 0 if m.fused_conv is not None else max(1, min(4096, (total + 255) // 256))
             it.blk_stats, it.blk_apply = ends[0], ends[1]
             if p.with_grad:
                 dres = res.grad if (res is not None and res.grad is not None) else None
@@ -1100,7 +1145,7 @@ class BNGroupOp(Op):
         f_red = [Launch('bn_stats_multi', 'bn_stats_multi', lib.dv_bn_stats_multi, (tab, n, 0 if p.comm.exchange else 1, ends[0]),
                         tot(f_red, 'bytes'))]
         f_app = [Launch('bn_apply_multi', 'bn_apply_multi<%s>' % dt, lib.dv_bn_apply_multi, (p.dtype, tab, n, ends[1]),
-                        tot(f_app, 'bytes'))]
+                        tot(f_app, 'bytes'))] if ends[1] else []
         # multi-rank step: ONE finalize launch for the group after the all-gather (instead of one per member)
         self._fin_multi = Launch('bn_finalize_multi', 'bn_finalize_multi', lib.dv_bn_finalize_multi,
                                  (tab, n, sum((m.C + 127) // 128 for m in self.members), self.local.data_ptr(),
@@ -1166,10 +1211,11 @@ class BNGroupOp(Op):
                 f_fin.append(Launch('bn_finalize', 'bn_finalize', lib.dv_bn_finalize,
                                     (self.gathered.data_ptr() + 4 * m.loff, R, self.width, Cn, st.w_master(gs), st.w_master(bs),
                                      eps, mom, rm, rv) + outs))
-            f_app.append(Launch('bn_apply', 'bn_apply<%s>' % dt, lib.dv_bn_apply,
-                                (p.dtype, x.ptr, x.ld, m.scale.data_ptr(), m.shift.data_ptr(),
-                                 res.ptr if res is not None else 0, res.ld if res is not None else 0, y.ptr, y.ld, M, Cn,
-                                 DV_RELU if m.relu else 0), _abytes(x) * (3 if res is not None else 2), 0, 'M%d C%d' % (M, Cn)))
+            if m.fused_conv is None:         # (else: the consuming conv applies it on load; y is never written)
+                f_app.append(Launch('bn_apply', 'bn_apply<%s>' % dt, lib.dv_bn_apply,
+                                    (p.dtype, x.ptr, x.ld, m.scale.data_ptr(), m.shift.data_ptr(),
+                                     res.ptr if res is not None else 0, res.ld if res is not None else 0, y.ptr, y.ld, M, Cn,
+                                     DV_RELU if m.relu else 0), _abytes(x) * (3 if res is not None else 2), 0, 'M%d C%d' % (M, Cn)))
             if p.with_grad:
                 dy = y.grad
                 mflag = 0 if m.relu else DV_NO_RELU_MASK

@@ -122,6 +122,28 @@ def conv_wgrad(d, x, dy, dw, workspace=None):
     L.check(lib.dv_conv3d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(workspace), nbytes, stream_ptr()), 'dv_conv3d_wgrad')
 
 
+def bn_in_desc(scale, shift, relu=True):
+    """dv_bn_in: the BatchNorm (+ReLU) a conv applies to its input on load (dv_conv3d_fwd_bn_in / dv_conv3d_wgrad_bn_in)"""
+    r = L.BnIn()
+    r.scale, r.shift, r.flags = _p(scale), _p(shift), (L.DV_RELU if relu else 0)
+    return r
+
+
+def conv_fwd_bn_in(d, x_bn, bn, w, y, stats):
+    lib = L.load()
+    L.check(lib.dv_conv3d_fwd_bn_in(C.byref(d), _p(x_bn), C.byref(bn), _p(w), _p(y), _p(stats), stream_ptr()), 'dv_conv3d_fwd_bn_in')
+
+
+def conv_wgrad_bn_in(d, x_bn, bn, dy, dw, workspace=None):
+    lib = L.load()
+    need = wgrad_workspace_bytes(d)
+    if workspace is None and need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dw.device)
+    nbytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    L.check(lib.dv_conv3d_wgrad_bn_in(C.byref(d), _p(x_bn), C.byref(bn), _p(dy), _p(dw), _p(workspace), nbytes, stream_ptr()),
+            'dv_conv3d_wgrad_bn_in')
+
+
 def quantize_fp8(x, M, C, ld, fmt, dtype, q=None, scale=None, workspace=None):
     """per-tensor fp8 quantisation of the [M, C] view at `x` (pitch ld elements): -> (q uint8 [M, C], scale float32[1])"""
     lib = L.load()

@@ -174,6 +174,29 @@ int dv_conv3d_wgrad_bn_ok(const dv_conv_desc* d);
 int dv_conv3d_wgrad_bn(const dv_conv_desc* d, const void* x, const void* g, float* dw, void* workspace,
                        int64_t workspace_bytes, const dv_bn_bwd* bn, void* stream);
 
+/* BatchNorm ON LOAD: conv -> BatchNorm (+ReLU) -> conv chains (backbone/s3dg.py:30-65 STConv3d: conv1 -> bn1 -> relu -> conv2;
+ * backbone/r21d.py:54-70) in which the second conv is the ONLY reader of y = [relu](x_bn * scale + shift).  Then y need not
+ * exist in memory: the second conv's forward and its weight gradient read x_bn (the BatchNorm's input, i.e. the first conv's
+ * raw output) and apply the affine map where their operand fragments are formed, with dv_bn_apply's expression
+ * (x * scale + shift, then max(., 0) with DV_RELU in `flags`): same bits as the two-launch plan, one write and one read of the
+ * activation less per pair.  The padding of the conv is a padding of y (zeros), not of x_bn.  scale / shift are the
+ * [cp8(Cin)] arrays dv_bn_stats_finalize / dv_bn_finalize wrote.  The data gradient is unchanged (it never reads y); the
+ * BatchNorm backward takes its ReLU mask from x_bn (DV_MASK_FROM_X).
+ * dv_conv3d_bn_in_ok: 0 = this problem cannot run that way (then call dv_bn_apply and the plain entry points); 1 / 2 = both
+ * dv_conv3d_fwd_bn_in and dv_conv3d_wgrad_bn_in take it (1: the LDS-staged temporal kernels, stride-1 3x1x1; 2: conv_gemm's
+ * 256 x 64 tile, e.g. the 7x1x1 / stride-2 stem conv of backbone/s3dg.py:151).  DV_F32 with DV_W3, no bias / activation flags;
+ * DV_STATS as in dv_conv3d_fwd.  Both return DV_EUNSUPPORTED where dv_conv3d_bn_in_ok says 0. */
+typedef struct dv_bn_in {
+  const float* scale;
+  const float* shift;
+  int32_t flags, _pad;           /* DV_RELU */
+} dv_bn_in;
+int dv_conv3d_bn_in_ok(const dv_conv_desc* d);
+int dv_conv3d_fwd_bn_in(const dv_conv_desc* d, const void* x_bn, const dv_bn_in* bn, const void* w_fwd, void* y, float* stats,
+                        void* stream);
+int dv_conv3d_wgrad_bn_in(const dv_conv_desc* d, const void* x_bn, const dv_bn_in* bn, const void* dy, float* dw,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- fp8 pointwise path (BASELINE configs[4]: "fp8 MFMA pointwise convs" of the 2D3D-ResNet-50 bottlenecks,
  * resnet_2d3d.py:130,167,173).  A 1x1x1 stride-1 conv is the GEMM Y[M, Cout] = X[M, Cin] W[Cout, Cin]^T; with OCP fp8
  * operands it runs on v_mfma_f32_32x32x64_f8f6f4 (fp32 accumulate, twice the bf16 rate per clock).  Operands are quantised

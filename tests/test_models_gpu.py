@@ -803,3 +803,38 @@ def test_training_steps_are_bitwise_reproducible(gpu, kind, net, dtype):
     for name, x, y in zip(('losses', 'gradients', 'parameters'), a, b):
         same = torch.equal(x, y)
         assert same, (name, float((x.float() - y.float()).abs().max()), int((x != y).sum()), x.numel())
+
+
+@pytest.mark.parametrize('net,clips,size', [('s3dg', 64, 112), ('r21d', 8, 112)])
+def test_batchnorm_on_load_plan_gives_the_same_bits(gpu, monkeypatch, net, clips, size):
+    """engine.FUSE_BN_IN (default on): in conv -> BatchNorm -> ReLU -> conv chains whose second conv is the only reader (the
+    1xkxk -> kx1x1 pairs of backbone/s3dg.py:30-65, the stem pair s3dg.py:151), the BatchNorm's output is never written: the
+    second conv's forward and weight gradient apply the affine map + ReLU to the BatchNorm's INPUT while they stage it
+    (dv_conv3d_fwd_bn_in / dv_conv3d_wgrad_bn_in), with dv_bn_apply's expression.  Same kernels, same products: the loss and
+    every gradient must agree with the unfused plan BIT FOR BIT, at the headline step."""
+    from dualvar_amd import engine, model as M
+    from dualvar_amd import _lib
+    if _lib.f32_exact():
+        pytest.skip('the BatchNorm-on-load kernels belong to the split mode')
+    block = torch.randn(clips, 2, 3, 8, size, size, generator=torch.Generator().manual_seed(3)).to(gpu)
+    grads, losses, fused = [], [], []
+    for on in (False, True):
+        monkeypatch.setattr(engine, 'FUSE_BN_IN', on)
+        torch.manual_seed(0)
+        m = M.SimCLR_Naked(net, 128, 0.07, False)
+        m.set_compute_dtype('fp32').train().to(gpu)
+        ret = m(block)
+        for st in m.stores():
+            st.zero_grad()
+        ret['clip_contrast_loss'].backward()
+        torch.cuda.synchronize()
+        losses.append(float(ret['clip_contrast_loss']))
+        grads.append(torch.cat([st.grad.detach().float().flatten().clone() for st in m.stores()]))
+        plans = [pl for lst in m.encoder_q[0]._plans.values() for pl in lst]
+        fused.append(sum(1 for pl in plans for op in pl.ops if getattr(op, 'bn_in', None) is not None))
+        del m, ret
+    print(net, 'convs applying the BatchNorm in front of them on load:', fused, 'loss', losses)
+    assert fused[0] == 0 and fused[1] >= (8 if net == 's3dg' else 1), fused
+    assert losses[0] == losses[1], losses
+    assert bool(torch.isfinite(grads[1]).all())
+    assert torch.equal(grads[0], grads[1]), float((grads[0] - grads[1]).abs().max())

@@ -1458,3 +1458,69 @@ def test_second_fp32_weight_gradient_form_stays_correct(gpu, cfg):
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0 and ' passed' in tail, tail
+
+
+BN_IN_CASES = [
+    # name, N, Cin, cin pitch, T, H, W, Cout, k, s, p, relu, expected dv_conv3d_bn_in_ok
+    ('c2c_tm3_t4', 20, 64, 64, 4, 56, 56, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), True, 1),
+    ('stem_tm7_s2', 16, 64, 64, 8, 56, 56, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0), True, 2),
+    ('stem_tm7_s2_ragged', 11, 64, 64, 8, 56, 55, 64, (7, 1, 1), (2, 1, 1), (3, 0, 0), True, 2),        # 529.4 tiles of 256 rows
+    ('odd_tm3_t2', 12, 83, 96, 2, 28, 28, 144, (3, 1, 1), (1, 1, 1), (1, 0, 0), True, 1),
+    ('tm3_t2_linear', 12, 48, 48, 2, 28, 28, 136, (3, 1, 1), (1, 1, 1), (1, 0, 0), False, 1),
+    ('r21d_tm3_t8', 8, 144, 144, 8, 56, 56, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), True, 0),        # 8 frames: no staged weight gradient
+    ('sp3', 8, 64, 64, 4, 56, 56, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), True, 0),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', BN_IN_CASES, ids=[c[0] for c in BN_IN_CASES])
+def test_batchnorm_on_load_gives_the_bits_of_apply_then_conv(gpu, case):
+    """dv_conv3d_fwd_bn_in / dv_conv3d_wgrad_bn_in (conv -> BN -> ReLU -> conv with the BatchNorm's output never written:
+    backbone/s3dg.py:30-65 STConv3d, and the stem pair s3dg.py:151) against the two-launch plan dv_bn_apply -> dv_conv3d_fwd /
+    dv_conv3d_wgrad on the same inputs: the same expression feeds the same kernels' products, so y, the BatchNorm partials and dW
+    must agree BIT FOR BIT; where dv_conv3d_bn_in_ok says 0 both entry points refuse."""
+    import ctypes as C
+    from dualvar_amd import _lib as L
+    from dualvar_amd._lib import DV_W3, DV_RELU
+    if _EXACT:
+        pytest.skip('the pre-split-weight instantiations do not exist under DUALVAR_F32_EXACT=1')
+    name, N, Cin, cpitch, T, H, W, Cout, k, s, p, relu, want = case
+    lib = L.load()
+    xr = ops.act_from_ncdhw(rnd(N, Cin, T, H, W, seed=11).to(gpu), DV_F32, cpitch=cpitch)
+    CP = ops.cp8(Cin)
+    scale, shift = torch.zeros(CP, device=gpu), torch.zeros(CP, device=gpu)
+    scale[:Cin] = (rnd(Cin, seed=12) * 0.5 + 1.0).to(gpu)
+    shift[:Cin] = (rnd(Cin, seed=13) * 0.3).to(gpu)
+    ya = ops.new_act(N, T, H, W, Cin, DV_F32, gpu, cpitch=cpitch, zero=True)
+    M_in = N * T * H * W
+    ops.call('dv_bn_apply', DV_F32, xr, xr.ld, scale, shift, None, 0, ya, ya.ld, M_in, Cin, DV_RELU if relu else 0)
+    To, Ho, Wo = ops.conv_out_dims(xr, k, s, p)
+    w = rnd(Cout, Cin, *k, seed=14, scale=(Cin * k[0]) ** -0.5)
+    wp = ops.pack_weight(w.to(gpu), cpitch)
+    w3 = ops.pack_w3(wp.view(Cout, -1))
+    out1 = ops.new_act(N, To, Ho, Wo, Cout, DV_F32, gpu, zero=True)
+    out2 = ops.new_act(N, To, Ho, Wo, Cout, DV_F32, gpu, zero=True)
+    d = ops.conv_desc(DV_F32, ya, out1, k, s, p, flags=ops.DV_STATS | DV_W3)
+    assert int(lib.dv_conv3d_bn_in_ok(C.byref(d))) == want, name
+    tiles = ops.stat_tiles(d)
+    st1, st2 = torch.zeros(2, Cout, tiles, device=gpu), torch.zeros(2, Cout, tiles, device=gpu)
+    bn = ops.bn_in_desc(scale, shift, relu)
+    dya = ops.act_from_ncdhw(rnd(N, Cout, To, Ho, Wo, seed=15).to(gpu), DV_F32)
+    d2 = ops.conv_desc(DV_F32, ya, dya, k, s, p)
+    if not want:
+        if name != 'r21d_tm3_t8':        # (that one's forward alone could: the pair is refused because its weight gradient cannot)
+            with pytest.raises(L.DualVarHipError, match='DV_EUNSUPPORTED'):
+                ops.conv_fwd_bn_in(d, xr, bn, w3, out2, st2)
+        with pytest.raises(L.DualVarHipError, match='DV_EUNSUPPORTED'):
+            ops.conv_wgrad_bn_in(d2, xr, bn, dya, torch.zeros_like(wp))
+        return
+    ops.conv_fwd(d, ya, w3, None, out1, st1)
+    ops.conv_fwd_bn_in(d, xr, bn, w3, out2, st2)
+    assert torch.equal(out1.buf, out2.buf), (name, float((out1.buf - out2.buf).abs().max()))
+    assert torch.equal(st1, st2), name
+    assert float(out1.buf.abs().max()) > 0.1
+    dw1, dw2 = torch.zeros_like(wp), torch.zeros_like(wp)
+    ops.conv_wgrad(d2, ya, dya, dw1)
+    ops.conv_wgrad_bn_in(d2, xr, bn, dya, dw2)
+    assert torch.equal(dw1, dw2), (name, float((dw1 - dw2).abs().max()))
+    assert float(dw1.abs().max()) > 0.1

@@ -59,6 +59,7 @@ def main():
     ap.add_argument('--no-stats', action='store_true', help='forward without the fused BatchNorm partials')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--w3', action='store_true', help='fp32: weights pre-split in fragment order (DV_W3), as the engine runs them')
+    ap.add_argument('--bn-in', action='store_true', help='fwd / wgrad through dv_conv3d_*_bn_in on the RAW values (scale 1, shift 0, ReLU): the same operands as --data relu')
     ap.add_argument('--data', default='relu', choices=['relu', 'normal', 'zeros'], help='activation values (power, hence clocks, depend on them)')
     args = ap.parse_args()
     L.require_device()
@@ -107,6 +108,12 @@ def main():
             jobs['fwd'] = (fwd3, bx + by)
             if max(s) == 1:
                 jobs['dgrad'] = (dg3, bx + by)
+        if args.bn_in:
+            x.buf.normal_()
+            sc, sh = torch.ones(x.cpitch, device=dev), torch.zeros(x.cpitch, device=dev)
+            bn = ops.bn_in_desc(sc, sh, True)
+            jobs['fwd'] = (lambda: ops.conv_fwd_bn_in(d3, x, bn, w3, y, stats), bx + by)
+            jobs['wgrad'] = (lambda: ops.conv_wgrad_bn_in(dd, x, bn, dy, dw, workspace=ws), bx + by)
         for ps in args.passes.split(','):
             fn, nbytes = jobs[ps]
             us = timed(fn, args.reps)

@@ -55,7 +55,7 @@ def short(name):
     if m:
         return 'conv_tap<f32,%s,256,64>' % ('sp' if m.group(1) == '0' else 'tm')          # (fwd and dgrad are one kernel)
     m = re.search(r'conv_wgrad_tm_kernelILi\d+ELi\d+ELi(\d+)ELi\d+ELi\d+ELi(\d+)E', n) or \
-        re.search(r'conv_wgrad_tm_kernel<\d+, \d+, (\d+), \d+, \d+, (\d+)>', n)
+        re.search(r'conv_wgrad_tm_kernel<\d+, \d+, (\d+), \d+, \d+, (\d+)(?:, (?:true|false))?>', n)      # (BatchNorm-on-load instantiations: same family)
     if m:
         return 'conv_wgrad<f32,16,64,%d>' % (int(m.group(1)) * int(m.group(2)))
     if re.search(r'conv_wgrad_sp_kernel', n):

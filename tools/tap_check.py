@@ -79,6 +79,44 @@ def check_fused_bn_reduce(lib, dev, dd_plain, dya, wd3, like, Ci, tag):
     return worst
 
 
+def check_bn_in(lib, dev, xa, dya, w, k, s, p, tag):
+    """dv_conv3d_fwd_bn_in / dv_conv3d_wgrad_bn_in on the raw values of xa against dv_bn_apply + the plain entry points (which this
+    script checks against float64): y, the BatchNorm partials and dW bit for bit, with and without the ReLU, scale / shift arrays
+    only cp8(C) long, the channel pitch beyond them poisoned in x"""
+    DT = L.DV_F32
+    Ci, Co = xa.C, dya.C
+    g = torch.Generator().manual_seed(7)
+    CPi = ops.cp8(Ci)
+    scale, shift = torch.zeros(CPi, device=dev), torch.zeros(CPi, device=dev)
+    scale[:Ci] = (1 + 0.3 * torch.randn(Ci, generator=g)).to(dev)
+    shift[:Ci] = (0.2 * torch.randn(Ci, generator=g)).to(dev)
+    wp = ops.pack_weight(w.to(dev), xa.cpitch)
+    w3 = ops.pack_w3(wp.view(Co, -1))
+    d = ops.conv_desc(DT, xa, dya, k, s, p, flags=L.DV_STATS | L.DV_W3)
+    dw_ = ops.conv_desc(DT, xa, dya, k, s, p)
+    ok = int(lib.dv_conv3d_bn_in_ok(C.byref(d)))
+    if not ok:
+        return 0
+    tiles = ops.stat_tiles(d)
+    for relu in (True, False):
+        act = ops.new_act(xa.N, xa.T, xa.H, xa.W, Ci, DT, dev, cpitch=xa.cpitch, zero=True)
+        ops.call('dv_bn_apply', DT, xa, xa.ld, scale, shift, None, 0, act, act.ld, xa.rows, Ci, L.DV_RELU if relu else 0)
+        y1, y2 = dya.like(), dya.like()
+        y1.buf.zero_(); y2.buf.zero_()
+        st1, st2 = torch.zeros(2, Co, tiles, device=dev), torch.zeros(2, Co, tiles, device=dev)
+        bn = ops.bn_in_desc(scale, shift, relu)
+        ops.conv_fwd(d, act, w3, None, y1, st1)
+        ops.conv_fwd_bn_in(d, xa, bn, w3, y2, st2)
+        dw1, dw2 = torch.zeros_like(wp), torch.zeros_like(wp)
+        ops.conv_wgrad(dw_, act, dya, dw1)
+        ops.conv_wgrad_bn_in(dw_, xa, bn, dya, dw2)
+        torch.cuda.synchronize()
+        assert torch.equal(y1.buf, y2.buf) and torch.equal(st1, st2), (tag, relu, float((y1.buf - y2.buf).abs().max()))
+        assert torch.equal(dw1, dw2), (tag, relu, float((dw1 - dw2).abs().max()))
+        assert float(y1.buf.abs().max()) > 0 and float(dw1.abs().max()) > 0 and bool(torch.isfinite(y2.buf).all())
+    return ok
+
+
 def main():
     L.require_device()
     dev = torch.device('cuda:0')
@@ -159,6 +197,12 @@ def main():
             print('   weight gradient (LDS-staged, %d row splits): %.2e' % (ss.value, e_w), flush=True)
             assert e_w == e_w and e_w < 3e-6, e_w
             worst = max(worst, e_w)
+        if k == (3, 1, 1):
+            xp = ops.Act(xa.buf.clone(), N, T, H, W, Ci, xa.cpitch, 0, DT, xa.cpitch)
+            xp.buf[:, Ci:] = 777.0                                 # pad lanes of the BatchNorm's input: must not reach the products
+            okb = check_bn_in(lib, dev, xp, dya, w, k, (1, 1, 1), p, 'N%d Cin%d T%d' % (N, Ci, T))
+            assert okb == (1 if T in (2, 4) else 0), (T, okb)
+            print('   BatchNorm on load (fwd + weight gradient, bit for bit against apply-then-conv): %s' % ('ok' if okb else 'n/a (T = %d)' % T), flush=True)
         print('N%d Cin%d T%d %dx%d Cout%d k%s: kind fwd %d dgrad %d | fwd %.2e mean %.2e var %.2e dgrad(+=) %.2e pad %s | fused bn sums %.2e' % (
             N, Ci, T, H, W, Co, 'x'.join(map(str, k)), kind, kind_d, e_f, e_m, e_v, e_d, pad_ok, e_bn), flush=True)
         assert e_bn < 2e-6, e_bn
