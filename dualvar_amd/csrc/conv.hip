@@ -19,6 +19,8 @@
 int dvt_conv_tap_kind(const void* conv_args, int mode);
 int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream);
 int64_t dvt_bn_ws_floats(int64_t rows, int np);
+int dvt_conv_pp_rows(const void* conv_args, int mode);
+int dvt_conv_pp_launch(const void* conv_args, int mode, void* stream);
 
 namespace {
 
@@ -1762,9 +1764,20 @@ static void query_args(const dv_conv_desc* d, int dgrad, ConvArgs& a) {
   a.out_bytes = (d->dtype == DV_F32 && ob < (1ll << 31)) ? (int)ob : 0;
 }
 
-// 0: conv_gemm / conv_gemm_ks; 1 / 2: the LDS-staged input-tile kernel (conv_tap.hip), spatial / temporal form
+// rows per tile when dv_conv3d_fwd runs this problem on the pixel-pair stem form (conv_tap.hip: conv_pp_fwd_kernel), else 0
+static int pp_rows_choice(const dv_conv_desc* d) {
+  if (d->dtype != DV_F32 || f32_exact() || !(d->flags & DV_W3)) return 0;
+  ConvArgs a;
+  query_args(d, 0, a);
+  a.lds_ = d->ldx;
+  return dvt_conv_pp_rows(&a, MODE_FWD);
+}
+
+// 0: conv_gemm / conv_gemm_ks; 1 / 2: the LDS-staged input-tile kernel (conv_tap.hip), spatial / temporal form; 3: its pixel-pair
+// stem form (forward only)
 static int tap_choice(const dv_conv_desc* d, int dgrad) {
   if (d->dtype != DV_F32 || f32_exact() || !(d->flags & DV_W3)) return 0;
+  if (!dgrad && pp_rows_choice(d)) return 3;
   ConvArgs a;
   query_args(d, dgrad, a);
   if (d->st > 1 || d->sh > 1 || d->sw > 1) {
@@ -1788,7 +1801,10 @@ extern "C" int dv_conv3d_tap_kind(const dv_conv_desc* d, int32_t dgrad) {
 
 extern "C" int dv_conv3d_tile_rows(const dv_conv_desc* d) {
   if (!d) return DV_EINVAL;
-  if (!check_desc(d) && tap_choice(d, 0)) return 256;
+  if (!check_desc(d)) {
+    if (const int r = pp_rows_choice(d)) return r;
+    if (tap_choice(d, 0)) return 256;
+  }
   const int64_t m = (int64_t)d->N * d->To * d->Ho * d->Wo;
   int bm, bn;
   pick_tile(d->dtype, (int)m, d->cout_pitch, bm, bn);
@@ -1899,6 +1915,7 @@ static int fwd_impl(const dv_conv_desc* d, const void* x, const void* w, const f
   const int esz = d->dtype == DV_F32 ? 4 : 2;
   if ((d->ldx * esz) % gvb || (a.ldw * esz) % gvb) return DV_EALIGN;
   if (bn_path != 2) trim_dead_taps(a, MODE_FWD, d->dtype);
+  if (d->dtype == DV_F32 && w3 && !bn_path && dvt_conv_pp_launch(&a, MODE_FWD, stream)) return dv_launch_status();
   if (d->dtype == DV_F32 && w3 && bn_path != 2 && dvt_conv_tap_launch(&a, MODE_FWD, stream)) return dv_launch_status();
   if (bn_path == 1) return DV_EUNSUPPORTED;          // (cannot happen: fwd_bn_in_path asked the same question)
   int bm, bn;

@@ -532,6 +532,224 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Pixel-pair stem form (forward): the network's first conv (backbone/s3dg.py:151 Conv_1a.conv1, 1x7x7 / stride 2 on RGB -- here a
+// 1 x 7 x 4 window over 8-channel pixel pairs of the zero-bordered frames, stride (1, 2, 1), no padding).
+// With 8 channels a 16-wide K tile straddles two taps, so conv_gemm ran it on the generic gather (per-lane tap decode, one DMA
+// round and one split per K tile: 105 TFLOP/s).  Here a workgroup owns G consecutive OUTPUT LINES of one frame (G * Wo <= 256
+// rows, 224 = 7 row blocks for 56-pixel lines) x 64 output channels and stages the 2 G + 5 input lines its windows reach ONCE
+// -- global -> registers -> bf16 triples -> planes [line][pair][hi|mid|lo][8], 48 B per pair --: the whole K range (14 K tiles =
+// 7 kernel rows x two pair-tap pairs) is then resident, a K tile's A fragment is three ds_read_b128 at
+// (line 2 j + dh, pair wo + 2 (kk & 1) + h) -- consecutive lanes are consecutive pairs: conflict-free, no masks (the border is
+// part of the ingest layout) --, and the K loop only streams the pre-split weights (LDS DMA, two stages) between barriers.
+// Output rows of a tile are contiguous in the tensor; epilogue and BatchNorm partials as conv_tap_kernel (per G * Wo rows).
+struct PpArgs {
+  const void* src;        // [N * T * Hp lines][Wp pairs][8] fp32
+  const void* w;          // pre-split weights (dv_pack_w3), K = ((dh * 4 + pair tap) * 8 + channel)
+  void* out;              // [M][ldo] fp32
+  float* stats;           // DV_STATS: [2][N][M / rows]
+  int M, N, NP, ldo, ldw, ntn, flags;
+  int src_bytes, w_bytes, out_bytes;
+  int Wo, Wp, Hp, G, rows, npos;       // output pixels per line, pairs per input line, input lines per frame, lines per tile, G * Wo, (2 G + 5) * Wp
+  FastDiv fWo, fWp, fHg;               // row -> (line, pixel); position -> (line, pair); tile -> (frame, line group)
+  int Hg;                              // line groups per frame (Ho / G)
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_pp_fwd_kernel(PpArgs a) {
+  constexpr int BN = 64, NW = 4, TM = 2, TN = 2, NK = 14;
+  constexpr int B_BYTES = BN * 96, BPC = B_BYTES / 1024, NPW = (BPC + NW - 1) / NW, D = NS - 1, NU = 3;
+  constexpr unsigned kOOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char dsm[];
+  const unsigned planes_off = NS * B_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int lbid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile_n = lbid % a.ntn, tile_m = lbid / a.ntn;
+  const int n0 = tile_n * BN, m0 = tile_m * a.rows;
+  const unsigned frame = fd_div((uint32_t)tile_m, a.fHg);
+  const unsigned ho0 = ((unsigned)tile_m - frame * (unsigned)a.Hg) * (unsigned)a.G;
+  const dma_rsrc_t src_rs = dma_make_rsrc(a.src, (unsigned)a.src_bytes), w_rs = dma_make_rsrc(a.w, (unsigned)a.w_bytes);
+  const unsigned dsm_base = lds_addr(dsm);
+
+  // ---- stage the input lines (the only activation traffic of this workgroup)
+  f32x4 sreg[NU][2];
+  const unsigned line0 = frame * (unsigned)a.Hp + 2u * ho0;
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const unsigned p = (unsigned)(tid + 256 * k);
+    uint32_t ln, pr;
+    fd_divmod(p, a.fWp, ln, pr);
+    const unsigned off = (int)p < a.npos ? ((line0 + ln) * (unsigned)a.Wp + pr) * 32u : kOOB;
+    gload16(sreg[k][0], src_rs, off, 0u);
+    gload16_hi(sreg[k][1], src_rs, off, 0u);
+  }
+  // ---- weight pieces of this wave (as conv_tap_kernel)
+  unsigned woff[NPW];
+  int pieces = 0;
+#pragma unroll
+  for (int u = 0; u < NPW; ++u) {
+    const int p = wave + NW * u;
+    const unsigned o = (unsigned)p * 1024u + (unsigned)lane * 16u;
+    const unsigned hh = o / (BN * 48u), rem = o - hh * (BN * 48u);
+    woff[u] = (hh * (unsigned)a.ldw + (unsigned)n0) * 48u + rem;
+    pieces += p < BPC ? 1 : 0;
+  }
+  auto w_issue = [&](int kk, int stage) {
+#pragma unroll
+    for (int u = 0; u < NPW; ++u)
+      if (wave + NW * u < BPC)
+        dma_load16(w_rs, dsm_base + stage * B_BYTES + (wave + NW * u) * 1024, woff[u] + (unsigned)kk * (unsigned)a.ldw * 96u);
+  };
+  // ---- A-fragment addressing: row r = 32 b + l31 of the tile -> (line j, pixel wo); rows past the end read position 0
+  const int nblk = (a.rows + 31) >> 5;
+  unsigned abase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = (wave + NW * i) * 32 + l31;
+    uint32_t j, wo;
+    fd_divmod((uint32_t)(r < a.rows ? r : 0), a.fWo, j, wo);
+    abase[i] = planes_off + (2u * j * (unsigned)a.Wp + wo + (unsigned)h) * 48u;
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int s = 0; s < D; ++s) w_issue(s, s);
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(sreg[0][0]), "+v"(sreg[0][1]), "+v"(sreg[1][0]), "+v"(sreg[1][1]), "+v"(sreg[2][0]), "+v"(sreg[2][1])::"memory");
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const int p = tid + 256 * k;
+    if (p < a.npos) {
+      const float v[8] = {sreg[k][0].x, sreg[k][0].y, sreg[k][0].z, sreg[k][0].w, sreg[k][1].x, sreg[k][1].y, sreg[k][1].z, sreg[k][1].w};
+      const Split3 q = split3(v);
+      bf16x8* dst = reinterpret_cast<bf16x8*>(dsm + planes_off + (unsigned)p * 48u);
+      dst[0] = q.hi; dst[1] = q.mid; dst[2] = q.lo;
+    }
+  }
+  const unsigned bbase = (unsigned)(h * BN + l31) * 48u;
+  const unsigned wp48 = (unsigned)a.Wp * 48u;
+  int cur = 0, nxt = D % NS;
+  for (int kk = 0; kk < NK; ++kk) {
+    dma_wait_upto(min(D - 1, NK - 1 - kk) * pieces);          // stage `cur` has landed (this wave's pieces)
+    __syncthreads();                                            // ... everybody's; stage `nxt` is free; kk == 0: the planes are published
+    if (kk + D < NK) w_issue(kk + D, nxt);
+    Split3 bf[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const bf16x8* pb = reinterpret_cast<const bf16x8*>(dsm + cur * B_BYTES + bbase + j * (32 * 48));
+      bf[j].hi = pb[0]; bf[j].mid = pb[1]; bf[j].lo = pb[2];
+    }
+    const unsigned koff = (unsigned)(kk >> 1) * wp48 + (unsigned)(kk & 1) * 96u;      // kernel row dh = kk / 2, pair taps 2 (kk & 1) + h
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (wave + NW * i >= nblk) continue;                      // (wave-uniform) 7 row blocks: the last wave carries one
+      const bf16x8* pa = reinterpret_cast<const bf16x8*>(dsm + abase[i] + koff);
+      Split3 af;
+      af.hi = pa[0]; af.mid = pa[1]; af.lo = pa[2];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) mma_split3(af, bf[j], acc[i][j]);
+    }
+    cur = cur + 1 == NS ? 0 : cur + 1;
+    nxt = nxt + 1 == NS ? 0 : nxt + 1;
+  }
+
+  // ---------------- epilogue: fp32 tiles straight from the accumulators (row term in voffset: range-checked)
+  const int flags = a.flags;
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+  const unsigned ldo4 = (unsigned)a.ldo * 4u;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + j * 32 + l31;
+      const unsigned cb = (unsigned)col * 4u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (wave + NW * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool ok = rl < a.rows;
+        const float v = ok ? acc[i][j][r] : 0.f;               // rows past the end feed neither the output nor the statistics
+        acc[i][j][r] = v;
+        if (ok && col < a.NP) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, (int)((unsigned)(m0 + rl) * ldo4 + cb), 0, 0);
+      }
+    }
+  }
+  if (flags & DV_STATS) {
+    // per column: sum and M2 about the tile mean (two passes over the accumulators), [2][N][tiles]
+    float* red = reinterpret_cast<float*>(dsm);                 // [NW][BN] + [BN] floats in the weight stages
+    float* meanb = red + NW * BN;
+    const int n_mt = a.M / a.rows;
+    __syncthreads();                                            // the weight stages are free
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+      s += __shfl_xor(s, 32);
+      if (h == 0) red[wave * BN + j * 32 + l31] = s;
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[w * BN + tid];
+      meanb[tid] = s / (float)a.rows;
+      if (n0 + tid < a.N) a.stats[(size_t)(n0 + tid) * n_mt + tile_m] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float mu = meanb[j * 32 + l31];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = (wave + NW * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float dlt = acc[i][j][r] - mu;
+          s += rl < a.rows ? dlt * dlt : 0.f;
+        }
+      s += __shfl_xor(s, 32);
+      if (h == 0) red[wave * BN + j * 32 + l31] = s;
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.N) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[w * BN + tid];
+      a.stats[(size_t)(a.N + n0 + tid) * n_mt + tile_m] = s;
+    }
+  }
+}
+
+// lines per tile of the pixel-pair stem form for this problem, or 0 (not that form / does not fit)
+static int pp_lines(const ConvArgs& a, int mode) {
+  static const int on = getenv("DUALVAR_CONV_PP_FWD") ? atoi(getenv("DUALVAR_CONV_PP_FWD")) : 1;
+  static const int any_size = (getenv("DUALVAR_CONV_TAP_GRID") ? atoi(getenv("DUALVAR_CONV_TAP_GRID")) : 128) <= 1;
+  const ConvGeom& g = a.g;
+  if (!on || mode != MODE_FWD || !(a.flags & DV_W3) || (a.flags & (DV_BIAS | DV_RELU | DV_SIGMOID | DV_ACCUM)) || a.out_bytes <= 0) return 0;
+  if (a.cls_on || a.bn_x != nullptr || a.in_scale != nullptr) return 0;
+  if (g.kt != 1 || g.kh != 7 || g.kw != 4 || g.st != 1 || g.sh != 2 || g.sw != 1 || g.pt || g.ph || g.pw || g.CP != 8 || a.lds_ != 8) return 0;
+  if (g.rW < 1 || g.rW > 64 || g.sW < g.rW + 3 || g.sH < 2 * g.rH + 5) return 0;
+  for (int G = std::min(256 / g.rW, g.rH); G >= 1; --G) {
+    if (g.rH % G) continue;
+    if ((2 * G + 5) * g.sW > 768) continue;                      // three staging units per thread
+    if (2 * 64 * 96 + (size_t)(2 * G + 5) * g.sW * 48 > 54000) continue;       // three workgroups per CU
+    if (!any_size && (G * g.rW < 128 || (int64_t)(a.M / (G * g.rW)) * ((a.NP + 63) / 64) < 512)) return 0;
+    return G;
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ host side
 // 0: not applicable; 1: spatial; 2: temporal
 static int tap_kind(const ConvArgs& a, int mode) {
@@ -582,6 +800,31 @@ static void launch_tap(const TapArgs& t, int grid, size_t lds, hipStream_t s) {
 // floats of dv_conv3d_dgrad_bn_ws's workspace for a launch of `rows` rows and `np` (padded) columns
 int64_t dvt_bn_ws_floats(int64_t rows, int np) {
   return (int64_t)((np + 63) / 64) * bn_ws_floats_per_coltile((int)((rows + 255) / 256));
+}
+
+// rows per tile (= rows per BatchNorm partial) when dv_conv3d_fwd runs this problem on the pixel-pair stem form, else 0
+int dvt_conv_pp_rows(const void* conv_args, int mode) {
+  const ConvArgs& a = *static_cast<const ConvArgs*>(conv_args);
+  return pp_lines(a, mode) * a.g.rW;
+}
+
+int dvt_conv_pp_launch(const void* conv_args, int mode, void* stream) {
+  const ConvArgs& a = *static_cast<const ConvArgs*>(conv_args);
+  const int G = pp_lines(a, mode);
+  if (!G) return 0;
+  const ConvGeom& g = a.g;
+  PpArgs t;
+  t.src = a.src; t.w = a.w; t.out = a.out; t.stats = a.stats;
+  t.M = a.M; t.N = a.N; t.NP = a.NP; t.ldo = a.ldo; t.ldw = a.ldw; t.ntn = (a.NP + 63) / 64;
+  t.flags = a.flags & DV_STATS;
+  t.src_bytes = a.src_bytes; t.w_bytes = a.w_bytes; t.out_bytes = a.out_bytes;
+  t.Wo = g.rW; t.Wp = g.sW; t.Hp = g.sH; t.G = G; t.rows = G * g.rW; t.npos = (2 * G + 5) * g.sW;
+  t.Hg = g.rH / G;
+  t.fWo = make_fastdiv((uint32_t)g.rW); t.fWp = make_fastdiv((uint32_t)g.sW); t.fHg = make_fastdiv((uint32_t)t.Hg);
+  const int grid = t.ntn * (a.M / t.rows);
+  const size_t lds = 2 * 64 * 96 + (size_t)t.npos * 48;
+  hipLaunchKernelGGL((conv_pp_fwd_kernel<2>), dim3(grid), dim3(256), lds, (hipStream_t)stream, t);
+  return 1;
 }
 
 // entry points for conv.hip (the argument block is conv_common.hpp's ConvArgs, passed by address)

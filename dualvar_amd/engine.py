@@ -466,6 +466,8 @@ def _conv_kname(lib, d, dgrad, dt, gv=16):
     """label of the kernel dv_conv3d_fwd / dv_conv3d_dgrad will launch for this descriptor (bench.py / profiles group by it)"""
     mode = 'DGRAD' if dgrad else 'FWD'
     tap = int(lib.dv_conv3d_tap_kind(C.byref(d), int(dgrad)))
+    if tap == 3:
+        return 'conv_pp<%s,%s>' % (dt, mode)         # (the pixel-pair stem form: tiles of whole output lines)
     if tap:
         return 'conv_tap<%s,%s,%s,256,64>' % (dt, mode, 'sp' if tap == 1 else 'tm')
     ks = int(lib.dv_conv3d_ksplit_cols(C.byref(d), int(dgrad)))

@@ -103,7 +103,9 @@ int dv_conv3d_ksplit_cols(const dv_conv_desc* d, int32_t dgrad);
 /* informational: 1 / 2 when dv_conv3d_fwd (dgrad = 0) / dv_conv3d_dgrad (1) will run this problem on the LDS-staged input-tile
  * kernel (csrc/conv_tap.hip) in its spatial (1x3x3) / temporal (3x1x1) form -- DV_F32 with DV_W3, stride 1, "same" padding,
  * channel pitch % 16 == 0, at least two rounds of 256-row x 64-column tiles: the separable pairs of backbone/s3dg.py:30-65 and
- * backbone/r21d.py:11-70 on the large maps -- else 0.  Its BatchNorm partials are per 256 rows (dv_conv3d_tile_rows). */
+ * backbone/r21d.py:11-70 on the large maps -- else 0.  Its BatchNorm partials are per 256 rows (dv_conv3d_tile_rows).
+ * 3 (dgrad = 0 only): the pixel-pair stem form of that kernel -- the RGB stem conv (backbone/s3dg.py:151) as a 1x7x4 window over
+ * 8-channel pixel pairs, stride (1,2,1): tiles of G whole output lines (dv_conv3d_tile_rows = G * Wo, e.g. 224). */
 int dv_conv3d_tap_kind(const dv_conv_desc* d, int32_t dgrad);
 /* y = conv(x, w) [+bias][act]; with DV_STATS also stats[2][Cout][tiles] = (sum, M2 about the
  * tile mean) of the values as stored.  */

@@ -54,6 +54,8 @@ def short(name):
     m = re.search(r'conv_tap_kernelILi(\d)E', n) or re.search(r'conv_tap_kernel<(\d)', n)
     if m:
         return 'conv_tap<f32,%s,256,64>' % ('sp' if m.group(1) == '0' else 'tm')          # (fwd and dgrad are one kernel)
+    if re.search(r'conv_pp_fwd_kernel', n):
+        return 'conv_pp<f32,FWD>'
     m = re.search(r'conv_wgrad_tm_kernelILi\d+ELi\d+ELi(\d+)ELi\d+ELi\d+ELi(\d+)E', n) or \
         re.search(r'conv_wgrad_tm_kernel<\d+, \d+, (\d+), \d+, \d+, (\d+)(?:, (?:true|false))?>', n)      # (BatchNorm-on-load instantiations: same family)
     if m:

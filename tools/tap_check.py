@@ -117,6 +117,49 @@ def check_bn_in(lib, dev, xa, dya, w, k, s, p, tag):
     return ok
 
 
+def check_pp_stem_forward(lib, dev, N, T, H, W, O, want_rows):
+    """the pixel-pair stem form of the forward (conv_pp_fwd_kernel): dv_ingest_ncdhw_pad + the 1x7x4 / stride (1,2,1) conv over pixel
+    pairs against torch's 7x7 / stride 2 / padding 3 conv3d in float64 (backbone/s3dg.py:151), with the BatchNorm partials and a
+    sentinel behind the output"""
+    DT = L.DV_F32
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, 3, T, H, W, generator=g)
+    w = 0.2 * torch.randn(O, 3, 1, 7, 7, generator=g)
+    yr = F.conv3d(x.double(), w.double(), None, (1, 2, 2), (0, 3, 3))
+    a = ops.new_act(N, T, H + 6, W + 6, 3, DT, dev, cpitch=4, zero=True)
+    ops.call('dv_ingest_ncdhw_pad', DT, x.to(dev), a, N, 3, T, H, W, 3 * T * H * W, 4, None, None, None, 0, 3)
+    pairs = ops.Act(a.buf.view(-1, 8), N, T, H + 6, (W + 6) // 2, 8, 8, 0, DT, 8)
+    To, Ho, Wo = yr.shape[2:]
+    M = N * To * Ho * Wo
+    OP = ops.cp8(O)
+    ybuf = torch.full((M + 300, OP), 12345.0, dtype=torch.float32, device=dev)
+    ybuf[:M] = 0
+    y = ops.Act(ybuf[:M], N, To, Ho, Wo, O, OP, 0, DT, OP)
+    d = ops.conv_desc(DT, pairs, y, (1, 7, 4), (1, 2, 1), (0, 0, 0), flags=L.DV_STATS | L.DV_W3)
+    kind, rows = int(lib.dv_conv3d_tap_kind(C.byref(d), 0)), ops.tile_rows(d)
+    assert kind == 3 and rows == want_rows, (kind, rows, want_rows)
+    w8 = torch.zeros(O, 3, 1, 7, 8)
+    w8[..., :7] = w
+    wp = ops.pack_weight(w8, 4).to(dev)                       # [O][7*8 taps][4] == [O][7*4 pair taps][8]
+    tiles = ops.stat_tiles(d)
+    assert tiles * rows == M
+    stats = torch.zeros(2, O, tiles, device=dev)
+    ops.conv_fwd(d, pairs, ops.pack_w3(wp.view(O, -1)), None, y, stats)
+    torch.cuda.synchronize()
+    e_f = float((ops.act_to_ncdhw(y).double().cpu() - yr).abs().max() / yr.abs().max())
+    local = torch.zeros(2 * O + 1, device=dev)
+    ops.call('dv_bn_reduce_stats', stats, tiles, rows, O, M, O, local)
+    mean_ref, var_ref = yr.mean(dim=(0, 2, 3, 4)), yr.var(dim=(0, 2, 3, 4), unbiased=False)
+    e_m = float(((local[:O].cpu().double() / M) - mean_ref).abs().max() / var_ref.sqrt().max())
+    e_v = float(((local[O:2 * O].cpu().double() / M) - var_ref).abs().max() / var_ref.max())
+    assert bool((ybuf[M:] == 12345.0).all()), 'wrote behind the output'
+    if OP > O:
+        assert float(ybuf[:M, O:].abs().max()) == 0.0
+    print('pixel-pair stem forward N%d T%d %dx%d Cout%d: tiles of %d rows | fwd %.2e mean %.2e var %.2e' % (N, T, H, W, O, rows, e_f, e_m, e_v), flush=True)
+    assert e_f == e_f and e_f < 3e-6 and e_m < 3e-6 and e_v < 1e-5, (e_f, e_m, e_v)
+    return e_f
+
+
 def main():
     L.require_device()
     dev = torch.device('cuda:0')
@@ -268,6 +311,9 @@ def main():
         else:
             e_d = float('nan')
         print('strided dgrad N%d Cin%d T%d->%d %dx%d Cout%d k%d s%d: kind %d | dgrad(+=) %.2e' % (N, Ci, Ti, To, H, W, Co, kt, st, kind_d, e_d), flush=True)
+    # the pixel-pair stem form of the forward on small frames: a ragged last row block (99 rows), a full 256-row tile, 56-pixel lines
+    for (N, T, H, W, O, rows) in [(2, 4, 18, 22, 24, 99), (1, 3, 32, 32, 64, 256), (2, 2, 24, 112, 40, 224), (1, 2, 10, 128, 72, 64)]:
+        worst = max(worst, check_pp_stem_forward(lib, dev, N, T, H, W, O, rows))
     print('worst', worst)
     assert worst < 5e-6, worst
     print('ok')
