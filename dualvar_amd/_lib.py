@@ -90,6 +90,7 @@ SIGNATURES = {
     'dv_conv3d_tile_shape': [CD, I32, P, P],
     'dv_conv3d_ksplit_cols': [CD, I32],
     'dv_conv3d_tap_kind': [CD, I32],
+    'dv_conv3d_tap_rows': [CD, I32],
     'dv_conv3d_fwd': [CD, P, P, P, P, P, P],
     'dv_conv3d_dgrad': [CD, P, P, P, P],
     'dv_conv3d_dgrad_bn': [CD, P, P, P, P, P],

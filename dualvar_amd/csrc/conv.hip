@@ -17,6 +17,7 @@
 
 // the LDS-staged input-tile kernels for stride-1 "same" 1x3x3 / 3x1x1 convs (conv_tap.hip); the argument is a ConvArgs*
 int dvt_conv_tap_kind(const void* conv_args, int mode);
+int dvt_conv_tap_rows(const void* conv_args, int mode);
 int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream);
 int64_t dvt_bn_ws_floats(int64_t rows, int np);
 int dvt_conv_pp_rows(const void* conv_args, int mode);
@@ -1799,11 +1800,28 @@ extern "C" int dv_conv3d_tap_kind(const dv_conv_desc* d, int32_t dgrad) {
   return tap_choice(d, dgrad);
 }
 
+extern "C" int dv_conv3d_tap_rows(const dv_conv_desc* d, int32_t dgrad) {
+  if (!d || check_desc(d)) return 0;
+  const int kind = tap_choice(d, dgrad);
+  if (!kind) return 0;
+  if (kind == 3) return pp_rows_choice(d);
+  if (d->st > 1 || d->sh > 1 || d->sw > 1) return 256;           // (the parity classes of a strided data gradient)
+  ConvArgs a;
+  query_args(d, dgrad, a);
+  trim_dead_taps(a, dgrad ? MODE_DGRAD : MODE_FWD, d->dtype);
+  return dvt_conv_tap_rows(&a, dgrad ? MODE_DGRAD : MODE_FWD);
+}
+
 extern "C" int dv_conv3d_tile_rows(const dv_conv_desc* d) {
   if (!d) return DV_EINVAL;
   if (!check_desc(d)) {
     if (const int r = pp_rows_choice(d)) return r;
-    if (tap_choice(d, 0)) return 256;
+    if (tap_choice(d, 0)) {              // (stride 1 here: the strided forward never runs on the LDS-staged kernel)
+      ConvArgs a;
+      query_args(d, 0, a);
+      trim_dead_taps(a, MODE_FWD, d->dtype);
+      return dvt_conv_tap_rows(&a, MODE_FWD);
+    }
   }
   const int64_t m = (int64_t)d->N * d->To * d->Ho * d->Wo;
   int bm, bn;
@@ -2044,6 +2062,7 @@ static int dgrad_impl(const dv_conv_desc* d, const void* dy, const void* wd, voi
     if (bn_ws) {                                       // dv_conv3d_dgrad_bn_ws: the ordered form, on the LDS-staged kernel only
       const int64_t need = dvt_bn_ws_floats(a.M, a.NP) * 4;
       const int64_t xb = (((int64_t)a.M - 1) * bnr->ldx + a.NP) * 4;
+      if (need <= 0) return DV_EUNSUPPORTED;             // (more tiles than the ticket region of the workspace holds)
       if (bn_ws_bytes < need || !aligned16(bn_ws) || xb >= (1ll << 31) || d->dtype != DV_F32) return DV_EINVAL;
       a.bn_ws = reinterpret_cast<float*>(bn_ws);
       a.bn_bytes = (int)xb;

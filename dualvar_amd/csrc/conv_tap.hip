@@ -67,13 +67,20 @@ struct TapArgs {
 // rows / tickets of the ordered fold (the protocol of elementwise.hip's ordered_fold: sc1 stores -> s_waitcnt vmcnt(0) -> barrier ->
 // one agent-scope ticket -> the last arriver reads with sc1 loads; validated on gfx950, see the comment there)
 constexpr int kBnFoldGroup = 32, kBnRow = 128;                  // tiles per group; floats per row: [sum g | sum g xhat] x 64 columns
+// Workspace layout: [kBnTickWords ticket words][per column tile: n_mt tile rows, ngrp group rows].  The tickets have a region of
+// their own that NO launch ever stores data into: the workspace is shared by launches of different shapes (and by the passes of
+// a step), whose row regions overlap -- with the tickets behind each column tile's rows (the first version of this round) a
+// launch's partial sums landed on the ticket words of another shape's layout, and from the second pass through a plan on the
+// folds ran on garbage counts (gradients 10 % off; tools/probes/fused_reduce_twice.py, test_repeated_passes_...).
+constexpr int kBnTickWords = 16384;
+__host__ __device__ __forceinline__ int bn_ws_tick_stride(int n_mt) { return (((n_mt + kBnFoldGroup - 1) / kBnFoldGroup) + 1 + 7) & ~7; }
 static inline int64_t bn_ws_floats_per_coltile(int n_mt) {
   const int ngrp = (n_mt + kBnFoldGroup - 1) / kBnFoldGroup;
-  return (int64_t)(n_mt + ngrp) * kBnRow + ((ngrp + 1 + 7) & ~7);
+  return (int64_t)(n_mt + ngrp) * kBnRow;
 }
 __device__ __forceinline__ size_t bn_ws_floats_per_coltile_dev(int n_mt) {
   const int ngrp = (n_mt + kBnFoldGroup - 1) / kBnFoldGroup;
-  return (size_t)(n_mt + ngrp) * kBnRow + (size_t)((ngrp + 1 + 7) & ~7);
+  return (size_t)(n_mt + ngrp) * kBnRow;
 }
 __device__ __forceinline__ void tap_coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float tap_coherent_load(const float* p) {
@@ -100,10 +107,13 @@ __device__ __forceinline__ void gload16_hi(f32x4& dst, dma_rsrc_t rsrc, unsigned
 // KIND 0: spatial (1 x kh x kw, NTAPS = kh * kw);  KIND 1: temporal (kt x 1 x 1, NTAPS = kt)
 // NU: staging units (8 channels of one position = 32 B) per thread: ceil(2 * npos / 256)
 // BNL: BatchNorm (+ReLU) of the layer in front applied to the staged slab (coefficients in an LDS table behind the zero slot)
-template <int KIND, int NTAPS, int BN, int NS, int NU, bool BNL = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_tap_kernel(TapArgs a) {
+// BM: rows per tile, 256 (a wave owns 64 rows) or 128 (32): the 128-row form is for launches of less than ~1.5 workgroups per CU
+// in the 256-row form (the 12 544-row levels): twice the workgroups, two or three of them resident per CU instead of one
+template <int KIND, int NTAPS, int BN, int NS, int NU, bool BNL = false, int BM = 256>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, BM == 128 ? 4 : 3))) void conv_tap_kernel(TapArgs a) {
   static_assert(!BNL || KIND == 1, "BatchNorm on load: temporal form (rows past the end never share a tile row with valid ones)");
-  constexpr int BM = 256, NW = 4, TM = 2, TN = BN / 32;
+  static_assert(BM == 256 || BM == 128, "tile height");
+  constexpr int NW = 4, TM = BM / 128, WR = BM / NW, TN = BN / 32;       // WR: rows of a wave
   constexpr int B_BYTES = BN * 96, BPC = B_BYTES / 1024;       // one weight stage: hi|mid|lo of both k halves, in 1 KiB DMA pieces
   static_assert(B_BYTES % 1024 == 0, "weight stage in 1 KiB pieces");
   constexpr int NPW = (BPC + NW - 1) / NW;                      // pieces per wave and stage (the last round may be partial)
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   for (int i = 0; i < TM; ++i) {
     amask[i] = 0; bfr[i] = 0; bpb[i] = 0;
     if constexpr (KIND == 0) {
-      const int rloc = 64 * wave + 32 * i + l31;
+      const int rloc = WR * wave + 32 * i + l31;
       abase[i] = planes_off + (unsigned)(h * npp + a.halo + rloc) * 48u;
       uint32_t q_, ww, hh_, q2;
       fd_divmod((uint32_t)(m0 + rloc), a.fW, q_, ww);
@@ -248,7 +258,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       amask[i] = inv;
     } else {
       // balanced (frame, pixel block) pairs per wave: border frames have a tap less
-      if (a.T == 2) { bfr[i] = i; bpb[i] = wave; }
+      if constexpr (BM == 128) {           // one (frame, 32-pixel block) per wave: T = 2 -> P = 64, T = 4 -> P = 32
+        if (a.T == 2) { bfr[i] = wave & 1; bpb[i] = wave >> 1; }
+        else { bfr[i] = wave; bpb[i] = 0; }
+      }
+      else if (a.T == 2) { bfr[i] = i; bpb[i] = wave; }
       else if (a.T == 4) {                 // frames {0, 2} and {1, 3} pair up: equal tap counts for 3 taps / padding 1 and 4 / 2
         const int f0 = ((wave & 1) << 1) | (wave >> 1);
         bfr[i] = i == 0 ? f0 : (f0 ^ 2); bpb[i] = i;
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       unsigned row;
       bool ok;
       if constexpr (KIND == 0) {
-        const int m = m0 + 64 * wave + 32 * i + rl;
+        const int m = m0 + WR * wave + 32 * i + rl;
         ok = m < a.M; row = (unsigned)m;
       } else {
         const unsigned q = (unsigned)(tile_m * a.P + bpb[i] * 32 + rl);
@@ -428,10 +442,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
     const int n_mt = (a.M + BM - 1) / BM, ngrp = (n_mt + G - 1) / G, grp = tile_m / G;
     const int gsize = min(G, n_mt - grp * G);
-    float* wsn = a.bn_ws + (size_t)tile_n * bn_ws_floats_per_coltile_dev(n_mt);
-    float* rows = wsn;
+    float* rows = a.bn_ws + kBnTickWords + (size_t)tile_n * bn_ws_floats_per_coltile_dev(n_mt);
     float* grows = rows + (size_t)n_mt * kBnRow;
-    unsigned* tick = reinterpret_cast<unsigned*>(grows + (size_t)ngrp * kBnRow);
+    unsigned* tick = reinterpret_cast<unsigned*>(a.bn_ws) + (size_t)tile_n * bn_ws_tick_stride(n_mt);      // [ngrp group tickets | 1]
     unsigned* lastf = reinterpret_cast<unsigned*>(redf + (NW * 2 + 2) * BN);
     const int which = tid >> 6, cc = tid & 63;                  // tid < 128: (sum index, column)
     const bool mine = tid < kBnRow;
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int r = 0; r < 16; ++r) {
           const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
           bool ok;
-          if constexpr (KIND == 0) ok = m0 + 64 * wave + 32 * i + rl < a.M;
+          if constexpr (KIND == 0) ok = m0 + WR * wave + 32 * i + rl < a.M;
           else ok = tile_m * a.P + bpb[i] * 32 + rl < a.NQ;
           const float dlt = acc[i][j][r] - mu;
           s += ok ? dlt * dlt : 0.f;
@@ -754,11 +767,12 @@ static int pp_lines(const ConvArgs& a, int mode) {
 // 0: not applicable; 1: spatial; 2: temporal
 static int tap_kind(const ConvArgs& a, int mode) {
   static const int on = getenv("DUALVAR_CONV_TAP") ? atoi(getenv("DUALVAR_CONV_TAP")) : 1;
-  // smallest grid (256-row x 64-column tiles) the kernel takes: half a chip's worth of workgroups.  The 12 544-row levels
-  // (Mixed_4b - 4f: 196 .. 245 tiles) are 10 - 20 % faster on it in isolation (1x3x3 forward 76.6 -> 63.4, 85.5 -> 69.5 us; 3x1x1
-  // data gradient 59.2 -> 47.6 us) and the step is equal within noise (18.13 / 18.11 / 18.09 ms at 512 / 256 / 128 on one box);
-  // below that conv_gemm's 64-row tiles / conv_gemm_ks fill the chip better.  DUALVAR_CONV_TAP_GRID overrides (tests: 1).
-  static const int min_grid = getenv("DUALVAR_CONV_TAP_GRID") ? atoi(getenv("DUALVAR_CONV_TAP_GRID")) : 128;
+  // smallest grid (counted in 256-row x 64-column tiles) the kernel takes.  With the 128-row tiles (tap_bm) the 64-channel
+  // branches of the 12 544-row levels (49 tiles) belong here too: their data gradients leave conv_gemm_ks (nine launches, 498 -> 177
+  // us) for +287 us of this kernel, forwards likewise, five more BatchNorms are applied on load -- step 16.35 - 16.49 -> 16.10 -
+  // 16.22 ms (thresholds 128 / 49 / 25 / 10: 16.35, 16.16, 16.18, 16.36 ms).  Below that (the 1 152-row levels) conv_gemm_ks's K split
+  // over the waves fills the chip better.  DUALVAR_CONV_TAP_GRID overrides (tests: 1).
+  static const int min_grid = getenv("DUALVAR_CONV_TAP_GRID") ? atoi(getenv("DUALVAR_CONV_TAP_GRID")) : 49;
   if (!on) return 0;
   const ConvGeom& g = a.g;
   if (!(a.flags & DV_W3) || (a.flags & (DV_BIAS | DV_RELU | DV_SIGMOID)) || a.out_bytes <= 0) return 0;
@@ -790,16 +804,32 @@ static int tap_kind(const ConvArgs& a, int mode) {
   return 0;
 }
 
-template <int KIND, int NTAPS, int NU, bool BNL = false>
+template <int KIND, int NTAPS, int NU, bool BNL = false, int BM = 256>
 static void launch_tap(const TapArgs& t, int grid, size_t lds, hipStream_t s) {
-  hipLaunchKernelGGL((conv_tap_kernel<KIND, NTAPS, 64, 3, NU, BNL>), dim3(grid), dim3(256), lds, s, t);
+  hipLaunchKernelGGL((conv_tap_kernel<KIND, NTAPS, 64, 3, NU, BNL, BM>), dim3(grid), dim3(256), lds, s, t);
+}
+
+// tile height: 128 rows where the 256-row form would launch fewer than ~1.5 workgroups per CU (the 12 544-row levels: 147 - 245
+// workgroups, one wave per SIMD, latency bound): twice the workgroups, two or three resident per CU.  Not for the parity
+// classes of the strided stem data gradient (large) nor for eight-frame temporal tiles (128 / 8 pixels < one row block).
+static int tap_bm(const ConvArgs& a, int kind) {
+  static const int on = getenv("DUALVAR_CONV_TAP_BM128") ? atoi(getenv("DUALVAR_CONV_TAP_BM128")) : 1;
+  // below ONE full round of three workgroups per CU (sweep on the headline step, kernel time summed over the step: 384 -> 17.60 -
+  // 17.65 ms, 800 -> 17.38 - 17.41, 1 600 -> 17.33 - 17.43; step time equal within noise)
+  static const int max_grid = getenv("DUALVAR_CONV_TAP_BM128_GRID") ? atoi(getenv("DUALVAR_CONV_TAP_BM128_GRID")) : 768;
+  if (!on || a.cls_on == 1) return 256;
+  if (kind == 2 && a.g.sT != 2 && a.g.sT != 4) return 256;
+  const int64_t grid = (int64_t)((a.M + 255) / 256) * ((a.NP + 63) / 64);
+  return grid < max_grid ? 128 : 256;
 }
 
 }  // namespace
 
 // floats of dv_conv3d_dgrad_bn_ws's workspace for a launch of `rows` rows and `np` (padded) columns
 int64_t dvt_bn_ws_floats(int64_t rows, int np) {
-  return (int64_t)((np + 63) / 64) * bn_ws_floats_per_coltile((int)((rows + 255) / 256));
+  const int n_mt = (int)((rows + 127) / 128), ntn = (np + 63) / 64;        // (sized for the 128-row tiles: covers both tile heights)
+  if ((int64_t)ntn * bn_ws_tick_stride(n_mt) > kBnTickWords) return 0;     // (more tickets than the ticket region holds: not fused)
+  return kBnTickWords + (int64_t)ntn * bn_ws_floats_per_coltile(n_mt);
 }
 
 // rows per tile (= rows per BatchNorm partial) when dv_conv3d_fwd runs this problem on the pixel-pair stem form, else 0
@@ -829,6 +859,12 @@ int dvt_conv_pp_launch(const void* conv_args, int mode, void* stream) {
 
 // entry points for conv.hip (the argument block is conv_common.hpp's ConvArgs, passed by address)
 int dvt_conv_tap_kind(const void* conv_args, int mode) { return tap_kind(*static_cast<const ConvArgs*>(conv_args), mode); }
+// rows per tile (= rows per BatchNorm partial) of that launch, 0 when the problem does not run on the kernel
+int dvt_conv_tap_rows(const void* conv_args, int mode) {
+  const ConvArgs& a = *static_cast<const ConvArgs*>(conv_args);
+  const int kind = tap_kind(a, mode);
+  return kind ? tap_bm(a, kind) : 0;
+}
 
 // launches the LDS-staged kernel for this problem if it is one of its forms; returns 1 when it did
 int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream) {
@@ -845,7 +881,8 @@ int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream) {
   t.CP = g.CP;
   t.H = g.sH; t.W = g.sW; t.T = g.sT; t.S = g.sH * g.sW;
   t.fW = make_fastdiv((uint32_t)g.sW); t.fH = make_fastdiv((uint32_t)g.sH); t.fS = make_fastdiv((uint32_t)t.S);
-  t.P = 256 / g.sT; t.lgP = 0;
+  const int bm = tap_bm(a, kind);
+  t.P = bm / g.sT; t.lgP = 0;
   while ((1 << t.lgP) < t.P) ++t.lgP;
   t.NQ = a.M / g.sT;
   t.pt = g.pt; t.wt0 = 0; t.wts = 1; t.oT = g.sT; t.ofs = 1; t.ofo = 0;
@@ -856,21 +893,27 @@ int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream) {
   t.bn_cpb = (a.N + 7) & ~7;
   if (a.bn_x == nullptr) { t.bn_ws = nullptr; t.bn_sums = nullptr; t.bn_bytes = 0; }
   t.in_scale = a.in_scale; t.in_shift = a.in_shift; t.in_C = a.in_C; t.in_relu = a.in_relu;
-  const int grid = t.ntn * ((a.M + 255) / 256);
+  const int grid = t.ntn * ((a.M + bm - 1) / bm);
   hipStream_t s = (hipStream_t)stream;
   if (kind == 1) {
     t.halo = g.ph * g.sW + g.pw;
-    t.npos = 256 + 2 * t.halo;
+    t.npos = bm + 2 * t.halo;
     t.npp = t.npos + ((4 - t.npos % 8) + 8) % 8;
     const size_t lds = 3 * 64 * 96 + (size_t)t.npp * 96 + 64;
-    if (2 * t.npos <= 512) launch_tap<0, 9, 2>(t, grid, lds, s);
+    if (bm == 128) launch_tap<0, 9, 2, false, 128>(t, grid, lds, s);        // (128 + 2 (W + 1) <= 256 positions: two units per thread)
+    else if (2 * t.npos <= 512) launch_tap<0, 9, 2>(t, grid, lds, s);
     else launch_tap<0, 9, 3>(t, grid, lds, s);
   } else {
     t.halo = 0;
-    t.npos = 256;
+    t.npos = bm;
     t.npp = t.npos + 4;
     const size_t lds = 3 * 64 * 96 + (size_t)t.npp * 96 + 64;
-    if (a.in_scale != nullptr) launch_tap<1, 3, 2, true>(t, grid, lds + (size_t)g.CP * 8, s);
+    if (bm == 128) {
+      if (a.in_scale != nullptr) launch_tap<1, 3, 1, true, 128>(t, grid, lds + (size_t)g.CP * 8, s);
+      else if (g.kt == 4) launch_tap<1, 4, 1, false, 128>(t, grid, lds, s);
+      else launch_tap<1, 3, 1, false, 128>(t, grid, lds, s);
+    }
+    else if (a.in_scale != nullptr) launch_tap<1, 3, 2, true>(t, grid, lds + (size_t)g.CP * 8, s);
     else if (g.kt == 4) launch_tap<1, 4, 2>(t, grid, lds, s);
     else launch_tap<1, 3, 2>(t, grid, lds, s);
   }

@@ -107,6 +107,9 @@ int dv_conv3d_ksplit_cols(const dv_conv_desc* d, int32_t dgrad);
  * 3 (dgrad = 0 only): the pixel-pair stem form of that kernel -- the RGB stem conv (backbone/s3dg.py:151) as a 1x7x4 window over
  * 8-channel pixel pairs, stride (1,2,1): tiles of G whole output lines (dv_conv3d_tile_rows = G * Wo, e.g. 224). */
 int dv_conv3d_tap_kind(const dv_conv_desc* d, int32_t dgrad);
+/* informational: rows per tile of that launch (256; 128 where the 256-row form would not fill the chip: the 12 544-row levels;
+ * the pixel-pair stem form: G * Wo), 0 when dv_conv3d_tap_kind is 0.  For dgrad = 0 this is dv_conv3d_tile_rows. */
+int dv_conv3d_tap_rows(const dv_conv_desc* d, int32_t dgrad);
 /* y = conv(x, w) [+bias][act]; with DV_STATS also stats[2][Cout][tiles] = (sum, M2 about the
  * tile mean) of the values as stored.  */
 int dv_conv3d_fwd(const dv_conv_desc* d, const void* x, const void* w_fwd, const float* bias,
@@ -137,7 +140,8 @@ int dv_conv3d_dgrad_bn(const dv_conv_desc* d, const void* dy, const void* w_dgra
  * the workgroups that take the last tickets add the rows in tile order: no float atomics, two runs give the same bits.  The
  * result is ADDED to sums[0][2][cp8(Cin)] (n_rep is ignored; the caller zeroes `sums`).  dv_conv3d_dgrad_bn_workspace returns
  * the bytes `workspace` must hold (0: this problem does not run on that kernel -- use dv_bn_bwd_reduce); its ticket words must be
- * ZERO before the first call and are left zero (memset the buffer once; it may be shared by consecutive calls on one stream). */
+ * ZERO before the first call and are left zero (memset the buffer once; it may be shared by consecutive calls on one stream, of
+ * any shapes: the tickets are the first 64 KiB of the buffer and no launch stores anything else there). */
 int64_t dv_conv3d_dgrad_bn_workspace(const dv_conv_desc* d);
 int dv_conv3d_dgrad_bn_ws(const dv_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const dv_bn_reduce* bn,
                           void* workspace, int64_t workspace_bytes, void* stream);

@@ -1384,9 +1384,12 @@ def test_lds_staged_input_tile_kernel_on_small_and_ragged_shapes(gpu):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DUALVAR_CONV_TAP_GRID='1')
-    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'tap_check.py')], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout[-3000:] + r.stderr[-2000:]
-    assert 'kind fwd 0' not in r.stdout and 'dgrad 0' not in r.stdout, r.stdout[-3000:]
+    for bm128 in ('0', '1'):             # the 256-row tiles, then the 128-row tiles small launches get by default (tap_bm)
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'tap_check.py')], capture_output=True, text=True, timeout=600,
+                           env=dict(env, DUALVAR_CONV_TAP_BM128=bm128))
+        assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout[-3000:] + r.stderr[-2000:]
+        assert 'kind fwd 0' not in r.stdout and 'dgrad 0' not in r.stdout, r.stdout[-3000:]
+        assert ('rows 128' in r.stdout) == (bm128 == '1') and 'rows 256' in r.stdout, r.stdout[-3000:]     # (eight-frame temporal tiles stay 256)
     # the pixel-pair stem form of the LDS-staged weight gradient (conv_wgrad_pp_kernel, with and without the BatchNorm apply
     # inside) on the small stem shapes of this file: the same tests, with the size thresholds lifted
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k',

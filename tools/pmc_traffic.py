@@ -53,7 +53,8 @@ def short(name):
     # the LDS-staged kernels of round 4 (csrc/conv_tap.hip, conv_tap_wgrad.hip)
     m = re.search(r'conv_tap_kernelILi(\d)E', n) or re.search(r'conv_tap_kernel<(\d)', n)
     if m:
-        return 'conv_tap<f32,%s,256,64>' % ('sp' if m.group(1) == '0' else 'tm')          # (fwd and dgrad are one kernel)
+        bm = '128' if re.search(r'conv_tap_kernel<[^>]*, 128>|conv_tap_kernelI\S*Li128EEE', n) else '256'
+        return 'conv_tap<f32,%s,%s,64>' % ('sp' if m.group(1) == '0' else 'tm', bm)          # (fwd and dgrad are one kernel)
     if re.search(r'conv_pp_fwd_kernel', n):
         return 'conv_pp<f32,FWD>'
     m = re.search(r'conv_wgrad_tm_kernelILi\d+ELi\d+ELi(\d+)ELi\d+ELi\d+ELi(\d+)E', n) or \

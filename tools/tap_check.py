@@ -29,6 +29,10 @@ CASES = [
     (3, 32, 8, 6, 5, 80, (3, 1, 1), (1, 0, 0)),
     (7, 80, 4, 7, 5, 136, (3, 1, 1), (1, 0, 0)),
     (9, 208, 2, 7, 7, 208, (3, 1, 1), (1, 0, 0)),
+    # more than 32 tiles per column tile: the two-level fold of the fused BatchNorm-backward reduce (49 tiles of 128 rows / 25 of 256;
+    # R(2+1)D's conv3 block at two clips)
+    (2, 128, 4, 28, 28, 230, (1, 3, 3), (0, 1, 1)),
+    (8, 64, 2, 28, 28, 64, (3, 1, 1), (1, 0, 0)),
 ]
 
 
@@ -246,8 +250,8 @@ def main():
             okb = check_bn_in(lib, dev, xp, dya, w, k, (1, 1, 1), p, 'N%d Cin%d T%d' % (N, Ci, T))
             assert okb == (1 if T in (2, 4) else 0), (T, okb)
             print('   BatchNorm on load (fwd + weight gradient, bit for bit against apply-then-conv): %s' % ('ok' if okb else 'n/a (T = %d)' % T), flush=True)
-        print('N%d Cin%d T%d %dx%d Cout%d k%s: kind fwd %d dgrad %d | fwd %.2e mean %.2e var %.2e dgrad(+=) %.2e pad %s | fused bn sums %.2e' % (
-            N, Ci, T, H, W, Co, 'x'.join(map(str, k)), kind, kind_d, e_f, e_m, e_v, e_d, pad_ok, e_bn), flush=True)
+        print('N%d Cin%d T%d %dx%d Cout%d k%s: rows %d: kind fwd %d dgrad %d | fwd %.2e mean %.2e var %.2e dgrad(+=) %.2e pad %s | fused bn sums %.2e' % (
+            N, Ci, T, H, W, Co, 'x'.join(map(str, k)), ops.tile_rows(d), kind, kind_d, e_f, e_m, e_v, e_d, pad_ok, e_bn), flush=True)
         assert e_bn < 2e-6, e_bn
         assert all(e == e for e in (e_f, e_m, e_v, e_d)), 'NaN'
         worst = max(worst, e_f, e_m, e_v, e_d)
