@@ -329,14 +329,14 @@ def run_leg(args, dtype, rank, world, distributed, dev):
     # (single stream for this one step, so that every kernel's time is its own: in the timed region the weight
     # gradients run on a side stream, concurrently with the main chain -- engine.Plan.run_backward)
     WD.phase(f'{dtype}: calibration step', 300 if wd_on else 0)
-    side_default, branch_default = _eng.WGRAD_SIDE_STREAM, _eng.BRANCH_STREAMS
-    _eng.WGRAD_SIDE_STREAM = _eng.BRANCH_STREAMS = False
+    side_default = _eng.WGRAD_SIDE_STREAM
+    _eng.WGRAD_SIDE_STREAM = False
     cal = KernelTimer()
     for p in all_plans(model):
         p.timer = cal
     step()
     torch.cuda.synchronize()
-    _eng.WGRAD_SIDE_STREAM, _eng.BRANCH_STREAMS = side_default, branch_default
+    _eng.WGRAD_SIDE_STREAM = side_default
     csum = cal.summary()
     if args.dump_launches and rank == 0:
         with open(args.dump_launches if dtype == args.dtype else args.dump_launches + '.' + dtype, 'w') as fh:

@@ -38,10 +38,6 @@ WGRAD_SIDE_STREAM = os.environ.get('DUALVAR_WGRAD_STREAM', '1') != '0'
 SIDE_LAUNCHES = ('conv_wgrad', 'gate_db')
 # side launches issued per main-stream event (the event marker costs the main stream a few microseconds each)
 WGRAD_BATCH = 4
-# Independent convs that follow one another in the forward list (the two separable branches of an Inception level, its merged entry
-# conv and the pool branch's 1x1x1: backbone/s3dg.py:93-134 runs the four branches of a block on the same input) are issued on two
-# streams: the main stream and a branch stream forked / joined with one event each way.  0 = off (A/B; bench.py's calibration step).
-BRANCH_STREAMS = os.environ.get('DUALVAR_BRANCH_STREAMS', '0') != '0'
 # BatchNorm + ReLU whose only consumer is a max-pool (the stems) run fused with it (module switch: the tests compare both forms)
 FUSE_BN_POOL = True
 # conv -> BatchNorm -> conv with a single reader: the BatchNorm-backward reduce can run in the second conv's data-gradient
@@ -507,8 +503,6 @@ class Plan:
         self._zero_words = 0         # fp32 words that must be zero at the start of every backward (atomic targets)
         self.zero_arena = None
         self._side = None            # side stream + events of run_backward
-        self._branch = None          # branch stream + events of run_forward (BRANCH_STREAMS)
-        self.f_pairs = set()         # id(launch): the NEXT launch of f_list is independent of it and may run beside it
         self._events = None
         self.grad_ready = None       # callable(plan, lo): gradient-arena elements [lo, total) are final (GradSync.attach)
         self.fp8_pointwise = False   # compute mode 'fp8pw' (backbone/base.py: set_compute_dtype)
@@ -738,28 +732,10 @@ class Plan:
         for op in self.ops:
             f, b = op.launches()
             self.f_list += f
-            op._f = f
             op._b = b
         for op in reversed(self.ops):
             self.b_list += op._b
         self.b_list = overlap_bn_exchange(self.b_list)
-        # forward pairs for the branch stream: two conv launches in a row whose ops do not feed one another
-        by_launch = {}
-        for op in self.ops:
-            if isinstance(op, ConvOp):
-                for l in getattr(op, '_f', ()):
-                    by_launch[id(l)] = op
-        i = 0
-        while i + 1 < len(self.f_list):
-            a, b = self.f_list[i], self.f_list[i + 1]
-            oa, ob = by_launch.get(id(a)), by_launch.get(id(b))
-            if (oa is not None and ob is not None and oa is not ob and a.name == 'conv_fwd' and b.name == 'conv_fwd'
-                    and len(oa._f) == 1 and len(ob._f) == 1 and ob.x.buf is not oa.y.buf and oa.y.buf is not ob.y.buf
-                    and (ob.bn_in is None or ob.bn_in.x.buf is not oa.y.buf)):
-                self.f_pairs.add(id(a))
-                i += 2
-            else:
-                i += 1
 
     # ------------------------------------------------------------------ execution
     def _run(self, lst):
@@ -773,39 +749,10 @@ class Plan:
                 t(l, s)
 
     def run_forward(self):
-        if not BRANCH_STREAMS or not self.f_pairs:
-            return self._run(self.f_list)
-        main = torch.cuda.current_stream(self.device)
-        if self._branch is None:
-            self._branch = torch.cuda.Stream(device=self.device)
-            self._branch_ev = [(torch.cuda.Event(), torch.cuda.Event()) for _ in self.f_pairs]
-        br = self._branch
-        sm, sb = main.cuda_stream, br.cuda_stream
-        t = self.timer
-        lst, i, k = self.f_list, 0, 0
-        while i < len(lst):
-            l = lst[i]
-            if id(l) in self.f_pairs:
-                ev0, ev1 = self._branch_ev[k]
-                k += 1
-                ev0.record(main)
-                br.wait_event(ev0)
-                for q, s_, so in ((lst[i + 1], sb, br), (l, sm, None)):      # the partner first: it is the shorter one
-                    if t is None:
-                        q(s_)
-                    elif so is None:
-                        t(q, s_)
-                    else:
-                        t(q, s_, so)
-                ev1.record(br)
-                main.wait_event(ev1)
-                i += 2
-                continue
-            if t is None:
-                l(sm)
-            else:
-                t(l, sm)
-            i += 1
+        # (Independent convs of an Inception level on a second stream, forked / joined with one event each way -- 27 pairs per pass --
+        # were measured again in round 4, with the LDS-staged kernels that can share a CU: 16.97 -> 17.10 ms, three A/B pairs.  The
+        # event hops cost more than the overlap of two 20 - 70 us kernels gains.  Not kept.)
+        self._run(self.f_list)
 
     def run_backward(self):
         """Weight gradients leave the critical path: a conv's wgrad needs only the finished gradient of its own
