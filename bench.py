@@ -92,6 +92,17 @@ def total_loss(ret):
     return loss
 
 
+def kernel_of(label):
+    """the GPU function (template instantiation) behind a launch label: the LDS-staged kernel's forward and data gradient are ONE
+    instantiation (the tap displacement is a runtime sign), and so is a data gradient with or without the fused BatchNorm-backward
+    reduce (a runtime pointer) -- what rocprofv3 lists as one kernel is one entry here.  `+bn_in` / `+bn_bwd_apply` stay: those
+    are template parameters."""
+    label = label.replace('+bn_reduce', '')
+    if label.startswith('conv_tap<'):
+        label = label.replace('FWD,', '').replace('DGRAD,', '')
+    return label
+
+
 class KernelTimer:
     """HIP-event timing of plan launches on the stream they are launched on (torch's current stream)."""
 
@@ -102,7 +113,7 @@ class KernelTimer:
     def __call__(self, launch, stream, stream_obj=None):
         """stream: raw hipStream_t the launch goes to; stream_obj: its torch stream when it is not the current one
         (the plan issues weight gradients on a side stream) -- the events are recorded on the launch's own stream"""
-        if self.only is not None and launch.kname != self.only:
+        if self.only is not None and kernel_of(launch.kname) != self.only:
             launch(stream)
             return
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -116,11 +127,11 @@ class KernelTimer:
             b.record(stream_obj)
         self.rec.append((launch, a, b))
 
-    def summary(self):
-        """{kname: [n, total_ms, total_bytes, total_flops]} (call after a device sync)"""
+    def summary(self, key=lambda k: k):
+        """{key(kname): [n, total_ms, total_bytes, total_flops]} (call after a device sync)"""
         out = {}
         for l, a, b in self.rec:
-            e = out.setdefault(l.kname, [0, 0.0, 0, 0])
+            e = out.setdefault(key(l.kname), [0, 0.0, 0, 0])
             e[0] += 1
             e[1] += a.elapsed_time(b)
             e[2] += l.bytes
@@ -345,7 +356,8 @@ def run_leg(args, dtype, rank, world, distributed, dev):
                 us = a.elapsed_time(b) * 1e3
                 fh.write('%s\t%s\t%.1f\t%.0f\t%.1f\t%d\t%d\t%s\n' % (l.name, l.kname, us, l.bytes / us / 1e3, l.flops / us / 1e6,
                                                                      l.bytes, l.flops, getattr(l, 'shape', '')))
-    dominant = max((k for k in csum if not k.startswith('host:')), key=lambda k: csum[k][1])
+    ksum = cal.summary(kernel_of)       # per GPU function: the dominant KERNEL is chosen (and timed live) at this granularity
+    dominant = max((k for k in ksum if not k.startswith('host:')), key=lambda k: ksum[k][1])
     probe = KernelTimer(only=dominant)
     for p in all_plans(model):
         p.timer = probe
@@ -374,7 +386,7 @@ def run_leg(args, dtype, rank, world, distributed, dev):
 
     print(f'[bench] {dtype}: timed region: {args.steps} steps in {dt:.3f} s', file=sys.stderr, flush=True)
     clips = world * B * V * args.steps
-    n, ms, nbytes, flops = probe.summary()[dominant]
+    n, ms, nbytes, flops = probe.summary(kernel_of)[dominant]
     avg_ms = ms / n
     bw = nbytes / n / (avg_ms * 1e-3) / 1e9              # GB/s algorithmic
     tf = flops / n / (avg_ms * 1e-3) / 1e12
@@ -397,7 +409,7 @@ def run_leg(args, dtype, rank, world, distributed, dev):
     except Exception:
         traffic = None
     # the same kernel alone on the GPU (calibration step, one stream): what the kernel itself achieves
-    cn, cms, cbytes, cflops = csum[dominant]
+    cn, cms, cbytes, cflops = ksum[dominant]
     iso_bw, iso_tf = cbytes / (cms * 1e-3) / 1e9, cflops / (cms * 1e-3) / 1e12
     roof['isolated'] = {'avg_launch_us': round(cms / cn * 1e3, 2), 'GB/s': round(iso_bw, 1), 'TFLOP/s': round(iso_tf, 2),
                         'frac_hbm': round(iso_bw / HBM_PEAK_GBS, 4), 'frac_mfma': round(iso_tf / MFMA_PEAK_TF[dtype], 4)}
@@ -408,7 +420,7 @@ def run_leg(args, dtype, rank, world, distributed, dev):
         roof['note'] = ('fp32 products = 6 bf16 MFMAs per 32x32x16 block (exact 3-way bf16 split of both operands): `peak` is the '
                         'fp32 matrix peak of the guide, `split_peak` the bf16 dense peak / 6')
     roof.update({'traffic': traffic, 'kernel': dominant, 'launches_per_step': n // args.steps,
-                 'avg_launch_us': round(avg_ms * 1e3, 2), 'share_of_kernel_time': round(csum[dominant][1] / tot_ms, 3),
+                 'avg_launch_us': round(avg_ms * 1e3, 2), 'share_of_kernel_time': round(ksum[dominant][1] / tot_ms, 3),
                  'other_bound_frac': round(min(f_hbm, f_mfma), 4),
                  'algorithmic_bytes_per_launch': round(nbytes / n),
                  'algorithmic_flops_per_launch': round(flops / n),
