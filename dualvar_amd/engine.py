@@ -37,7 +37,11 @@ WGRAD_SIDE_STREAM = os.environ.get('DUALVAR_WGRAD_STREAM', '1') != '0'
 # backward launches whose results only the optimizer reads: weight gradients, the gate FCs' bias gradients
 SIDE_LAUNCHES = ('conv_wgrad', 'gate_db')
 # side launches issued per main-stream event (the event marker costs the main stream a few microseconds each)
-WGRAD_BATCH = 4
+WGRAD_BATCH = int(os.environ.get('DUALVAR_WGRAD_BATCH', '4'))
+# ... but a LARGE weight gradient is released at once (it then runs beside its own layer's data gradient): batched, the last
+# ones of a pass -- the stem's and Conv_2c's, 0.4 - 0.6 ms each -- waited for the end of the main chain although their operands
+# had been ready for up to a millisecond (tools/step_timeline.py: 1.6 ms of the step ran nothing but those)
+WGRAD_FLUSH_FLOPS = float(os.environ.get('DUALVAR_WGRAD_FLUSH_GFLOP', '3')) * 1e9
 # BatchNorm + ReLU whose only consumer is a max-pool (the stems) run fused with it (module switch: the tests compare both forms)
 FUSE_BN_POOL = True
 # conv -> BatchNorm -> conv with a single reader: the BatchNorm-backward reduce can run in the second conv's data-gradient
@@ -793,7 +797,7 @@ class Plan:
             if nm in SIDE_LAUNCHES or (nm == 'stem_pad_taps' and last_side):
                 pending.append(l)
                 last_side = True
-                if len(pending) >= WGRAD_BATCH:
+                if len(pending) >= WGRAD_BATCH or l.flops >= WGRAD_FLUSH_FLOPS:
                     flush()
             else:
                 last_side = False
