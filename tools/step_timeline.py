@@ -60,6 +60,10 @@ def main():
     print('main queue idle inside the step: %.3f ms; largest gaps:' % (sum(g[0] for g in gaps) / 1e6))
     for g in gaps[:8]:
         print('   %7.1f us between %s and %s' % (g[0] / 1e3, g[1], g[2]))
+    # how much of that idle time is the ordinary kernel-to-kernel latency of one queue, and how much is the GPU waiting for the host
+    for lo, hi in ((0, 3e3), (3e3, 6e3), (6e3, 12e3), (12e3, 30e3), (30e3, 1e12)):
+        sel = [g[0] for g in gaps if lo <= g[0] < hi]
+        print('   gaps of %4.0f .. %-6s us: %4d, %.3f ms' % (lo / 1e3, ('%.0f' % (hi / 1e3)) if hi < 1e11 else 'inf', len(sel), sum(sel) / 1e6))
 
 
 if __name__ == '__main__':
