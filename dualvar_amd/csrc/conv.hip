@@ -22,6 +22,8 @@ int dvt_conv_tap_launch(const void* conv_args, int mode, void* stream);
 int64_t dvt_bn_ws_floats(int64_t rows, int np);
 int dvt_conv_pp_rows(const void* conv_args, int mode);
 int dvt_conv_pp_launch(const void* conv_args, int mode, void* stream);
+// dv_conv3d_dgrad_bn's reduce over what a data gradient has written (conv_experiments.hip); the argument is a ConvArgs*
+void dvx_dgrad_bn_tail_launch(const void* conv_args, int is_f32, void* stream);
 
 namespace {
 
@@ -455,7 +457,7 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
     // tests/test_ops_gpu.py::test_fp32_partial_tiles_do_not_write_behind_the_output).  No LDS staging, no barrier, no
     // per-element address arithmetic (what made the per-element form of round 1 slow).
     bool direct = false;
-    if constexpr (EO == 4) direct = full_tile && a.out_bytes > 0 && a.cls_on != 1 && a.bn_x == nullptr;
+    if constexpr (EO == 4) direct = full_tile && a.out_bytes > 0 && a.cls_on != 1;
     if (direct) {
       const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
       const unsigned ldo4 = (unsigned)a.ldo * 4u;
@@ -544,63 +546,6 @@ __attribute__((amdgpu_waves_per_eu(conv_waves_per_simd(sizeof(T), GVB, BM, BN)))
       }
     }
     }   // !direct
-    // BatchNorm-backward reduce fused into the data gradient (ConvArgs::bn_x, dv_conv3d_dgrad_bn).  A pass of its own over the
-    // tile this workgroup has just written (read back from L2) and the matching tile of the BatchNorm's input: at this point
-    // the accumulators are dead, so it costs the kernel no registers -- inside the store loop it took 20-30 VGPRs and a
-    // resident workgroup per CU from every data gradient, fused or not.
-    constexpr int CPT = BN * EO / 16;                // 16-byte chunks per tile row
-    constexpr bool BNRED = (MODE == MODE_DGRAD) && sizeof(T) != 1 && (NT % CPT == 0);
-    if constexpr (BNRED) {
-      if (a.bn_x != nullptr) {
-        constexpr int RG = NT / CPT;                 // row groups: thread = (row group, chunk), the chunk is fixed
-        static_assert(RG * 2 * BN * 4 <= (int)sizeof(smem), "bn reduce scratch");
-        const int ch = tid % CPT, rg = tid / CPT, col0 = n0 + ch * EPC;
-        float mu[EPC], is[EPC], sc[EPC], sh[EPC], s1[EPC], s2[EPC];
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-          const bool ok = col0 + e < a.N;
-          mu[e] = ok ? a.bn_mean[col0 + e] : 0.f;
-          is[e] = ok ? a.bn_invstd[col0 + e] : 0.f;
-          sc[e] = (ok && a.bn_mask) ? a.bn_scale[col0 + e] : 0.f;
-          sh[e] = (ok && a.bn_mask) ? a.bn_shift[col0 + e] : 0.f;
-          s1[e] = s2[e] = 0.f;
-        }
-        __syncthreads();                             // the tile's stores are visible to the whole workgroup
-        if (col0 < a.NP) {
-          const int rows_here = min(BM, a.M - m0);
-          for (int r = rg; r < rows_here; r += RG) {
-            const size_t orow = out_row(m0 + r);
-            float gq[EPC], xq[EPC];
-            Pack16<OT>::load(out + orow * a.ldo + col0, gq);
-            Pack16<OT>::load(reinterpret_cast<const OT*>(a.bn_x) + orow * a.bn_ldx + col0, xq);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-              const float act = xq[e] * sc[e] + sh[e];          // the forward's expression (dv_bn_apply), same rounding
-              const float gg = (a.bn_mask && !(act > 0.f)) ? 0.f : gq[e];
-              s1[e] += gg;
-              s2[e] += gg * (xq[e] - mu[e]) * is[e];
-            }
-          }
-        }
-        float* red = reinterpret_cast<float*>(smem);            // [RG][2][BN]
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-          red[(rg * 2 + 0) * BN + ch * EPC + e] = s1[e];
-          red[(rg * 2 + 1) * BN + ch * EPC + e] = s2[e];
-        }
-        __syncthreads();
-        // the row groups of a column in a fixed order; one atomic per column and sum into replica tile_m % bn_rep
-        // (dv_bn_bwd_reduce's layout, read by dv_bn_bwd_apply)
-        if (tid < BN && n0 + tid < a.N) {
-          float t1 = 0.f, t2 = 0.f;
-          for (int w = 0; w < RG; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
-          const int cpb = (a.N + 7) & ~7;
-          float* dst = a.bn_sums + (size_t)(tile_m % a.bn_rep) * 2 * cpb + n0 + tid;
-          atomicAdd(dst, t1);
-          atomicAdd(dst + cpb, t2);
-        }
-      }
-    }
   }
 
   if constexpr (STATS_MODE && sizeof(T) == 4) {
@@ -2033,6 +1978,50 @@ extern "C" int dv_conv3d_dgrad_fp8(const dv_conv_desc* d, const void* dy8, const
   return dv_launch_status();
 }
 
+// the launches of one data gradient (`a` complete): parity classes / LDS-staged kernel / K split over the waves / conv_gemm
+static int dgrad_launch(const dv_conv_desc* d, ConvArgs& a, bool w3, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  a.cls_on = 0;
+  const bool strided = d->st > 1 || d->sh > 1 || d->sw > 1;
+  if (strided && d->kt >= d->st && d->kh >= d->sh && d->kw >= d->sw) {
+    // one dense stride-1 launch per parity class of the input positions (see ConvArgs): every class has >= 1 tap
+    ConvArgs cls[8];
+    const int ncls = dgrad_classes(d, a, cls);
+    if (w3) {
+      // pre-split weights: every class on the LDS-staged input-tile kernel (conv_tap.hip, temporal form), or not at all
+      for (int i = 0; i < ncls; ++i)
+        if (!dvt_conv_tap_kind(&cls[i], MODE_DGRAD)) return DV_EUNSUPPORTED;
+      for (int i = 0; i < ncls; ++i) dvt_conv_tap_launch(&cls[i], MODE_DGRAD, stream);
+      return dv_launch_status();
+    }
+    if (a.bn_ws) return DV_EUNSUPPORTED;
+    for (int i = 0; i < ncls; ++i) {
+      ConvArgs& c = cls[i];
+      int bm, bn;
+      pick_tile(d->dtype, c.M, c.NP, bm, bn);
+      c.ntn = (c.NP + bn - 1) / bn;
+      const int grid = c.ntn * ((c.M + bm - 1) / bm);
+      if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, c, grid, s);
+      else launch_gemm<bf16_t, MODE_DGRAD, 16>(bm, bn, c, grid, s);
+    }
+    return dv_launch_status();
+  }
+  trim_dead_taps(a, MODE_DGRAD, d->dtype);
+  if (d->dtype == DV_F32 && w3 && dvt_conv_tap_launch(&a, MODE_DGRAD, stream)) return dv_launch_status();
+  if (a.bn_ws) return DV_EUNSUPPORTED;           // (the ordered fused reduce exists on the LDS-staged kernel only)
+  int bm, bn;
+  pick_tile(d->dtype, a.M, a.NP, bm, bn);
+  a.ntn = (a.NP + bn - 1) / bn;
+  const int grid = a.ntn * ((a.M + bm - 1) / bm);
+  if (const int kbn = ks_tile(d->dtype, a, bm)) {
+    launch_ks<MODE_DGRAD>(kbn, a, s);
+    return dv_launch_status();
+  }
+  if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, a, grid, s);
+  else launch_gemm<bf16_t, MODE_DGRAD, 16>(bm, bn, a, grid, s);
+  return dv_launch_status();
+}
+
 static int dgrad_impl(const dv_conv_desc* d, const void* dy, const void* wd, void* dx, const dv_bn_reduce* bnr, void* stream,
                       void* bn_ws = nullptr, int64_t bn_ws_bytes = 0) {
   int rc = check_desc(d);
@@ -2085,46 +2074,17 @@ static int dgrad_impl(const dv_conv_desc* d, const void* dy, const void* wd, voi
     }
     a.fCP = make_fastdiv((uint32_t)a.g.CP);
   }
-  hipStream_t s = (hipStream_t)stream;
-  a.cls_on = 0;
-  const bool strided = d->st > 1 || d->sh > 1 || d->sw > 1;
-  if (strided && d->kt >= d->st && d->kh >= d->sh && d->kw >= d->sw) {
-    // one dense stride-1 launch per parity class of the input positions (see ConvArgs): every class has >= 1 tap
-    ConvArgs cls[8];
-    const int ncls = dgrad_classes(d, a, cls);
-    if (w3) {
-      // pre-split weights: every class on the LDS-staged input-tile kernel (conv_tap.hip, temporal form), or not at all
-      for (int i = 0; i < ncls; ++i)
-        if (!dvt_conv_tap_kind(&cls[i], MODE_DGRAD)) return DV_EUNSUPPORTED;
-      for (int i = 0; i < ncls; ++i) dvt_conv_tap_launch(&cls[i], MODE_DGRAD, stream);
-      return dv_launch_status();
-    }
-    if (a.bn_ws) return DV_EUNSUPPORTED;
-    for (int i = 0; i < ncls; ++i) {
-      ConvArgs& c = cls[i];
-      int bm, bn;
-      pick_tile(d->dtype, c.M, c.NP, bm, bn);
-      c.ntn = (c.NP + bn - 1) / bn;
-      const int grid = c.ntn * ((c.M + bm - 1) / bm);
-      if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, c, grid, s);
-      else launch_gemm<bf16_t, MODE_DGRAD, 16>(bm, bn, c, grid, s);
-    }
+  if (bnr && !bn_ws) {
+    // dv_conv3d_dgrad_bn, the atomic form: the plain data gradient on whatever kernel takes it, then the reduce over what it wrote
+    ConvArgs tail = a;
+    a.bn_x = nullptr;
+    const int rc2 = dgrad_launch(d, a, w3, stream);
+    if (rc2) return rc2;
+    tail.out_bytes = a.out_bytes;
+    dvx_dgrad_bn_tail_launch(&tail, d->dtype == DV_F32 ? 1 : 0, stream);
     return dv_launch_status();
   }
-  trim_dead_taps(a, MODE_DGRAD, d->dtype);
-  if (d->dtype == DV_F32 && w3 && dvt_conv_tap_launch(&a, MODE_DGRAD, stream)) return dv_launch_status();
-  if (a.bn_ws) return DV_EUNSUPPORTED;           // (the ordered fused reduce exists on the LDS-staged kernel only)
-  int bm, bn;
-  pick_tile(d->dtype, a.M, a.NP, bm, bn);
-  a.ntn = (a.NP + bn - 1) / bn;
-  const int grid = a.ntn * ((a.M + bm - 1) / bm);
-  if (const int kbn = ks_tile(d->dtype, a, bm)) {
-    launch_ks<MODE_DGRAD>(kbn, a, s);
-    return dv_launch_status();
-  }
-  if (d->dtype == DV_F32) launch_gemm<float, MODE_DGRAD, 16>(bm, bn, a, grid, s);
-  else launch_gemm<bf16_t, MODE_DGRAD, 16>(bm, bn, a, grid, s);
-  return dv_launch_status();
+  return dgrad_launch(d, a, w3, stream);
 }
 
 extern "C" int dv_conv3d_dgrad(const dv_conv_desc* d, const void* dy, const void* wd, void* dx, void* stream) {

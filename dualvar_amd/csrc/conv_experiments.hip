@@ -374,6 +374,74 @@ __attribute__((amdgpu_waves_per_eu(wgrad_f32s_waves_per_simd(BI, BJ, ROWS, NS)))
       wgrad_store_block(a, split, i0 + i * 32, j0 + wj0 + j * 32 + l31, h, acc[i][j]);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// dv_conv3d_dgrad_bn, the ATOMIC form of the BatchNorm-backward reduce behind a data gradient (engine.FUSE_BN_REDUCE, off by
+// default; rounds 1 - 3 carried it as a tail inside conv_gemm_kernel): a pass over the tile rows the data gradient has just
+// written (L2-resident for the layers it was meant for) and the BatchNorm's input, sum g and sum g * xhat per column, one atomic
+// per column and 128-row tile into replica tile % n_rep.  Measured a loss on every step it was tried on; kept as a
+// tested entry point.  The ORDERED form that the default plan uses lives in conv_tap.hip (dv_conv3d_dgrad_bn_ws).
+struct BnTailArgs {
+  const void* g;          // dL/dy as written by the data gradient, [M][ldg]
+  const void* x;          // the BatchNorm's input, [M][ldx]
+  const float *mean, *invstd, *scale, *shift;
+  float* sums;            // [n_rep][2][cp8(N)]
+  int M, N, NP, ldg, ldx, n_rep, mask;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void dgrad_bn_tail_kernel(BnTailArgs a) {
+  constexpr int BM = 128, BN = 64, NT = 256, EO = (int)sizeof(T), EPC = 16 / EO, CPT = BN * EO / 16, RG = NT / CPT;
+  __shared__ float red[RG * 2 * BN];
+  const int tid = threadIdx.x;
+  const int ntn = (a.NP + BN - 1) / BN;
+  const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int ch = tid % CPT, rg = tid / CPT, col0 = n0 + ch * EPC;
+  float mu[EPC], is[EPC], sc[EPC], sh[EPC], s1[EPC], s2[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    const bool ok = col0 + e < a.N;
+    mu[e] = ok ? a.mean[col0 + e] : 0.f;
+    is[e] = ok ? a.invstd[col0 + e] : 0.f;
+    sc[e] = (ok && a.mask) ? a.scale[col0 + e] : 0.f;
+    sh[e] = (ok && a.mask) ? a.shift[col0 + e] : 0.f;
+    s1[e] = s2[e] = 0.f;
+  }
+  if (col0 < a.NP) {
+    const int rows_here = min(BM, a.M - m0);
+    const T* g = reinterpret_cast<const T*>(a.g);
+    const T* x = reinterpret_cast<const T*>(a.x);
+    for (int r = rg; r < rows_here; r += RG) {
+      const size_t row = (size_t)(m0 + r);
+      float gq[EPC], xq[EPC];
+      Pack16<T>::load(g + row * a.ldg + col0, gq);
+      Pack16<T>::load(x + row * a.ldx + col0, xq);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float act = xq[e] * sc[e] + sh[e];          // the forward's expression (dv_bn_apply), same rounding
+        const float gg = (a.mask && !(act > 0.f)) ? 0.f : gq[e];
+        s1[e] += gg;
+        s2[e] += gg * (xq[e] - mu[e]) * is[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    red[(rg * 2 + 0) * BN + ch * EPC + e] = s1[e];
+    red[(rg * 2 + 1) * BN + ch * EPC + e] = s2[e];
+  }
+  __syncthreads();
+  if (tid < BN && n0 + tid < a.N) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int w = 0; w < RG; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
+    const int cpb = (a.N + 7) & ~7;
+    float* dst = a.sums + (size_t)(tile_m % a.n_rep) * 2 * cpb + n0 + tid;
+    atomicAdd(dst, t1);
+    atomicAdd(dst + cpb, t2);
+  }
+}
+
 }  // namespace
 
 // ---- entry points for conv.hip (plain C++ symbols of the shared object's own translation units; the argument block is
@@ -392,4 +460,15 @@ void dvx_launch_wgrad_f32s(int cfg, const void* args, int grid, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (cfg == 0) hipLaunchKernelGGL((conv_wgrad_f32s_kernel<64, 256, 16, 3>), dim3(grid), dim3(256), 0, s, aa);
   else hipLaunchKernelGGL((conv_wgrad_f32s_kernel<128, 128, 16, 3>), dim3(grid), dim3(256), 0, s, aa);
+}
+
+// entry point for conv.hip (dv_conv3d_dgrad_bn): the reduce over what the data gradient `a` (ConvArgs) has written
+void dvx_dgrad_bn_tail_launch(const void* conv_args, int is_f32, void* stream) {
+  const ConvArgs& c = *static_cast<const ConvArgs*>(conv_args);
+  BnTailArgs t;
+  t.g = c.out; t.x = c.bn_x; t.mean = c.bn_mean; t.invstd = c.bn_invstd; t.scale = c.bn_scale; t.shift = c.bn_shift;
+  t.sums = c.bn_sums; t.M = c.M; t.N = c.N; t.NP = c.NP; t.ldg = c.ldo; t.ldx = c.bn_ldx; t.n_rep = c.bn_rep; t.mask = c.bn_mask;
+  const int grid = ((c.NP + 63) / 64) * ((c.M + 127) / 128);
+  if (is_f32) hipLaunchKernelGGL((dgrad_bn_tail_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, t);
+  else hipLaunchKernelGGL((dgrad_bn_tail_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, t);
 }
