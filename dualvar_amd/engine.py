@@ -38,10 +38,17 @@ WGRAD_SIDE_STREAM = os.environ.get('DUALVAR_WGRAD_STREAM', '1') != '0'
 SIDE_LAUNCHES = ('conv_wgrad', 'gate_db')
 # side launches issued per main-stream event (the event marker costs the main stream a few microseconds each)
 WGRAD_BATCH = int(os.environ.get('DUALVAR_WGRAD_BATCH', '4'))
-# ... but a LARGE weight gradient is released at once (it then runs beside its own layer's data gradient): batched, the last
-# ones of a pass -- the stem's and Conv_2c's, 0.4 - 0.6 ms each -- waited for the end of the main chain although their operands
-# had been ready for up to a millisecond (tools/step_timeline.py: 1.6 ms of the step ran nothing but those)
+# ... but a LARGE weight gradient (>= WGRAD_FLUSH_FLOPS) is released at once and runs beside its own layer's data gradient --
+# where that pays.  Batched, the last ones of an S3D-G pass (the stem's and Conv_2c's, 0.4 - 0.6 ms each) waited for the end of the
+# main chain although their operands had been ready for up to a millisecond (tools/step_timeline.py: 1.6 ms of the step ran
+# nothing but those; 0.65 ms now), step 16.41 -> 16.15 ms.  It pays where the main chain has bandwidth-bound work for the weight
+# gradients to run beside (BatchNorm backward, pools, gating); where the chain is as matrix-bound as they are, two such kernels
+# on one GPU are slower than one after the other: R3D 26.5 -> 27.6 ms, even for its last four only.  The plan decides from its own
+# composition: estimated time of the chain's non-conv launches / of its data gradients (S3D-G 1.03, r50 0.93, R(2+1)D 0.65 --
+# measured gain, gain, neutral --, R3D 0.27 -- measured loss): early release at >= WGRAD_EARLY_RATIO.
 WGRAD_FLUSH_FLOPS = float(os.environ.get('DUALVAR_WGRAD_FLUSH_GFLOP', '3')) * 1e9
+WGRAD_EARLY_RATIO = 0.5
+WGRAD_EARLY = os.environ.get('DUALVAR_WGRAD_EARLY', 'auto')        # 'auto' | '0' | '1' (A/B)
 # BatchNorm + ReLU whose only consumer is a max-pool (the stems) run fused with it (module switch: the tests compare both forms)
 FUSE_BN_POOL = True
 # conv -> BatchNorm -> conv with a single reader: the BatchNorm-backward reduce can run in the second conv's data-gradient
@@ -507,6 +514,7 @@ class Plan:
         self._zero_words = 0         # fp32 words that must be zero at the start of every backward (atomic targets)
         self.zero_arena = None
         self._side = None            # side stream + events of run_backward
+        self.wgrad_early = False     # large weight gradients leave for the side stream at once (finalize decides)
         self._events = None
         self.grad_ready = None       # callable(plan, lo): gradient-arena elements [lo, total) are final (GradSync.attach)
         self.fp8_pointwise = False   # compute mode 'fp8pw' (backbone/base.py: set_compute_dtype)
@@ -740,6 +748,10 @@ class Plan:
         for op in reversed(self.ops):
             self.b_list += op._b
         self.b_list = overlap_bn_exchange(self.b_list)
+        # early release of the large weight gradients: see WGRAD_EARLY_RATIO
+        t_conv = sum(max(l.flops / 1.5e14, l.bytes / 4e12) for l in self.b_list if l.name == 'conv_dgrad')
+        t_other = sum(l.bytes / 4e12 for l in self.b_list if l.name != 'conv_dgrad' and l.name not in SIDE_LAUNCHES)
+        self.wgrad_early = (t_other >= WGRAD_EARLY_RATIO * t_conv) if WGRAD_EARLY == 'auto' else WGRAD_EARLY == '1'
 
     # ------------------------------------------------------------------ execution
     def _run(self, lst):
@@ -792,12 +804,13 @@ class Plan:
                 else:
                     t(q, ss, side)
             pending.clear()
+        early = self.wgrad_early
         for l in self.b_list:
             nm = l.name
             if nm in SIDE_LAUNCHES or (nm == 'stem_pad_taps' and last_side):
                 pending.append(l)
                 last_side = True
-                if len(pending) >= WGRAD_BATCH or l.flops >= WGRAD_FLUSH_FLOPS:
+                if len(pending) >= WGRAD_BATCH or (early and l.flops >= WGRAD_FLUSH_FLOPS):
                     flush()
             else:
                 last_side = False
