@@ -59,7 +59,11 @@ FUSE_BN_REDUCE = False        # (module switch, no environment variable: tests/t
 # The same fusion in its ORDERED form on the LDS-staged input-tile kernel (dv_conv3d_dgrad_bn_ws: the sums come from the
 # accumulators and one read of the BatchNorm's input, tile rows are folded in tile order -- no float atomics): taken wherever the
 # consuming conv's data gradient runs on that kernel (fp32 mode: the separable pairs and the strided stem conv of S3D-G / R(2+1)D).
-FUSE_BN_REDUCE_TAP = os.environ.get('DUALVAR_FUSE_BN_REDUCE_TAP', '1') != '0'      # (A/B switch; tests monkeypatch the module attribute)
+# OFF by default since the end of round 4: while the step's tail was weight gradients waiting for the end of the main chain it was
+# a wash (data gradients +0.35 ms, reduce launches -0.25 ms, step equal); with the large weight gradients released early
+# (WGRAD_EARLY_RATIO) the main chain is the critical path again and the fusion costs 0.15 ms (16.23 vs 16.38 ms, three A/B pairs;
+# every K threshold between 512 and 2 900 lies in between).
+FUSE_BN_REDUCE_TAP = os.environ.get('DUALVAR_FUSE_BN_REDUCE_TAP', '0') != '0'      # (A/B switch; tests monkeypatch the module attribute)
 # ... only behind a long K loop (>= 512 = taps x channel pitch of dY) and never for the strided stem conv: the epilogue's read of
 # the BatchNorm input is exposed at the end of a workgroup's life, and for a short loop it costs more than the standalone reduce
 # saves -- all eight candidates of the S3D-G step fused: data gradients +740 us, reduce launches -565 us (the stem conv alone 422 ->

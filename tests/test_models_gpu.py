@@ -707,7 +707,7 @@ def test_fused_bn_reduce_plan_gives_the_same_gradients(gpu, monkeypatch, net, dt
 
 
 def test_ordered_fused_bn_reduce_on_the_lds_staged_kernel_at_headline_size(gpu, monkeypatch):
-    """engine.FUSE_BN_REDUCE_TAP (default on): where a conv -> BatchNorm -> conv chain's second conv runs its data gradient on the
+    """engine.FUSE_BN_REDUCE_TAP (optional plan, off by default since the end of round 4): where a conv -> BatchNorm -> conv chain's second conv runs its data gradient on the
     LDS-staged input-tile kernel, the BatchNorm backward's sums come out of that launch (dv_conv3d_dgrad_bn_ws: accumulators + one
     read of the BatchNorm input, per-tile rows folded in tile order).  The headline step (S3D-G, 64 x 2 clips of 8x112x112, fp32)
     with and without it: the same gradients up to the grouping of the fp32 row sums, and the fused plan is bit-reproducible."""
@@ -849,14 +849,17 @@ def test_batchnorm_on_load_plan_gives_the_same_bits(gpu, monkeypatch, net, clips
     assert torch.equal(grads[0], grads[1]), float((grads[0] - grads[1]).abs().max())
 
 
+@pytest.mark.parametrize('fused_reduce', [True, False], ids=['fused_bn_reduce', 'default_plan'])
 @pytest.mark.parametrize('net,clips', [('s3dg', 16), ('r21d', 4)])
-def test_repeated_passes_through_one_plan_give_the_same_bits(gpu, net, clips):
+def test_repeated_passes_through_one_plan_give_the_same_bits(gpu, monkeypatch, net, clips, fused_reduce):
     """The same forward + backward three times through one plan, no optimizer step in between: every pass must reproduce the first
     pass's gradients BIT FOR BIT.  What this guards: state that outlives a pass -- the ticket workspace the fused BatchNorm-backward
     reduces of a plan share (dv_conv3d_dgrad_bn_ws: launches of different shapes, hence different row layouts, in one buffer).  Its
     first version kept a launch's tickets behind its rows, where another shape's partial sums land: from the SECOND pass on the
     folds ran on garbage counts and the gradients were 10 % off, which no single-pass test could see."""
-    from dualvar_amd import model as M
+    from dualvar_amd import engine, model as M
+    if fused_reduce:
+        monkeypatch.setattr(engine, 'FUSE_BN_REDUCE_TAP', True)      # (the plan with the shared ticket workspace; off by default)
     block = torch.randn(clips, 2, 3, 8, 112, 112, generator=torch.Generator().manual_seed(3)).to(gpu)
     torch.manual_seed(0)
     m = M.SimCLR_Naked(net, 128, 0.07, False)
@@ -870,5 +873,13 @@ def test_repeated_passes_through_one_plan_give_the_same_bits(gpu, net, clips):
         torch.cuda.synchronize()
         grads.append(torch.cat([st.grad.detach().float().flatten().clone() for st in m.stores()]))
     assert bool(torch.isfinite(grads[0]).all())
+    if fused_reduce and not _lib_f32_exact():
+        plans = [pl for lst in m.encoder_q[0]._plans.values() for pl in lst]
+        assert sum(1 for pl in plans for op in pl.ops if getattr(op, 'bn_fuse_tap', False)) >= 2
     for it in (1, 2):
         assert torch.equal(grads[it], grads[0]), (it, float((grads[it] - grads[0]).abs().max()), float(grads[0].abs().max()))
+
+
+def _lib_f32_exact():
+    from dualvar_amd import _lib
+    return _lib.f32_exact()
