@@ -22,6 +22,11 @@
 // position base + l31 -- stride 48 B, conflict-free for ds_read_b128 at ANY base (3 is odd: the 16 lanes of a read group hit 16
 // different 16-byte slots), so a tap offset costs nothing.
 //
+// Variants of the one kernel (template parameters): BM = 128-row tiles for launches of less than one full round of workgroups (the
+// 12 544-row levels; tap_bm); BNL = the BatchNorm (+ReLU) in front of the conv applied to the staged slab (dv_conv3d_fwd_bn_in: the
+// activation between a 1xkxk -> kx1x1 pair is never written); and, further down, conv_pp_fwd_kernel: the RGB stem's forward as
+// tiles of whole output lines over pixel pairs.
+//
 // Activations go global -> VGPR -> split -> LDS (not LDS-DMA: the fp32 staging copy would cost 16 - 24 KB of LDS per stage and a
 // resident workgroup).  The loads of chunk c + 1 are issued at the start of chunk c and consumed at its end; they are inline
 // assembly with their own counted s_waitcnt so that the compiler's wait-count pass, which cannot see the LDS-DMA weight pieces,
